@@ -1,0 +1,627 @@
+/*
+ * lb_oracle.c -- TEST INFRASTRUCTURE ONLY (see lb_oracle.h).
+ *
+ * A CPU restatement of the reference algorithm for the lattice-Boltzmann
+ * hot path: collision, halo swap, propagation and the conserved-moment
+ * statistics. Written from the reference's behaviour; each function cites
+ * the reference file:line it follows. Summation orders follow the reference
+ * (modes summed over p = 0..nvel-1, populations over m = 0..nvel-1) and the
+ * file is compiled with -ffp-contract=off so that no FMA contraction
+ * changes the rounding relative to the reference's x86-64 gcc -O build.
+ *
+ * Parity status: PINNED by tests/golden (compiled-reference outputs) and by
+ * the reference regression logs; see tests/test_oracle_golden.py.
+ */
+
+#include <float.h>
+#include <math.h>
+#include <stddef.h>
+#include <string.h>
+
+#include "lb_oracle.h"
+
+enum {X = 0, Y = 1, Z = 2};
+enum {NHYDRO = 10};                    /* 1 + 3 + 6, lb_data.h:140 */
+enum {MAP_FLUID = 0};                  /* map.h:23 */
+
+static const double cs2 = (1.0/3.0);   /* LB_CS2_DOUBLE, lb_data.h:149 */
+
+/* Velocity sets and weights: values of lb_d3q19.h:26-38, lb_d3q27.h:28-43 */
+
+static const int8_t cv19[19][3] = {
+  { 0, 0, 0},
+  { 1, 1, 0}, { 1, 0, 1}, { 1, 0, 0}, { 1, 0,-1}, { 1,-1, 0},
+  { 0, 1, 1}, { 0, 1, 0}, { 0, 1,-1}, { 0, 0, 1}, { 0, 0,-1},
+  { 0,-1, 1}, { 0,-1, 0}, { 0,-1,-1},
+  {-1, 1, 0}, {-1, 0, 1}, {-1, 0, 0}, {-1, 0,-1}, {-1,-1, 0}};
+
+static int weight19(const int8_t c[3]) {
+  int c2 = c[X]*c[X] + c[Y]*c[Y] + c[Z]*c[Z];
+  return (c2 == 0) ? 12 : ((c2 == 1) ? 2 : 1);          /* over 36 */
+}
+
+static int weight27(const int8_t c[3]) {
+  int c2 = c[X]*c[X] + c[Y]*c[Y] + c[Z]*c[Z];
+  return (c2 == 0) ? 64 : ((c2 == 1) ? 16 : ((c2 == 2) ? 4 : 1)); /* /216 */
+}
+
+/*
+ * lbo_model_create
+ *
+ * cv, wv: lb_d3q19.h / lb_d3q27.h. ma: lb_d3q19.c:107-153,
+ * lb_d3q27.c:150-195. na[m] = 1/sum_p wv[p] ma[m][p]^2 (lb_d3q19.c:69-77).
+ * mi[p][m] = wv[p] na[m] ma[m][p] (model.c:381-387).
+ */
+
+int lbo_model_create(int nvel, lbo_model_t * model) {
+
+  if (model == NULL) return -1;
+  if (nvel != 19 && nvel != 27) return -1;
+
+  memset(model, 0, sizeof(lbo_model_t));
+  model->nvel = nvel;
+
+  if (nvel == 19) {
+    for (int p = 0; p < 19; p++) {
+      for (int ia = 0; ia < 3; ia++) model->cv[p][ia] = cv19[p][ia];
+      model->wv[p] = weight19(cv19[p])/36.0;
+    }
+  }
+  else {
+    /* D3Q27: p = 0 is rest; then x slowest, z fastest from (-1,-1,-1),
+     * skipping the rest vector (lb_d3q27.h:28-34) */
+    int p = 1;
+    for (int ix = -1; ix <= 1; ix++) {
+      for (int iy = -1; iy <= 1; iy++) {
+	for (int iz = -1; iz <= 1; iz++) {
+	  if (ix == 0 && iy == 0 && iz == 0) continue;
+	  model->cv[p][X] = ix; model->cv[p][Y] = iy; model->cv[p][Z] = iz;
+	  p += 1;
+	}
+      }
+    }
+    for (p = 0; p < 27; p++) model->wv[p] = weight27(model->cv[p])/216.0;
+  }
+
+  for (int p = 0; p < nvel; p++) {
+    double cx = 1.0*model->cv[p][X];
+    double cy = 1.0*model->cv[p][Y];
+    double cz = 1.0*model->cv[p][Z];
+    double (* ma)[LBO_NVEL_MAX] = model->ma;
+
+    ma[0][p] = 1.0;
+    ma[1][p] = cx;
+    ma[2][p] = cy;
+    ma[3][p] = cz;
+    ma[4][p] = cx*cx - cs2;
+    ma[5][p] = cx*cy;
+    ma[6][p] = cx*cz;
+    ma[7][p] = cy*cy - cs2;
+    ma[8][p] = cy*cz;
+    ma[9][p] = cz*cz - cs2;
+
+    if (nvel == 19) {
+      double c2   = cx*cx + cy*cy + cz*cz;
+      double chi1 = (2.0*c2 - 3.0)*(3.0*cz*cz - c2);
+      double chi2 = (2.0*c2 - 3.0)*(cy*cy - cx*cx);
+      double chi3 = 3.0*c2*c2 - 6.0*c2 + 1;
+      ma[10][p] = chi1;
+      ma[11][p] = chi1*cx;
+      ma[12][p] = chi1*cy;
+      ma[13][p] = chi1*cz;
+      ma[14][p] = chi2;
+      ma[15][p] = chi2*cx;
+      ma[16][p] = chi2*cy;
+      ma[17][p] = chi2*cz;
+      ma[18][p] = chi3;
+    }
+    else {
+      double hx = cx*cx - cs2;
+      double hy = cy*cy - cs2;
+      double hz = cz*cz - cs2;
+      ma[10][p] = 3.0*hx*cy;
+      ma[11][p] = 3.0*hx*cz;
+      ma[12][p] = 3.0*hy*cz;
+      ma[13][p] = 3.0*hy*cx;
+      ma[14][p] = 3.0*hz*cx;
+      ma[15][p] = 3.0*hz*cy;
+      ma[16][p] = cx*cy*cz;
+      ma[17][p] = 9.0*hx*hy;
+      ma[18][p] = 9.0*hy*hz;
+      ma[19][p] = 9.0*hz*hx;
+      ma[20][p] = 9.0*hx*cy*cz;
+      ma[21][p] = 9.0*hy*cz*cx;
+      ma[22][p] = 9.0*hz*cx*cy;
+      ma[23][p] = 9.0*hx*hy*cz;
+      ma[24][p] = 9.0*hy*hz*cx;
+      ma[25][p] = 9.0*hz*hx*cy;
+      ma[26][p] = 27.0*hx*hy*hz;
+    }
+  }
+
+  for (int m = 0; m < nvel; m++) {
+    double wip = 0.0;
+    for (int p = 0; p < nvel; p++) {
+      wip += model->wv[p]*model->ma[m][p]*model->ma[m][p];
+    }
+    model->na[m] = 1.0/wip;
+  }
+
+  for (int p = 0; p < nvel; p++) {
+    for (int m = 0; m < nvel; m++) {
+      model->mi[p][m] = model->wv[p]*model->na[m]*model->ma[m][p];
+    }
+  }
+
+  return 0;
+}
+
+int lbo_nsite(const lbo_param_t * p) {
+  int nh2 = 2*p->nhalo;
+  return (p->nlocal[X] + nh2)*(p->nlocal[Y] + nh2)*(p->nlocal[Z] + nh2);
+}
+
+static void strides(const lbo_param_t * p, int nall[3], ptrdiff_t str[3]) {
+  for (int ia = 0; ia < 3; ia++) nall[ia] = p->nlocal[ia] + 2*p->nhalo;
+  str[Z] = 1;
+  str[Y] = nall[Z];
+  str[X] = (ptrdiff_t) nall[Y]*nall[Z];       /* coords.c:211-215 */
+}
+
+/*
+ * Relaxation rates for the single-fluid kernel: collision.c:1287-1300
+ * (shear), :1339-1373 (bulk), :1443-1538 (ghosts; scheme-driven).
+ */
+
+static int relaxation_rates(const lbo_param_t * p, double * rtau_shear,
+			    double * rtau_bulk, double rtau_ghost[LBO_NVEL_MAX]) {
+
+  double eta = p->eta_shear;
+  double rtau = 1.0/(0.5 + eta/(p->rho0*cs2));
+
+  *rtau_shear = rtau;
+
+  for (int m = 0; m < LBO_NVEL_MAX; m++) rtau_ghost[m] = 0.0;
+
+  switch (p->scheme) {
+  case LBO_M10:
+    *rtau_bulk = 1.0/(0.5 + p->eta_bulk/(p->rho0*cs2));
+    for (int m = NHYDRO; m < p->nvel; m++) rtau_ghost[m] = 1.0;
+    break;
+  case LBO_BGK:
+    *rtau_bulk = rtau;
+    for (int m = NHYDRO; m < p->nvel; m++) rtau_ghost[m] = rtau;
+    break;
+  case LBO_TRT:
+    {
+      /* Only defined for nvel = 19 here (the reference leaves the d3q27
+       * ghost rates uninitialised: collision.c:1487-1534). */
+      double tau = eta/(p->rho0*cs2);
+      double rtau_odd = 0.5 + 2.0*tau/(tau + 3.0/8.0);
+      if (rtau_odd > 2.0) rtau_odd = 2.0;
+      if (p->nvel != 19) return -1;
+      *rtau_bulk = 1.0/(0.5 + p->eta_bulk/(p->rho0*cs2));
+      rtau_ghost[10] = rtau; rtau_ghost[14] = rtau; rtau_ghost[18] = rtau;
+      rtau_ghost[11] = rtau_odd; rtau_ghost[12] = rtau_odd;
+      rtau_ghost[13] = rtau_odd; rtau_ghost[15] = rtau_odd;
+      rtau_ghost[16] = rtau_odd; rtau_ghost[17] = rtau_odd;
+    }
+    break;
+  default:
+    return -1;
+  }
+
+  return 0;
+}
+
+/*
+ * lbo_collide
+ *
+ * Single-fluid collision for all interior sites: lb_collision_mrt1_site,
+ * collision.c:259-599 (fluctuations off, no free-energy stress, constant
+ * viscosity). Non-fluid sites are left untouched (collision.c:299-304,
+ * 581-595). force may be NULL (zero field); status may be NULL (all fluid).
+ * rho, u (SoA, addr_rank1(nsite,3,index,ia) = nsite*ia + index) may be NULL.
+ *
+ * The reference also "collides" the y/z halo sites in the x-interior range
+ * (kernel.c:194-209); those results are overwritten by lb_halo and are not
+ * reproduced here.
+ */
+
+int lbo_collide(const lbo_param_t * p, double * f, const double * force,
+		const char * status, double * rho_out, double * u_out) {
+
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+  int nvel = p->nvel;
+  double rtau, rtau_bulk, rtau_ghost[LBO_NVEL_MAX];
+  lbo_model_t model;
+  const double rdim = 1.0/3.0;
+
+  if (lbo_model_create(nvel, &model) != 0) return -1;
+  if (relaxation_rates(p, &rtau, &rtau_bulk, rtau_ghost) != 0) return -1;
+
+  /* REFERENCE QUIRK, reproduced on purpose. For D3Q19 the reference does
+   * not use lb->param->ma in the collision but the unrolled literal
+   * d3q19_f2mode_chunk, and that routine multiplies f[4] by 0 instead of
+   * ma[13][4] = chi1*cz = -1 when forming mode 13 (collision.c:2300,
+   * "mode[13] += fchunk[4]*c0"). All other 721 literal coefficients of
+   * f2mode/mode2f equal ma and mi = wv*na*ma. The effect is invisible with
+   * M10 (ghost modes are discarded) but changes BGK and TRT results, which
+   * keep (1 - rtau_ghost) of mode 13. Parity means matching the reference,
+   * so the collision transform (only) carries the same coefficient. */
+  if (nvel == 19) model.ma[13][4] = 0.0;
+
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+
+  #pragma omp parallel for collapse(2) schedule(static)
+  for (int ic = 1; ic <= p->nlocal[X]; ic++) {
+    for (int jc = 1; jc <= p->nlocal[Y]; jc++) {
+      for (int kc = 1; kc <= p->nlocal[Z]; kc++) {
+
+	ptrdiff_t index = str[X]*(p->nhalo + ic - 1)
+	  + str[Y]*(p->nhalo + jc - 1) + (p->nhalo + kc - 1);
+	double mode[LBO_NVEL_MAX];
+	double fl[LBO_NVEL_MAX];
+	double frc[3], u[3];
+	double s[3][3], seq[3][3];
+	double rho, rrho, tr_s, tr_seq;
+	int m;
+
+	if (status && status[index] != MAP_FLUID) continue;
+
+	for (int q = 0; q < nvel; q++) fl[q] = f[nsite*q + index];
+
+	for (int ia = 0; ia < 3; ia++) {
+	  frc[ia] = p->fbody[ia];
+	  if (force) frc[ia] += force[nsite*ia + index];
+	}
+
+	/* f -> modes (collision.c:338-349) */
+	for (m = 0; m < nvel; m++) {
+	  double sum = 0.0;
+	  for (int q = 0; q < nvel; q++) sum += fl[q]*model.ma[m][q];
+	  mode[m] = sum;
+	}
+
+	rho = mode[0];
+	m = 0;
+	for (int ia = 0; ia < 3; ia++) {
+	  for (int ib = ia; ib < 3; ib++) {
+	    s[ia][ib] = mode[4 + m];
+	    s[ib][ia] = mode[4 + m];
+	    m++;
+	  }
+	}
+
+	/* velocity with half-force (collision.c:376-382) */
+	rrho = 1.0/rho;
+	for (int ia = 0; ia < 3; ia++) u[ia] = rrho*(mode[1+ia] + 0.5*frc[ia]);
+
+	/* stress relaxation (collision.c:408-474) */
+	tr_s = 0.0; tr_seq = 0.0;
+	for (int ia = 0; ia < 3; ia++) {
+	  for (int ib = 0; ib < 3; ib++) seq[ia][ib] = rho*u[ia]*u[ib];
+	  tr_s   += s[ia][ia];
+	  tr_seq += seq[ia][ia];
+	}
+	for (int ia = 0; ia < 3; ia++) {
+	  s[ia][ia]   -= rdim*tr_s;
+	  seq[ia][ia] -= rdim*tr_seq;
+	}
+	tr_s = tr_s - rtau_bulk*(tr_s - tr_seq);
+
+	for (int ia = 0; ia < 3; ia++) {
+	  for (int ib = 0; ib < 3; ib++) {
+	    double dab = (ia == ib);
+	    s[ia][ib] -= rtau*(s[ia][ib] - seq[ia][ib]);
+	    s[ia][ib] += dab*rdim*tr_s;
+	    s[ia][ib] += (2.0 - rtau)*(u[ia]*frc[ib] + frc[ia]*u[ib]);
+	  }
+	}
+
+	/* post-collision modes (collision.c:523-544) */
+	for (int ia = 0; ia < 3; ia++) mode[1+ia] += frc[ia];
+	m = 0;
+	for (int ia = 0; ia < 3; ia++) {
+	  for (int ib = ia; ib < 3; ib++) {
+	    mode[4 + m] = s[ia][ib];
+	    m++;
+	  }
+	}
+	for (m = NHYDRO; m < nvel; m++) {
+	  mode[m] = mode[m] - rtau_ghost[m]*(mode[m] - 0.0);
+	}
+
+	/* modes -> f (collision.c:548-559) */
+	for (int q = 0; q < nvel; q++) {
+	  double sum = 0.0;
+	  for (m = 0; m < nvel; m++) sum += model.mi[q][m]*mode[m];
+	  f[nsite*q + index] = sum;
+	}
+
+	if (rho_out) rho_out[index] = rho;
+	if (u_out) {
+	  for (int ia = 0; ia < 3; ia++) u_out[nsite*ia + index] = u[ia];
+	}
+      }
+    }
+  }
+
+  return 0;
+}
+
+/*
+ * lbo_halo
+ *
+ * Net effect on one rank with periodic boundaries of lb_halo() with the
+ * LB_HALO_TARGET scheme, i.e. halo_swap_packed (halo_swap.c:709-1063) with
+ * nswap = 1: three sequential passes X, Y, Z; each copies the first/last
+ * interior plane (full extent, *including* halo, in the other two
+ * directions) to the opposite width-1 halo layer adjacent to the interior,
+ * so that edges and corners are completed by the later passes (that is what
+ * the host corner fill of halo_swap.c:893-915,968-1012 achieves). With
+ * nhalo > 1 only the layer next to the interior is filled.
+ *
+ * data has nel components in SoA order: data[nsite*n + index].
+ */
+
+int lbo_halo(const lbo_param_t * p, int nel, double * data) {
+
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+  int nh = p->nhalo;
+
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+
+  for (int id = 0; id < 3; id++) {
+    int d1 = (id + 1) % 3;
+    int d2 = (id + 2) % 3;
+    /* plane coordinates (0-based, in nall): source lo/hi, destination */
+    int src_lo = nh;                      /* first interior plane */
+    int src_hi = nh + p->nlocal[id] - 1;  /* last interior plane */
+    int dst_lo = nh - 1;                  /* halo plane below */
+    int dst_hi = nh + p->nlocal[id];      /* halo plane above */
+
+    #pragma omp parallel for schedule(static)
+    for (int n = 0; n < nel; n++) {
+      double * d = data + nsite*n;
+      for (int i1 = 0; i1 < nall[d1]; i1++) {
+	for (int i2 = 0; i2 < nall[d2]; i2++) {
+	  ptrdiff_t off = str[d1]*i1 + str[d2]*i2;
+	  d[off + str[id]*dst_lo] = d[off + str[id]*src_hi];
+	  d[off + str[id]*dst_hi] = d[off + str[id]*src_lo];
+	}
+      }
+    }
+  }
+
+  return 0;
+}
+
+/*
+ * lbo_propagate
+ *
+ * Pull streaming, lb_propagation_kernel (propagation.c:162-212):
+ * fprime[index, p] = f[index - cv[p].str, p] for interior sites; the 1-d
+ * iteration covers whole x-planes imin..imax (kernel.c:172-188: kindex0 is
+ * the first site of plane imin, extent nlocal[X]*nall[Y]*nall[Z]), so y/z
+ * halo sites in those planes copy in place (mask = 0, kernel.c:374-400).
+ * The x halo planes of fprime are not written. Pointer swap (propagation.c:223-252) is the
+ * caller's business.
+ */
+
+int lbo_propagate(const lbo_param_t * p, const double * f, double * fprime) {
+
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+  int nh = p->nhalo;
+  lbo_model_t model;
+
+  if (lbo_model_create(p->nvel, &model) != 0) return -1;
+
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+
+  #pragma omp parallel for collapse(2) schedule(static)
+  for (int q = 0; q < p->nvel; q++) {
+    for (int i = nh; i < nh + p->nlocal[X]; i++) {
+      ptrdiff_t dp = model.cv[q][X]*str[X] + model.cv[q][Y]*str[Y]
+	+ model.cv[q][Z]*str[Z];
+      for (int j = 0; j < nall[Y]; j++) {
+	for (int k = 0; k < nall[Z]; k++) {
+	  ptrdiff_t index = str[X]*i + str[Y]*j + k;
+	  int interior = (j >= nh && j < nh + p->nlocal[Y] &&
+			  k >= nh && k < nh + p->nlocal[Z]);
+	  fprime[nsite*q + index] = f[nsite*q + index - (interior ? dp : 0)];
+	}
+      }
+    }
+  }
+
+  return 0;
+}
+
+/*
+ * lbo_moments
+ *
+ * out[0..4]: volume, sum rho, sum rho^2, min rho, max rho over fluid sites
+ *            (stats_distribution_print, stats_distribution.c:55-117; plain
+ *            sums in x,y,z order; rho summed over p = 0..nvel-1 as
+ *            lb_0th_moment, model.c:819-833).
+ * out[5..7]: total momentum sum_p f_p c_p over fluid sites with Kahan
+ *            compensation over p = 1..nvel-1 (distribution_gm_kernel,
+ *            stats_distribution.c:281-350; kahan_add_double util_sum.c:30).
+ *            The reference's accumulation order across sites depends on its
+ *            thread decomposition; here sites are visited in x,y,z order by
+ *            one accumulator (the serial, one-thread order).
+ * out[8]   : unused (0).
+ */
+
+typedef struct {double sum; double cs;} kahan_acc_t;
+
+static void kahan_add_val(kahan_acc_t * k, double val) {
+  volatile double y = val + k->cs;
+  volatile double t = k->sum + y;
+  k->cs  = y - (t - k->sum);
+  k->sum = t;
+}
+
+int lbo_moments(const lbo_param_t * p, const double * f, const char * status,
+		double out[9]) {
+
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+  lbo_model_t model;
+  kahan_acc_t g[3] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+
+  if (lbo_model_create(p->nvel, &model) != 0) return -1;
+
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+
+  out[0] = 0.0; out[1] = 0.0; out[2] = 0.0;
+  out[3] = +DBL_MAX; out[4] = -DBL_MAX;
+  out[8] = 0.0;
+
+  for (int ic = 1; ic <= p->nlocal[X]; ic++) {
+    for (int jc = 1; jc <= p->nlocal[Y]; jc++) {
+      for (int kc = 1; kc <= p->nlocal[Z]; kc++) {
+	ptrdiff_t index = str[X]*(p->nhalo + ic - 1)
+	  + str[Y]*(p->nhalo + jc - 1) + (p->nhalo + kc - 1);
+	double rho = 0.0;
+	if (status && status[index] != MAP_FLUID) continue;
+	for (int q = 0; q < p->nvel; q++) rho += f[nsite*q + index];
+	out[0] += 1.0;
+	out[1] += rho;
+	out[2] += rho*rho;
+	if (rho < out[3]) out[3] = rho;
+	if (rho > out[4]) out[4] = rho;
+	for (int q = 1; q < p->nvel; q++) {
+	  double fq = f[nsite*q + index];
+	  kahan_add_val(&g[X], fq*model.cv[q][X]);
+	  kahan_add_val(&g[Y], fq*model.cv[q][Y]);
+	  kahan_add_val(&g[Z], fq*model.cv[q][Z]);
+	}
+      }
+    }
+  }
+
+  out[5] = g[X].sum + g[X].cs;
+  out[6] = g[Y].sum + g[Y].cs;
+  out[7] = g[Z].sum + g[Z].cs;
+
+  return 0;
+}
+
+/*
+ * lbo_equilibrium
+ *
+ * Second-order equilibrium, lb_1st_moment_equilib_set (model.c:915-941):
+ * f_p = rho w_p (1 + 3 u.c + 4.5 (c c - delta/3):uu) with the reference's
+ * loop order for the double contraction.
+ */
+
+int lbo_equilibrium(const lbo_model_t * m, double rho, const double u[3],
+		    double * feq) {
+
+  for (int p = 0; p < m->nvel; p++) {
+    double rcs2 = 1.0/cs2;
+    double udotc = 0.0;
+    double sdotq = 0.0;
+    for (int ia = 0; ia < 3; ia++) {
+      udotc += u[ia]*m->cv[p][ia];
+      for (int ib = 0; ib < 3; ib++) {
+	double dab = (ia == ib);
+	sdotq += (m->cv[p][ia]*m->cv[p][ib] - cs2*dab)*u[ia]*u[ib];
+      }
+    }
+    feq[p] = rho*m->wv[p]*(1.0 + rcs2*udotc + 0.5*rcs2*rcs2*sdotq);
+  }
+
+  return 0;
+}
+
+/*
+ * lbo_init_synthetic
+ *
+ * The seeded synthetic state of SURVEY.md section 8(d) (the same generator
+ * as oracle/ref_driver.c:init_f, which produced the golden vectors):
+ * equilibrium of rho = 1 + 0.01 cos(2 pi (x/Lx + y/Ly + z/Lz)),
+ * u = 0.01 (sin 2 pi y/Ly, sin 2 pi z/Lz, sin 2 pi x/Lx), each population
+ * multiplied by (1 + 1e-3 (r - 1/2)), r from the 32-bit LCG
+ * s = 1664525 s + 1013904223 (seed 12345) advanced in global (x,y,z,p)
+ * order. ntotal is the global box, noffset the offset of this sub-domain
+ * (zero for a single domain). Halo sites are set to zero.
+ */
+
+static void lcg_jump(uint32_t n, uint32_t * amul, uint32_t * cadd) {
+  /* (a, c) of the n-fold composition of s -> 1664525 s + 1013904223 */
+  uint32_t a = 1u, c = 0u;
+  uint32_t ab = 1664525u, cb = 1013904223u;
+  while (n) {
+    if (n & 1u) { a = ab*a; c = ab*c + cb; }
+    cb = (ab + 1u)*cb;
+    ab = ab*ab;
+    n >>= 1;
+  }
+  *amul = a; *cadd = c;
+}
+
+int lbo_init_synthetic(const lbo_param_t * p, const int ntotal[3],
+		       const int noffset[3], double * f) {
+
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+  lbo_model_t model;
+  const double pi = 3.14159265358979323846;
+
+  if (lbo_model_create(p->nvel, &model) != 0) return -1;
+
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+  memset(f, 0, sizeof(double)*nsite*p->nvel);
+
+  #pragma omp parallel for collapse(2) schedule(static)
+  for (int ic = 1; ic <= p->nlocal[X]; ic++) {
+    for (int jc = 1; jc <= p->nlocal[Y]; jc++) {
+      /* global position of the first site of this z-row in LCG order */
+      int ig = noffset[X] + ic - 1;
+      int jg = noffset[Y] + jc - 1;
+      uint64_t n0 = (((uint64_t) ig*ntotal[Y] + jg)*ntotal[Z] + noffset[Z])
+	*(uint64_t) p->nvel;
+      uint32_t a, c, s;
+      lcg_jump((uint32_t) (n0 & 0xffffffffu), &a, &c);
+      s = a*12345u + c;
+      for (int kc = 1; kc <= p->nlocal[Z]; kc++) {
+	ptrdiff_t index = str[X]*(p->nhalo + ic - 1)
+	  + str[Y]*(p->nhalo + jc - 1) + (p->nhalo + kc - 1);
+	double x = (ig*1.0)/ntotal[X];
+	double y = (jg*1.0)/ntotal[Y];
+	double z = (noffset[Z] + kc - 1.0)/ntotal[Z];
+	double rho = 1.0 + 0.01*cos(2.0*pi*(x + y + z));
+	double u[3];
+	double feq[LBO_NVEL_MAX];
+	u[X] = 0.01*sin(2.0*pi*y);
+	u[Y] = 0.01*sin(2.0*pi*z);
+	u[Z] = 0.01*sin(2.0*pi*x);
+	lbo_equilibrium(&model, rho, u, feq);
+	for (int q = 0; q < p->nvel; q++) {
+	  double r;
+	  s = 1664525u*s + 1013904223u;
+	  r = s/4294967296.0;
+	  f[nsite*q + index] = feq[q]*(1.0 + 1.0e-3*(r - 0.5));
+	}
+      }
+    }
+  }
+
+  return 0;
+}

@@ -1,0 +1,65 @@
+/*
+ * lb_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C99) of the reference lattice-Boltzmann hot path
+ * (zazu29/ludwig v0.20.1). Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library; the product
+ * (ludwig_amd/) never does.
+ *
+ * Parity status: PINNED. Checked against golden vectors produced by the
+ * compiled reference itself (oracle/_ref, built by oracle/Makefile; fixtures
+ * in tests/golden/, generator oracle/make_golden.py) and against the
+ * conserved quantities in the reference's own regression logs
+ * (tests/regression/d3q19-short/serial-dist-*.log).
+ *
+ * Storage is the reference's SoA ("reverse") order, memory.h:187-188:
+ *   f[(n*nvel + p)*nsite + index]
+ *   index = (nhalo+ic-1)*nall[Y]*nall[Z] + (nhalo+jc-1)*nall[Z] + (nhalo+kc-1)
+ * (coords.c:211-215,617-631), 1-based interior coordinates.
+ */
+
+#ifndef LB_ORACLE_H
+#define LB_ORACLE_H
+
+#include <stdint.h>
+
+#define LBO_NVEL_MAX 27
+
+enum lbo_scheme {LBO_M10 = 0, LBO_BGK = 1, LBO_TRT = 2}; /* lb_data_options.h:23-25 */
+
+typedef struct lbo_model_s {
+  int nvel;
+  int8_t cv[LBO_NVEL_MAX][3];
+  double wv[LBO_NVEL_MAX];
+  double na[LBO_NVEL_MAX];
+  double ma[LBO_NVEL_MAX][LBO_NVEL_MAX];
+  double mi[LBO_NVEL_MAX][LBO_NVEL_MAX];
+} lbo_model_t;
+
+typedef struct lbo_param_s {
+  int nvel;
+  int nlocal[3];
+  int nhalo;
+  int scheme;              /* enum lbo_scheme */
+  double rho0;
+  double eta_shear;
+  double eta_bulk;
+  double fbody[3];         /* global body force density */
+} lbo_param_t;
+
+int lbo_model_create(int nvel, lbo_model_t * model);
+
+int lbo_nsite(const lbo_param_t * p);
+
+int lbo_collide(const lbo_param_t * p, double * f, const double * force,
+		const char * status, double * rho, double * u);
+int lbo_halo(const lbo_param_t * p, int nel, double * data);
+int lbo_propagate(const lbo_param_t * p, const double * f, double * fprime);
+int lbo_moments(const lbo_param_t * p, const double * f, const char * status,
+		double out[9]);
+int lbo_init_synthetic(const lbo_param_t * p, const int ntotal[3],
+		       const int noffset[3], double * f);
+int lbo_equilibrium(const lbo_model_t * m, double rho, const double u[3],
+		    double * feq);
+
+#endif

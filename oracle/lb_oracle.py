@@ -1,0 +1,169 @@
+"""ctypes/numpy front end of oracle/liblb_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py may
+import this module. The product (ludwig_amd/) never does.
+
+Arrays are numpy float64 in the reference's SoA order: f.shape == (nvel,
+nall_x, nall_y, nall_z), C-contiguous, i.e. f.ravel()[nsite*p + index]
+(reference memory.h:187-188, coords.c:617-631).
+"""
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liblb_oracle.so")
+
+M10, BGK, TRT = 0, 1, 2
+SCHEMES = {"m10": M10, "bgk": BGK, "trt": TRT}
+NVEL_MAX = 27
+
+
+class Param(ctypes.Structure):
+    _fields_ = [
+        ("nvel", ctypes.c_int),
+        ("nlocal", ctypes.c_int * 3),
+        ("nhalo", ctypes.c_int),
+        ("scheme", ctypes.c_int),
+        ("rho0", ctypes.c_double),
+        ("eta_shear", ctypes.c_double),
+        ("eta_bulk", ctypes.c_double),
+        ("fbody", ctypes.c_double * 3),
+    ]
+
+
+class Model(ctypes.Structure):
+    _fields_ = [
+        ("nvel", ctypes.c_int),
+        ("cv", (ctypes.c_int8 * 3) * NVEL_MAX),
+        ("wv", ctypes.c_double * NVEL_MAX),
+        ("na", ctypes.c_double * NVEL_MAX),
+        ("ma", (ctypes.c_double * NVEL_MAX) * NVEL_MAX),
+        ("mi", (ctypes.c_double * NVEL_MAX) * NVEL_MAX),
+    ]
+
+
+def build():
+    """Compile liblb_oracle.so (and oracle/_ref when /root/reference exists)."""
+    subprocess.run(["make", "-s", "-C", _HERE, "all"], check=True)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        dp = ctypes.c_void_p
+        pp = ctypes.POINTER(Param)
+        _lib.lbo_model_create.argtypes = [ctypes.c_int, ctypes.POINTER(Model)]
+        _lib.lbo_nsite.argtypes = [pp]
+        _lib.lbo_collide.argtypes = [pp, dp, dp, dp, dp, dp]
+        _lib.lbo_halo.argtypes = [pp, ctypes.c_int, dp]
+        _lib.lbo_propagate.argtypes = [pp, dp, dp]
+        _lib.lbo_moments.argtypes = [pp, dp, dp, dp]
+        _lib.lbo_init_synthetic.argtypes = [pp, dp, dp, dp]
+    return _lib
+
+
+def make_param(nvel, nlocal, nhalo=1, scheme=M10, eta=0.1, zeta=0.3,
+               rho0=1.0, fbody=(0.0, 0.0, 0.0)):
+    if isinstance(scheme, str):
+        scheme = SCHEMES[scheme]
+    p = Param()
+    p.nvel = nvel
+    p.nlocal[:] = list(nlocal)
+    p.nhalo = nhalo
+    p.scheme = scheme
+    p.rho0 = rho0
+    p.eta_shear = eta
+    p.eta_bulk = zeta
+    p.fbody[:] = list(fbody)
+    return p
+
+
+def nall(p):
+    return tuple(p.nlocal[i] + 2 * p.nhalo for i in range(3))
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def model(nvel):
+    m = Model()
+    rc = lib().lbo_model_create(nvel, ctypes.byref(m))
+    assert rc == 0
+    out = {
+        "nvel": nvel,
+        "cv": np.array([[m.cv[p][a] for a in range(3)] for p in range(nvel)],
+                       dtype=np.int8),
+        "wv": np.array(m.wv[:nvel]),
+        "na": np.array(m.na[:nvel]),
+        "ma": np.array([[m.ma[i][j] for j in range(nvel)]
+                        for i in range(nvel)]),
+        "mi": np.array([[m.mi[i][j] for j in range(nvel)]
+                        for i in range(nvel)]),
+    }
+    return out
+
+
+def collide(p, f, force=None, status=None, rho=None, u=None):
+    assert f.dtype == np.float64 and f.shape == (p.nvel,) + nall(p)
+    if status is not None:
+        assert status.dtype == np.int8
+    rc = lib().lbo_collide(ctypes.byref(p), _ptr(f), _ptr(force),
+                           _ptr(status), _ptr(rho), _ptr(u))
+    if rc != 0:
+        raise ValueError("lbo_collide: unsupported parameters")
+
+
+def halo(p, data):
+    nel = data.shape[0]
+    assert data.dtype == np.float64 and data.shape == (nel,) + nall(p)
+    rc = lib().lbo_halo(ctypes.byref(p), nel, _ptr(data))
+    assert rc == 0
+
+
+def propagate(p, f, fprime):
+    assert f.shape == fprime.shape == (p.nvel,) + nall(p)
+    rc = lib().lbo_propagate(ctypes.byref(p), _ptr(f), _ptr(fprime))
+    assert rc == 0
+
+
+def moments(p, f, status=None):
+    out = np.zeros(9)
+    rc = lib().lbo_moments(ctypes.byref(p), _ptr(f), _ptr(status), _ptr(out))
+    assert rc == 0
+    return out
+
+
+def init_synthetic(p, ntotal=None, noffset=(0, 0, 0)):
+    if ntotal is None:
+        ntotal = tuple(p.nlocal)
+    f = np.zeros((p.nvel,) + nall(p))
+    nt = np.array(ntotal, dtype=np.int32)
+    no = np.array(noffset, dtype=np.int32)
+    rc = lib().lbo_init_synthetic(ctypes.byref(p), _ptr(nt), _ptr(no), _ptr(f))
+    assert rc == 0
+    return f
+
+
+def step(p, f, fprime, force=None, status=None, rho=None, u=None):
+    """One reference time step: collide, halo, propagate (ludwig.c:802-860).
+
+    Returns (f_new, fprime_new): the arrays swapped as lb_model_swapf does.
+    """
+    collide(p, f, force, status, rho, u)
+    halo(p, f)
+    propagate(p, f, fprime)
+    return fprime, f

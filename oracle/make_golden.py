@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref).
+
+TEST INFRASTRUCTURE ONLY. Run in the development container, where
+/root/reference exists:
+
+    make -C oracle ref && python oracle/make_golden.py
+
+Each fixture holds inputs and the reference's outputs (data only) for one
+parameter set of the hot path lb_collide -> lb_halo -> lb_propagation
+(reference ludwig.c:802-860), produced by oracle/ref_driver.c linked against
+the reference objects built (with assertions on, -DADDR_SOA) from the sources
+under /root/reference. Arrays are raw float64 in the reference's SoA order,
+shape (nvel, nall_x, nall_y, nall_z) (hydro fields: (3, ...) or (...)).
+
+Keys: meta (JSON string), f0, force, f_collide, rho, u, f_prop, f_final and,
+for some cases, f_halo.
+"""
+
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "..", "tests", "golden")
+
+# name, nvel, (nx, ny, nz), nhalo, scheme, eta, zeta, fbody, fieldforce,
+# solid, nsteps, keep_halo
+CASES = [
+    ("q19_m10",         19, (6, 5, 4), 1, "m10", 0.1, 0.3, (0, 0, 0), 0, 0, 5, True),
+    ("q19_bgk",         19, (6, 5, 4), 1, "bgk", 0.1, 0.1, (0, 0, 0), 0, 0, 5, False),
+    ("q19_trt",         19, (6, 5, 4), 1, "trt", 0.05, 0.2, (0, 0, 0), 0, 0, 5, False),
+    ("q19_m10_fbody",   19, (6, 5, 4), 1, "m10", 0.1, 0.3, (1e-5, 2e-5, -3e-5), 0, 0, 5, False),
+    ("q19_bgk_ffield",  19, (6, 5, 4), 1, "bgk", 0.2, 0.2, (2e-6, 0, 1e-6), 1, 0, 5, False),
+    ("q19_trt_ffield",  19, (6, 5, 4), 1, "trt", 0.1, 0.3, (0, 1e-6, 0), 1, 0, 5, False),
+    ("q19_m10_nh2_ffield", 19, (6, 5, 4), 2, "m10", 0.1, 0.3, (0, 0, 0), 1, 0, 5, True),
+    ("q19_m10_solid",   19, (6, 5, 4), 1, "m10", 0.1, 0.3, (1e-5, 0, 0), 0, 1, 1, False),
+    ("q27_m10",         27, (6, 5, 4), 1, "m10", 0.1, 0.3, (0, 0, 0), 0, 0, 5, True),
+    ("q27_bgk",         27, (6, 5, 4), 1, "bgk", 0.1, 0.1, (0, 0, 0), 0, 0, 5, False),
+    ("q27_m10_ffield",  27, (6, 5, 4), 1, "m10", 0.1, 0.3, (1e-5, -1e-5, 2e-5), 1, 0, 5, False),
+    ("q27_bgk_nh2",     27, (5, 4, 6), 2, "bgk", 0.15, 0.15, (0, 0, 1e-5), 0, 0, 5, False),
+]
+
+
+def run_case(case, tmp):
+    (name, nvel, n, nhalo, scheme, eta, zeta, fb, ff, solid, nsteps,
+     keep_halo) = case
+    exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
+    prefix = os.path.join(tmp, name)
+    args = [exe, "dump", prefix, *map(str, n), str(nhalo), scheme,
+            repr(eta), repr(zeta), *[repr(float(x)) for x in fb],
+            str(ff), str(solid), str(nsteps)]
+    subprocess.run(args, check=True)
+    meta = json.load(open(prefix + ".json"))
+    meta["name"] = name
+    meta["scheme_name"] = scheme
+    nall = tuple(meta["nall"])
+
+    def load(key, lead):
+        a = np.fromfile("%s.%s.f64" % (prefix, key), dtype="<f8")
+        return a.reshape(lead + nall)
+
+    out = {"meta": np.array(json.dumps(meta))}
+    out["f0"] = load("f0", (nvel,))
+    out["force"] = load("force", (3,))
+    out["f_collide"] = load("f_collide", (nvel,))
+    out["rho"] = load("rho", ())
+    out["u"] = load("u", (3,))
+    if keep_halo:
+        out["f_halo"] = load("f_halo", (nvel,))
+    out["f_prop"] = load("f_prop", (nvel,))
+    out["f_final"] = load("f_final", (nvel,))
+    return out
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        for case in CASES:
+            out = run_case(case, tmp)
+            fn = os.path.join(GOLD, case[0] + ".npz")
+            np.savez_compressed(fn, **out)
+            print("wrote", fn, os.path.getsize(fn))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,339 @@
+/*****************************************************************************
+ *
+ *  ref_driver.c
+ *
+ *  TEST INFRASTRUCTURE ONLY (oracle side). Never linked into the product.
+ *
+ *  A small driver (our code) that links against the *compiled reference*
+ *  (objects built by oracle/Makefile from the sources where they lie under
+ *  /root/reference; outputs only in oracle/_ref/) and exercises the hot path
+ *  exactly as ludwig.c does per time step:
+ *
+ *      lb_collide()      reference src/collision.c:143   (ludwig.c:802)
+ *      lb_halo()         reference src/model.c:553       (ludwig.c:816)
+ *      lb_propagation()  reference src/propagation.c:43  (ludwig.c:860)
+ *
+ *  It has two jobs:
+ *   (1) "dump" mode: write golden vectors (raw little-endian doubles) for
+ *       the parity tests: tests/golden/ is produced from these by
+ *       oracle/make_golden.py;
+ *   (2) "time" mode: time the reference CPU path (the cpu_baseline leg of
+ *       bench.py, kind "reference").
+ *
+ *  NVEL is a compile-time choice in the reference (-D_D3Q19_ / -D_D3Q27_),
+ *  so one binary per model is built. Memory order is -DADDR_SOA.
+ *
+ *  Usage:
+ *    ref_driver dump <prefix> nx ny nz nhalo scheme eta zeta fx fy fz \
+ *               fieldforce solid nsteps
+ *    ref_driver time nx ny nz scheme eta zeta nsteps
+ *
+ *  scheme: m10 | bgk | trt
+ *
+ *****************************************************************************/
+
+#include <assert.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "pe.h"
+#include "coords.h"
+#include "physics.h"
+#include "lb_data.h"
+#include "collision.h"
+#include "propagation.h"
+#include "hydro.h"
+#include "map.h"
+#include "noise.h"
+
+#define PI_ 3.14159265358979323846
+
+typedef struct {
+  int ntotal[3];
+  int nhalo;
+  lb_relaxation_enum_t nrelax;
+  double eta, zeta;
+  double fbody[3];
+  int fieldforce;       /* per-site force field on/off */
+  int solid;            /* a block of MAP_BOUNDARY sites on/off */
+  int nsteps;
+} case_t;
+
+static uint32_t lcg_state = 12345u;
+
+static double lcg_uniform(void) {
+  lcg_state = 1664525u*lcg_state + 1013904223u;
+  return lcg_state/4294967296.0;
+}
+
+static double wtime(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1.0e-9*ts.tv_nsec;
+}
+
+static void dump(const char * prefix, const char * name, const double * a,
+		 size_t n) {
+  char fn[1024];
+  FILE * fp = NULL;
+  snprintf(fn, sizeof(fn), "%s.%s.f64", prefix, name);
+  fp = fopen(fn, "wb");
+  if (fp == NULL) { perror(fn); exit(1); }
+  if (fwrite(a, sizeof(double), n, fp) != n) { perror(fn); exit(1); }
+  fclose(fp);
+}
+
+static lb_relaxation_enum_t scheme_from_string(const char * s) {
+  if (strcmp(s, "m10") == 0) return LB_RELAXATION_M10;
+  if (strcmp(s, "bgk") == 0) return LB_RELAXATION_BGK;
+  if (strcmp(s, "trt") == 0) return LB_RELAXATION_TRT;
+  fprintf(stderr, "unknown scheme %s\n", s);
+  exit(1);
+}
+
+/* Synthetic initial condition of SURVEY.md section 8(d): second-order
+ * equilibrium of a smooth (rho, u) field times (1 + 1e-3 (r - 1/2)) with r
+ * from the 32-bit LCG advanced in (x,y,z,p) order. */
+
+static void init_f(cs_t * cs, lb_t * lb, const case_t * c) {
+
+  int nlocal[3];
+  cs_nlocal(cs, nlocal);
+  lcg_state = 12345u;
+
+  for (int ic = 1; ic <= nlocal[X]; ic++) {
+    for (int jc = 1; jc <= nlocal[Y]; jc++) {
+      for (int kc = 1; kc <= nlocal[Z]; kc++) {
+	int index = cs_index(cs, ic, jc, kc);
+	double x = (ic - 1.0)/c->ntotal[X];
+	double y = (jc - 1.0)/c->ntotal[Y];
+	double z = (kc - 1.0)/c->ntotal[Z];
+	double rho = 1.0 + 0.01*cos(2.0*PI_*(x + y + z));
+	double u[3];
+	u[X] = 0.01*sin(2.0*PI_*y);
+	u[Y] = 0.01*sin(2.0*PI_*z);
+	u[Z] = 0.01*sin(2.0*PI_*x);
+	lb_1st_moment_equilib_set(lb, index, rho, u);
+	for (int p = 0; p < lb->model.nvel; p++) {
+	  double f = 0.0;
+	  double r = lcg_uniform();
+	  lb_f(lb, index, p, LB_RHO, &f);
+	  lb_f_set(lb, index, p, LB_RHO, f*(1.0 + 1.0e-3*(r - 0.5)));
+	}
+      }
+    }
+  }
+}
+
+static void init_force(cs_t * cs, hydro_t * hydro, const case_t * c) {
+
+  int nlocal[3];
+  cs_nlocal(cs, nlocal);
+
+  for (int ic = 1; ic <= nlocal[X]; ic++) {
+    for (int jc = 1; jc <= nlocal[Y]; jc++) {
+      for (int kc = 1; kc <= nlocal[Z]; kc++) {
+	int index = cs_index(cs, ic, jc, kc);
+	double x = (ic - 1.0)/c->ntotal[X];
+	double y = (jc - 1.0)/c->ntotal[Y];
+	double z = (kc - 1.0)/c->ntotal[Z];
+	double f[3] = {0.0, 0.0, 0.0};
+	if (c->fieldforce) {
+	  f[X] = 1.0e-5*cos(2.0*PI_*x);
+	  f[Y] = 1.0e-5*cos(2.0*PI_*y);
+	  f[Z] = 1.0e-5*cos(2.0*PI_*z);
+	}
+	for (int ia = 0; ia < 3; ia++) {
+	  hydro->force->data[addr_rank1(hydro->nsite, 3, index, ia)] = f[ia];
+	}
+      }
+    }
+  }
+}
+
+/* A 2x2x2 block of MAP_BOUNDARY sites at (2..3, 2..3, 2..3) */
+
+static void init_map(cs_t * cs, map_t * map, const case_t * c) {
+  if (c->solid == 0) return;
+  for (int ic = 2; ic <= 3; ic++) {
+    for (int jc = 2; jc <= 3; jc++) {
+      for (int kc = 2; kc <= 3; kc++) {
+	map_status_set(map, cs_index(cs, ic, jc, kc), MAP_BOUNDARY);
+      }
+    }
+  }
+}
+
+int main(int argc, char ** argv) {
+
+  int timing = 0;
+  char prefix[512] = "";
+  case_t c = {0};
+
+  pe_t * pe = NULL;
+  cs_t * cs = NULL;
+  physics_t * phys = NULL;
+  lb_t * lb = NULL;
+  hydro_t * hydro = NULL;
+  map_t * map = NULL;
+  noise_t * noise = NULL;
+
+  if (argc >= 2 && strcmp(argv[1], "dump") == 0 && argc == 16) {
+    int a = 2;
+    strncpy(prefix, argv[a++], sizeof(prefix) - 1);
+    c.ntotal[X] = atoi(argv[a++]);
+    c.ntotal[Y] = atoi(argv[a++]);
+    c.ntotal[Z] = atoi(argv[a++]);
+    c.nhalo = atoi(argv[a++]);
+    c.nrelax = scheme_from_string(argv[a++]);
+    c.eta = atof(argv[a++]);
+    c.zeta = atof(argv[a++]);
+    c.fbody[X] = atof(argv[a++]);
+    c.fbody[Y] = atof(argv[a++]);
+    c.fbody[Z] = atof(argv[a++]);
+    c.fieldforce = atoi(argv[a++]);
+    c.solid = atoi(argv[a++]);
+    c.nsteps = atoi(argv[a++]);
+  }
+  else if (argc >= 2 && strcmp(argv[1], "time") == 0 && argc == 9) {
+    int a = 2;
+    timing = 1;
+    c.ntotal[X] = atoi(argv[a++]);
+    c.ntotal[Y] = atoi(argv[a++]);
+    c.ntotal[Z] = atoi(argv[a++]);
+    c.nhalo = 1;
+    c.nrelax = scheme_from_string(argv[a++]);
+    c.eta = atof(argv[a++]);
+    c.zeta = atof(argv[a++]);
+    c.nsteps = atoi(argv[a++]);
+  }
+  else {
+    fprintf(stderr, "usage: see header of ref_driver.c\n");
+    return 1;
+  }
+
+  MPI_Init(&argc, &argv);
+
+  pe_create(MPI_COMM_WORLD, PE_QUIET, &pe);
+  cs_create(pe, &cs);
+  cs_ntotal_set(cs, c.ntotal);
+  cs_nhalo_set(cs, c.nhalo);
+  cs_init(cs);
+
+  physics_create(pe, &phys);
+  physics_rho0_set(phys, 1.0);
+  physics_eta_shear_set(phys, c.eta);
+  physics_eta_bulk_set(phys, c.zeta);
+  physics_fbody_set(phys, c.fbody);
+
+  {
+    lb_data_options_t opts = lb_data_options_default();
+    opts.ndim = NDIM;
+    opts.nvel = NVEL;
+    opts.ndist = 1;
+    opts.nrelax = c.nrelax;
+    opts.halo = LB_HALO_TARGET;
+    lb_data_create(pe, cs, &opts, &lb);
+  }
+  {
+    hydro_options_t hopts = hydro_options_nhalo(1);
+    hydro_create(pe, cs, NULL, &hopts, &hydro);
+  }
+  map_create(pe, cs, 0, &map);
+  noise_create(pe, cs, &noise);
+  noise_init(noise, 0);
+  assert(noise->on[NOISE_RHO] == 0);
+
+  init_f(cs, lb, &c);
+  init_force(cs, hydro, &c);
+  init_map(cs, map, &c);
+
+  {
+    size_t nf = (size_t) lb->nsite*lb->model.nvel;
+    size_t ns = (size_t) lb->nsite;
+
+    if (timing == 0) {
+
+      dump(prefix, "f0", lb->f, nf);
+      dump(prefix, "force", hydro->force->data, 3*ns);
+
+      for (int n = 0; n < c.nsteps; n++) {
+	lb_collide(lb, hydro, map, noise, NULL, NULL);
+	if (n == 0) {
+	  dump(prefix, "f_collide", lb->f, nf);
+	  dump(prefix, "rho", hydro->rho->data, ns);
+	  dump(prefix, "u", hydro->u->data, 3*ns);
+	}
+	lb_halo(lb);
+	if (n == 0) dump(prefix, "f_halo", lb->f, nf);
+	lb_propagation(lb);
+	if (n == 0) dump(prefix, "f_prop", lb->f, nf);
+      }
+      dump(prefix, "f_final", lb->f, nf);
+      {
+	/* Header: everything a reader needs; consumed by make_golden.py */
+	char fn[1024];
+	FILE * fp = NULL;
+	int nall[3];
+	cs_nall(cs, nall);
+	snprintf(fn, sizeof(fn), "%s.json", prefix);
+	fp = fopen(fn, "w");
+	fprintf(fp, "{\"nvel\": %d, \"nlocal\": [%d, %d, %d], \"nhalo\": %d,"
+		" \"nall\": [%d, %d, %d], \"nsite\": %d, \"scheme\": %d,"
+		" \"eta\": %.17g, \"zeta\": %.17g, \"rho0\": 1.0,"
+		" \"fbody\": [%.17g, %.17g, %.17g], \"fieldforce\": %d,"
+		" \"solid\": %d, \"nsteps\": %d, \"layout\": \"soa\"}\n",
+		NVEL, c.ntotal[X], c.ntotal[Y], c.ntotal[Z], c.nhalo,
+		nall[X], nall[Y], nall[Z], lb->nsite, (int) c.nrelax,
+		c.eta, c.zeta, c.fbody[X], c.fbody[Y], c.fbody[Z],
+		c.fieldforce, c.solid, c.nsteps);
+	fclose(fp);
+      }
+    }
+    else {
+      double tc = 0.0, th = 0.0, tp = 0.0, t0, t1;
+      double sites = 1.0*c.ntotal[X]*c.ntotal[Y]*c.ntotal[Z];
+      int nthreads = 1;
+#ifdef _OPENMP
+      nthreads = omp_get_max_threads();
+#endif
+      /* one untimed warm-up step */
+      lb_collide(lb, hydro, map, noise, NULL, NULL);
+      lb_halo(lb);
+      lb_propagation(lb);
+      for (int n = 0; n < c.nsteps; n++) {
+	t0 = wtime();
+	lb_collide(lb, hydro, map, noise, NULL, NULL);
+	t1 = wtime(); tc += t1 - t0; t0 = t1;
+	lb_halo(lb);
+	t1 = wtime(); th += t1 - t0; t0 = t1;
+	lb_propagation(lb);
+	t1 = wtime(); tp += t1 - t0;
+      }
+      printf("{\"nvel\": %d, \"nlocal\": [%d, %d, %d], \"steps\": %d,"
+	     " \"threads\": %d, \"t_collide\": %.6f, \"t_halo\": %.6f,"
+	     " \"t_propagation\": %.6f, \"mlups\": %.4f}\n",
+	     NVEL, c.ntotal[X], c.ntotal[Y], c.ntotal[Z], c.nsteps, nthreads,
+	     tc, th, tp, 1.0e-6*sites*c.nsteps/(tc + th + tp));
+    }
+  }
+
+  noise_free(noise);
+  map_free(map);
+  hydro_free(hydro);
+  lb_free(lb);
+  physics_free(phys);
+  cs_free(cs);
+  pe_free(pe);
+
+  MPI_Finalize();
+
+  return 0;
+}

@@ -1,0 +1,79 @@
+"""Shared helpers for the tests: golden fixtures and comparison metrics."""
+
+import glob
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN_DIR = os.path.join(HERE, "golden")
+
+# Parity tolerances (BASELINE.json north_star: 1e-12 relative on conserved
+# density/momentum; SURVEY.md 8(d): max|df|/max|f| <= 1e-12).
+RTOL_F = 1.0e-12
+RTOL_CONSERVED = 1.0e-12
+
+
+def golden_names():
+    return sorted(os.path.basename(f)[:-4]
+                  for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    g["meta"] = json.loads(str(g["meta"]))
+    return g
+
+
+def interior(a, nhalo):
+    """Interior view of an array whose last three axes are (x, y, z)."""
+    h = nhalo
+    return a[..., h:-h, h:-h, h:-h]
+
+
+def xplanes(a, nhalo):
+    """Sites of the x-interior planes, with the width-1 y/z halo ring."""
+    h = nhalo
+    o = nhalo - 1
+    return a[..., h:-h, o:a.shape[-2] - o, o:a.shape[-1] - o]
+
+
+def shell1(a, nhalo):
+    """Interior plus the width-1 halo shell next to it.
+
+    This is the region lb_halo() defines (halo_swap.c, nswap = 1). Layers
+    further out (nhalo > 1) are not exchanged; in the reference they hold
+    whatever its unmasked halo-site collision left there (NaN from 0/0).
+    """
+    o = nhalo - 1
+    if o == 0:
+        return a
+    return a[..., o:-o, o:-o, o:-o]
+
+
+def relmax(a, b):
+    """max|a-b| / max|b|"""
+    return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+
+def status_from_meta(meta):
+    """The MAP_BOUNDARY block of oracle/ref_driver.c:init_map."""
+    nall = tuple(meta["nall"])
+    st = np.zeros(nall, dtype=np.int8)
+    if meta["solid"]:
+        h = meta["nhalo"]
+        st[h + 1:h + 3, h + 1:h + 3, h + 1:h + 3] = 1
+    return st
+
+
+def momentum_scale(f, cv, nhalo):
+    """Sum over interior sites of |g_a| (max over a): the natural scale for
+    errors in the total momentum. The synthetic states have a net momentum
+    that cancels to ~0 (sines over whole periods), so |sum g| itself is an
+    ill-conditioned denominator; sum |g| is what rounding errors scale with.
+    """
+    fi = interior(f, nhalo)
+    g = np.tensordot(cv.astype(np.float64).T, fi, axes=(1, 0))
+    return float(np.max(np.sum(np.abs(g), axis=(1, 2, 3))))
