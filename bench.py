@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""MLUPS benchmark of the LB time step (lb_collide + lb_halo + lb_propagation)
+on D3Q19 256^3 (BASELINE.json), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over the whole lattice through the
+C-ABI: lbmi_lb_collide, lbmi_lb_halo, lbmi_lb_propagation. In the default
+FUSED mode the three calls execute as ONE kernel (pull-propagation with
+periodic index wrap + collision); --mode eager runs the reference's three
+separate stages. Inputs are resident in HBM before the timed region.
+
+N > 1: strong scaling, the 256^3 box is cut into N slabs along X (the
+reference's `grid N_1_1`), X halo planes travel over RCCL (ncclSend/ncclRecv)
+on a second stream overlapped with the interior planes.
+
+Prints ONE JSON line on rank 0.
+"""
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, nargs=3, default=[256, 256, 256])
+    ap.add_argument("--nvel", type=int, default=19)
+    ap.add_argument("--scheme", default="m10", choices=["m10", "bgk", "trt"])
+    ap.add_argument("--mode", default="fused", choices=["fused", "eager"])
+    ap.add_argument("--hydro", type=int, default=1,
+                    help="1: lb_collide reads hydro->force and writes "
+                    "hydro->rho,u as the reference does; 0: NULL hydro arrays")
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Reference (oracle/_ref, kind 'reference') or oracle port (kind 'port')
+    timed on this host's cores: same box, same scheme, a few steps."""
+    cores = len(os.sched_getaffinity(0))
+    exe = os.path.join(ROOT, "oracle", "_ref",
+                       "ref_driver_d3q%d_fast" % args.nvel)
+    size = list(args.size)
+    zeta = 0.3 if args.scheme == "m10" else 0.1
+    sample = "%dx%dx%d %s, %d steps after 1 warm-up" % (*size, args.scheme,
+                                                         args.cpu_steps)
+    if os.path.exists(exe):
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores))
+        try:
+            out = subprocess.run(
+                [exe, "time", *map(str, size), args.scheme, "0.1", repr(zeta),
+                 str(args.cpu_steps)], env=env, check=True,
+                capture_output=True, text=True, timeout=900).stdout
+            r = json.loads(out.strip().splitlines()[-1])
+            return {"value": round(r["mlups"], 3), "unit": "MLUPS",
+                    "cores": cores, "kind": "reference",
+                    "sample": sample + " (reference built -O2 -DNDEBUG "
+                    "-fopenmp, AoS, lb_collide+lb_halo+lb_propagation; "
+                    "t_collide/halo/prop = %.3f/%.3f/%.3f s)"
+                    % (r["t_collide"], r["t_halo"], r["t_propagation"])}
+        except Exception as e:      # fall through to the port
+            sys.stderr.write("cpu_baseline: reference run failed: %r\n" % e)
+    import numpy as np
+    from oracle import lb_oracle as lbo
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    p = lbo.make_param(args.nvel, size, 1, args.scheme, 0.1, zeta)
+    f = lbo.init_synthetic(p)
+    fp = np.zeros_like(f)
+    f, fp = lbo.step(p, f, fp)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        f, fp = lbo.step(p, f, fp)
+    dt = time.perf_counter() - t0
+    mlups = 1e-6 * size[0] * size[1] * size[2] * args.cpu_steps / dt
+    return {"value": round(mlups, 3), "unit": "MLUPS", "cores": cores,
+            "kind": "port", "sample": sample + " (oracle/lb_oracle.c, OpenMP)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with "
+                             "torch.distributed.run" % args.gpus)
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import ludwig_amd
+    from ludwig_amd import synthetic
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no CPU path exists")
+    torch.cuda.set_device(local_rank)
+
+    if world > 1:
+        # control plane only (barrier, max-reduction, id broadcast); the
+        # data path is the library's own RCCL communicator
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    ntotal = tuple(args.size)
+    dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, nhalo=1)
+    mode = ludwig_amd.FUSED if args.mode == "fused" else ludwig_amd.EAGER
+    lb = ludwig_amd.LB(args.nvel, dec.nlocal, 1, mode=mode,
+                       halo_scheme=ludwig_amd.HALO_REDUCED, device=local_rank,
+                       cartsz=world, cartrank=rank)
+    zeta = 0.3 if args.scheme == "m10" else 0.1
+    lb.relaxation_set(args.scheme, 0.1, zeta)
+
+    if world > 1:
+        ids = [ludwig_amd.LB.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        lb.comm_init(ids[0])
+
+    m = ludwig_amd.lb.model(args.nvel)
+    synthetic.fill_device(lb, m["cv"], m["wv"], ntotal,
+                          xrange=(dec.noffset[0], dec.noffset[0] + dec.nlocal[0]))
+    hydro = None
+    if args.hydro:
+        hydro = ludwig_amd.Hydro(lb.nall, lb.device)
+        hydro.force = torch.zeros((3,) + lb.nall, dtype=torch.float64,
+                                  device=lb.device)   # hydro_f_zero
+        torch.cuda.synchronize()
+
+    def allsum(v):
+        if world == 1:
+            return v
+        t = torch.tensor(v, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.numpy()
+
+    mom0 = allsum(lb.moments()[[1, 5, 6, 7]])
+
+    for _ in range(args.warmup):
+        lb.step(hydro)
+    lb.synchronize()
+    lb.timing(True)
+
+    barrier()
+    torch.cuda.synchronize()
+    lb.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lb.step(hydro)
+    lb.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+
+    kms, nlaunch = lb.timing_read()
+    lb.timing(False)
+    mom1 = allsum(lb.moments()[[1, 5, 6, 7]])
+
+    sites = ntotal[0] * ntotal[1] * ntotal[2]
+    mlups = 1e-6 * sites * args.steps / dt
+
+    if rank == 0:
+        algo_bytes = 2 * args.nvel * 8
+        moved_bytes = algo_bytes + (56 if args.hydro else 0)
+        local_sites = dec.nlocal[0] * dec.nlocal[1] * dec.nlocal[2]
+        roofline = None
+        if nlaunch > 0 and args.mode == "fused":
+            t_launch = 1e-3 * kms / nlaunch
+            achieved = 1e-9 * algo_bytes * local_sites / t_launch
+            roofline = {
+                "bound": "hbm", "kernel": "k_propagate_collide",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "bytes_per_lup": algo_bytes,
+                "avg_launch_ms": round(1e3 * t_launch, 5),
+                "launches": nlaunch,
+                "achieved_incl_hydro_io": round(
+                    1e-9 * moved_bytes * local_sites / t_launch, 1),
+                "bytes_per_lup_incl_hydro_io": moved_bytes,
+            }
+        out = {
+            "metric": "MLUPS (million lattice updates/sec) D3Q%d %dx%dx%d"
+                      % (args.nvel, *ntotal),
+            "value": round(mlups, 1),
+            "unit": "MLUPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "D3Q%d %s single-fluid %dx%dx%d periodic, "
+                            "lb_collide+lb_halo+lb_propagation per step"
+                            % (args.nvel, args.scheme.upper(), *ntotal),
+                "mode": args.mode,
+                "hydro_io": bool(args.hydro),
+                "decomposition": "x-slab %d_1_1" % world,
+                "halo": "index wrap (1 GPU); reduced X planes over RCCL (N>1)",
+            },
+            "roofline": roofline,
+            "check": {
+                "mass_drift_rel": float(abs(mom1[0] - mom0[0]) / mom0[0]),
+                "momentum_drift_abs": float(np.max(np.abs(mom1[1:] - mom0[1:]))),
+            },
+        }
+        if args.cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    lb.free()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

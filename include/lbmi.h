@@ -1,0 +1,228 @@
+/*****************************************************************************
+ *
+ *  lbmi.h
+ *
+ *  C-ABI of liblbmi: an MI355X (gfx950) native lattice-Boltzmann time step
+ *  -- collision, halo swap, propagation and the conserved-moment statistics --
+ *  behind the call surface of the reference (zazu29/ludwig v0.20.1):
+ *
+ *      lb_collide()      src/collision.h:27     (called ludwig.c:802)
+ *      lb_halo()         src/lb_data.h:159      (called ludwig.c:816)
+ *      lb_halo_swap()    src/lb_data.h:160
+ *      lb_propagation()  src/propagation.h:21   (called ludwig.c:860)
+ *      lb_memcpy()       src/lb_data.h:156
+ *      stats_distribution_print() / distribution_stats_momentum()
+ *                        src/stats_distribution.c:55,201
+ *
+ *  Plain C: pointers, ints and doubles only. All array arguments are DEVICE
+ *  pointers (hipMalloc or equivalent) unless stated otherwise. There is no
+ *  CPU fallback: every compute entry point launches hand-written HIP kernels
+ *  and fails (negative return, lbmi_last_error()) when no device is present.
+ *
+ *  Memory layout is the reference's, unchanged (so that other Ludwig kernels
+ *  can keep dereferencing lb->target->f with LB_ADDR):
+ *
+ *    SoA ("reverse", -DADDR_SOA, memory.h:187-188):
+ *      f[(n*nvel + p)*nsite + index]           LB_ADDR, lb_data.h:136
+ *      hydro vectors: v[nsite*ia + index]      addr_rank1, memory.h:184
+ *      index = (nhalo+ic-1)*nall[Y]*nall[Z] + (nhalo+jc-1)*nall[Z]
+ *              + (nhalo+kc-1)                  cs_index, coords.c:617-631
+ *      nall[] = nlocal[] + 2*nhalo, nsite = nall[X]*nall[Y]*nall[Z]
+ *
+ *  All functions return 0 on success and a negative lbmi_error_t otherwise;
+ *  lbmi_last_error() then returns a static description (the reference itself
+ *  aborts via pe_fatal()/tdpAssert(); the shim in INTEGRATION.md maps a
+ *  non-zero return to pe_fatal()).
+ *
+ *  Threading: one host thread per handle, one GPU per handle (the reference
+ *  runs one MPI rank per GPU, ludwig.c:467-492). No global mutable state
+ *  apart from the thread-local error string.
+ *
+ *****************************************************************************/
+
+#ifndef LBMI_H
+#define LBMI_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#include <stddef.h>
+#include <stdint.h>
+
+#define LBMI_VERSION_MAJOR 0
+#define LBMI_VERSION_MINOR 1
+
+typedef struct lbmi_s lbmi_t;           /* opaque handle ~ lb_t + halo_swap_t */
+
+typedef enum lbmi_error_e {
+  LBMI_SUCCESS         =  0,
+  LBMI_ERR_ARGUMENT    = -1,            /* bad argument (assert() upstream) */
+  LBMI_ERR_UNSUPPORTED = -2,            /* e.g. d3q27 + TRT, ndist = 2      */
+  LBMI_ERR_NODEVICE    = -3,            /* no HIP device / wrong arch       */
+  LBMI_ERR_HIP         = -4,            /* a HIP runtime call failed        */
+  LBMI_ERR_RCCL        = -5,            /* an RCCL call failed              */
+  LBMI_ERR_STATE       = -6             /* call out of order                */
+} lbmi_error_t;
+
+/* Relaxation scheme: lb_relaxation_enum_t, src/lb_data_options.h:19-22 */
+typedef enum lbmi_relaxation_e {
+  LBMI_RELAXATION_M10 = 0,
+  LBMI_RELAXATION_BGK = 1,
+  LBMI_RELAXATION_TRT = 2
+} lbmi_relaxation_t;
+
+/* Halo scheme. FULL has the semantics of LB_HALO_TARGET (halo_swap.c:709):
+ * every population in the complete width-1 shell. REDUCED has those of
+ * LB_HALO_OPENMP_REDUCED (model.c:1192-1219): only populations that
+ * propagate into the interior are guaranteed. */
+typedef enum lbmi_halo_e {
+  LBMI_HALO_FULL    = 0,
+  LBMI_HALO_REDUCED = 2
+} lbmi_halo_t;
+
+/* How the three calls of a time step are executed.
+ * EAGER: lb_collide = in-place collision kernel, lb_halo = halo kernels,
+ *        lb_propagation = pull kernel + pointer swap; f is canonical after
+ *        every call (exactly the reference's observable behaviour).
+ * FUSED: lb_halo and lb_propagation only record that a halo swap and a
+ *        propagation are pending; the next lb_collide runs ONE kernel that
+ *        pulls (propagation), wraps periodic directions by index (halo),
+ *        collides, and writes fprime, then swaps. lbmi_lb_flush() (called by
+ *        lbmi_lb_memcpy_d2h, lbmi_lb_moments and lbmi_lb_f) materialises
+ *        the pending halo + propagation so that any reader sees the same
+ *        f as in EAGER mode. Requires an all-fluid or bounce-back-free step
+ *        (nothing may modify f between lb_collide and lb_propagation). */
+typedef enum lbmi_mode_e {
+  LBMI_MODE_EAGER = 0,
+  LBMI_MODE_FUSED = 1
+} lbmi_mode_t;
+
+typedef struct lbmi_options_s {
+  int nvel;                 /* 19 or 27 (lb_data.h:33-44)                    */
+  int ndist;                /* 1 (binary two-distribution LB: unsupported)   */
+  int nlocal[3];            /* local lattice extent (cs_nlocal)              */
+  int nhalo;                /* halo width of the allocation (cs_nhalo)       */
+  int device;               /* HIP device ordinal, or -1: current device     */
+  int mode;                 /* lbmi_mode_t                                   */
+  int halo_scheme;          /* lbmi_halo_t                                   */
+  int cartsz;               /* number of slabs along X (1 = single GPU)      */
+  int cartrank;             /* this rank's slab, 0 <= cartrank < cartsz      */
+  int reserved[7];          /* must be zero                                  */
+} lbmi_options_t;
+
+/* Borrowed per-call fields of lb_collide(): hydro_t and map_t device arrays
+ * (collision.c:200-202, 329-333, 571-579). Any pointer may be NULL:
+ * force == NULL is a zero force field; status == NULL is all MAP_FLUID;
+ * rho/u == NULL are not written. */
+typedef struct lbmi_hydro_s {
+  const double * force;     /* hydro->force->data, 3*nsite                   */
+  const char   * status;    /* map->status, nsite bytes, 0 = MAP_FLUID       */
+  double       * rho;       /* hydro->rho->data, nsite                       */
+  double       * u;         /* hydro->u->data, 3*nsite                       */
+} lbmi_hydro_t;
+
+/* ---- life cycle: lb_data_create / lb_free (model.c:56-213) -------------- */
+
+int lbmi_options_default(lbmi_options_t * opts);
+int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle);
+int lbmi_free(lbmi_t * lb);
+const char * lbmi_last_error(void);
+
+int lbmi_nsite(const lbmi_t * lb, size_t * nsite);
+int lbmi_nall(const lbmi_t * lb, int nall[3]);
+
+/* Model tables as the reference builds them (lb_d3q19.c, lb_d3q27.c,
+ * model.c:358-390); host arrays of nvel, 3*nvel, nvel, nvel*nvel. */
+int lbmi_model(int nvel, int8_t * cv, double * wv, double * na, double * ma);
+
+/* ---- parameters -------------------------------------------------------- */
+
+/* lb_collision_relaxation_times_set (collision.c:1181-1264) with the
+ * global physics_t values passed explicitly. */
+int lbmi_set_relaxation(lbmi_t * lb, int scheme, double rho0,
+			double eta_shear, double eta_bulk);
+/* force_global of lb_collision_parameters_commit (collision.c:1928-1980) */
+int lbmi_set_body_force(lbmi_t * lb, const double fbody[3]);
+/* The relaxation rates in use: rtau_shear, rtau_bulk, ghost even, ghost odd */
+int lbmi_relaxation_rates(const lbmi_t * lb, double rtau[4]);
+
+/* ---- stateless kernels on caller-owned device arrays -------------------- */
+
+/* lb_collision_mrt1 (collision.c:223-599): in-place collision of interior
+ * fluid sites. */
+int lbmi_collide(lbmi_t * lb, double * f, const lbmi_hydro_t * hydro);
+
+/* lb_halo_swap (model.c:565-595): fill the width-1 halo shell of f (single
+ * rank: periodic wrap in all directions; cartsz > 1: X through RCCL). */
+int lbmi_halo(lbmi_t * lb, double * f, int scheme);
+
+/* lb_propagation_kernel (propagation.c:162-212): fprime <- pull(f). The
+ * caller swaps the pointers (lb_model_swapf, propagation.c:223-252). */
+int lbmi_propagate(lbmi_t * lb, const double * f, double * fprime);
+
+/* Fused propagation(t) + collision(t+1): fprime <- collide(pull(f)).
+ * wrap != 0: periodic directions local to this rank are wrapped by index
+ * arithmetic (no halo needed in Y, Z, and in X when cartsz == 1);
+ * wrap == 0: f must have a valid halo shell. */
+int lbmi_propagate_collide(lbmi_t * lb, const double * f, double * fprime,
+			   const lbmi_hydro_t * hydro, int wrap);
+
+/* halo_swap_packed for a generic SoA field of nel components, e.g.
+ * hydro->u (hydro_u_halo, hydro.c:190-215). */
+int lbmi_field_halo(lbmi_t * lb, int nel, double * data);
+
+/* stats_distribution_print + distribution_stats_momentum
+ * (stats_distribution.c:55-117, 201-350) over interior fluid sites.
+ * out (HOST array of 9): volume, sum rho, sum rho^2, min rho, max rho,
+ * g_x, g_y, g_z (Kahan-compensated), 0. Local to this rank. */
+int lbmi_moments(lbmi_t * lb, const double * f, const char * status,
+		 double out[9]);
+
+/* ---- the lb_t-like stateful surface ------------------------------------ */
+
+/* Attach the two distribution arrays (lb->target->f, lb->target->fprime).
+ * With f == NULL the library allocates (and owns) both, zero-initialised
+ * as lb_data_create does (model.c:106-109,131-147). */
+int lbmi_lb_bind(lbmi_t * lb, double * f, double * fprime);
+/* Current arrays: what lb->target->f / fprime must point at after a call
+ * (the swap of propagation.c:240-248). */
+int lbmi_lb_pointers(lbmi_t * lb, double ** f, double ** fprime);
+
+int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro);  /* lb_collide */
+int lbmi_lb_halo(lbmi_t * lb);                                 /* lb_halo    */
+int lbmi_lb_propagation(lbmi_t * lb);                          /* lb_propagation */
+int lbmi_lb_flush(lbmi_t * lb);
+
+/* lb_memcpy (model.c:228-266): whole-array copies between a HOST array of
+ * nvel*nsite doubles and the current f. */
+int lbmi_lb_memcpy_h2d(lbmi_t * lb, const double * f_host);
+int lbmi_lb_memcpy_d2h(lbmi_t * lb, double * f_host);
+int lbmi_lb_moments(lbmi_t * lb, const char * status, double out[9]);
+
+/* ---- streams / synchronisation ----------------------------------------- */
+
+int lbmi_synchronize(lbmi_t * lb);
+/* hipStream_t of the compute stream, as void* */
+int lbmi_stream(lbmi_t * lb, void ** stream);
+/* Average device time (ms) of the fused kernel launches since the last
+ * call, measured with hipEvents on the compute stream (bench.py roofline);
+ * enable with lbmi_timing(lb, 1). */
+int lbmi_timing(lbmi_t * lb, int on);
+int lbmi_timing_read(lbmi_t * lb, double * ms_total, int * nlaunch);
+
+/* ---- multi-GPU: 1-d slab decomposition along X over RCCL ---------------- */
+
+#define LBMI_UNIQUE_ID_BYTES 128
+/* ncclGetUniqueId: HOST buffer of LBMI_UNIQUE_ID_BYTES, call on rank 0 and
+ * distribute by any out-of-band means (MPI_Bcast, torch.distributed store) */
+int lbmi_comm_unique_id(void * id);
+/* ncclCommInitRank over the cartsz ranks given at lbmi_create() */
+int lbmi_comm_init(lbmi_t * lb, const void * id);
+int lbmi_comm_free(lbmi_t * lb);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

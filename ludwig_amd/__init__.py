@@ -1,0 +1,11 @@
+"""ludwig_amd -- host-side mirror of the reference's lattice-Boltzmann call
+surface (lb_collide / lb_halo / lb_propagation of zazu29/ludwig) on top of
+liblbmi.so, the MI355X-native C-ABI library in ludwig_amd/csrc.
+
+There is no CPU path: importing is always possible, but creating an LB object
+fails loudly when the HIP library or a gfx950 device is missing.
+"""
+
+from .lib import build, library, LbmiError  # noqa: F401
+from .lb import LB, Hydro, M10, BGK, TRT, EAGER, FUSED, HALO_FULL, HALO_REDUCED  # noqa: F401
+from .decomp import SlabDecomposition  # noqa: F401

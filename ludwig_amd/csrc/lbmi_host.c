@@ -1,0 +1,982 @@
+/*****************************************************************************
+ *
+ *  lbmi_host.c
+ *
+ *  ANSI C (C99) host side of liblbmi: the handle (the part of lb_t and
+ *  halo_swap_t the hot path needs), parameter handling, the eager and the
+ *  fused (deferred) execution of lb_collide / lb_halo / lb_propagation,
+ *  and the RCCL ring for the slab decomposition. All compute is done by the
+ *  HIP kernels of lbmi_kernels.hip; there is no CPU fallback.
+ *
+ *  Reference counterparts are cited at each function; see include/lbmi.h.
+ *
+ *****************************************************************************/
+
+#define __HIP_PLATFORM_AMD__ 1
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include "lbmi.h"
+#include "lbmi_kernels.h"
+
+enum {X = 0, Y = 1, Z = 2};
+enum {LBMI_NEVENT = 4096};
+
+struct lbmi_s {
+  lbmi_options_t opts;
+  lbmi_kparam_t kp;
+  int device;
+
+  int8_t cv[LBMI_NVEL_MAX][3];
+  lbmi_halo_sel_t sel_full[3];       /* all populations, both sides */
+  lbmi_halo_sel_t sel_reduced[3];    /* c_d = +1 low side, c_d = -1 high */
+
+  hipStream_t stream;                /* compute */
+  hipStream_t comm_stream;           /* halo exchange (multi-GPU overlap) */
+  hipEvent_t ev_ready;               /* boundary planes of f written */
+  hipEvent_t ev_halo;                /* x halo planes of f filled */
+
+  /* lb_t-like state */
+  double * f;
+  double * fprime;
+  int owns_f;
+  int pending_halo;                  /* FUSED: lb_halo recorded */
+  int pending_prop;                  /* FUSED: lb_propagation recorded */
+
+  /* moments workspace */
+  double * mom_work;
+  double * mom_out;
+
+  /* RCCL ring (X slabs) */
+  ncclComm_t comm;
+  int have_comm;
+  double * sendlo, * sendhi, * recvlo, * recvhi;   /* device buffers */
+  size_t xbuf_doubles;
+
+  /* kernel timing */
+  int timing;
+  int nev;
+  hipEvent_t ev0[LBMI_NEVENT];
+  hipEvent_t ev1[LBMI_NEVENT];
+  int ev_created;
+  double ms_accum;
+  int launches_accum;
+};
+
+static __thread char lbmi_errbuf[512] = "no error";
+
+static int lbmi_fail(int code, const char * fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(lbmi_errbuf, sizeof(lbmi_errbuf), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+const char * lbmi_last_error(void) {
+  return lbmi_errbuf;
+}
+
+#define HIPCHECK(call)							\
+  do {									\
+    hipError_t e_ = (call);						\
+    if (e_ != hipSuccess) {						\
+      return lbmi_fail(LBMI_ERR_HIP, "%s:%d: %s: %s", __FILE__, __LINE__, \
+		       #call, hipGetErrorString(e_));			\
+    }									\
+  } while (0)
+
+#define KCHECK(call)							\
+  do {									\
+    int e_ = (call);							\
+    if (e_ != 0) {							\
+      return lbmi_fail(LBMI_ERR_HIP, "%s:%d: %s: %s", __FILE__, __LINE__, \
+		       #call, hipGetErrorString((hipError_t) e_));	\
+    }									\
+  } while (0)
+
+#define NCCLCHECK(call)							\
+  do {									\
+    ncclResult_t r_ = (call);						\
+    if (r_ != ncclSuccess) {						\
+      return lbmi_fail(LBMI_ERR_RCCL, "%s:%d: %s: %s", __FILE__, __LINE__, \
+		       #call, ncclGetErrorString(r_));			\
+    }									\
+  } while (0)
+
+/*****************************************************************************
+ *
+ *  lbmi_options_default  (lb_data_options_default, lb_data_options.c:24-38)
+ *
+ *****************************************************************************/
+
+int lbmi_options_default(lbmi_options_t * opts) {
+
+  if (opts == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "opts is NULL");
+
+  memset(opts, 0, sizeof(lbmi_options_t));
+  opts->nvel = 19;
+  opts->ndist = 1;
+  opts->nlocal[X] = 64; opts->nlocal[Y] = 64; opts->nlocal[Z] = 64;
+  opts->nhalo = 1;
+  opts->device = -1;
+  opts->mode = LBMI_MODE_EAGER;
+  opts->halo_scheme = LBMI_HALO_FULL;
+  opts->cartsz = 1;
+  opts->cartrank = 0;
+
+  return 0;
+}
+
+int lbmi_model(int nvel, int8_t * cv, double * wv, double * na, double * ma) {
+  if (nvel != 19 && nvel != 27) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "nvel = %d (19 or 27)", nvel);
+  }
+  if (!cv || !wv || !na || !ma) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  return lbmi_k_model(nvel, cv, wv, na, ma);
+}
+
+/* Populations needed per halo side (lb_halo_size, model.c:1192-1219): the
+ * low halo plane of direction d is read by pulls with c_d = +1. */
+
+static void lbmi_halo_selections(lbmi_t * lb) {
+  for (int d = 0; d < 3; d++) {
+    lbmi_halo_sel_t * sf = &lb->sel_full[d];
+    lbmi_halo_sel_t * sr = &lb->sel_reduced[d];
+    memset(sf, 0, sizeof(*sf));
+    memset(sr, 0, sizeof(*sr));
+    for (int p = 0; p < lb->kp.nvel; p++) {
+      sf->lo[sf->nlo++] = (int8_t) p;
+      sf->hi[sf->nhi++] = (int8_t) p;
+      if (lb->cv[p][d] == +1) sr->lo[sr->nlo++] = (int8_t) p;
+      if (lb->cv[p][d] == -1) sr->hi[sr->nhi++] = (int8_t) p;
+    }
+  }
+}
+
+/*****************************************************************************
+ *
+ *  lbmi_create  (lb_data_create + lb_init, model.c:56-331;
+ *                halo_swap_create, halo_swap.c:109-266)
+ *
+ *****************************************************************************/
+
+int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
+
+  lbmi_t * lb = NULL;
+  int ndevice = 0;
+  hipDeviceProp_t prop;
+
+  if (opts == NULL || handle == NULL) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_create: NULL argument");
+  }
+  *handle = NULL;
+
+  if (opts->nvel != 19 && opts->nvel != 27) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "nvel = %d: only d3q19 and d3q27",
+		     opts->nvel);
+  }
+  if (opts->ndist != 1) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = %d: single-fluid only",
+		     opts->ndist);
+  }
+  if (opts->nhalo < 1) return lbmi_fail(LBMI_ERR_ARGUMENT, "nhalo < 1");
+  for (int d = 0; d < 3; d++) {
+    if (opts->nlocal[d] < 1) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "nlocal[%d] = %d", d, opts->nlocal[d]);
+    }
+  }
+  if (opts->cartsz < 1 || opts->cartrank < 0 || opts->cartrank >= opts->cartsz) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "cartsz/cartrank = %d/%d",
+		     opts->cartsz, opts->cartrank);
+  }
+  if (opts->mode != LBMI_MODE_EAGER && opts->mode != LBMI_MODE_FUSED) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "mode = %d", opts->mode);
+  }
+  if (opts->halo_scheme != LBMI_HALO_FULL &&
+      opts->halo_scheme != LBMI_HALO_REDUCED) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "halo_scheme = %d", opts->halo_scheme);
+  }
+
+  {
+    long long nsite = 1;
+    long long nall[3];
+    for (int d = 0; d < 3; d++) {
+      nall[d] = (long long) opts->nlocal[d] + 2*opts->nhalo;
+      nsite *= nall[d];
+    }
+    /* site indices are 32-bit in the kernels (the reference uses int
+     * throughout, LB_ADDR); population offsets are 64-bit */
+    if (nsite >= 2147483647LL) {
+      return lbmi_fail(LBMI_ERR_UNSUPPORTED, "nsite = %lld exceeds 2^31-1",
+		       nsite);
+    }
+  }
+
+  if (hipGetDeviceCount(&ndevice) != hipSuccess || ndevice < 1) {
+    return lbmi_fail(LBMI_ERR_NODEVICE,
+		     "no HIP device: liblbmi has no CPU fallback");
+  }
+
+  lb = (lbmi_t *) calloc(1, sizeof(lbmi_t));
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "calloc failed");
+
+  lb->opts = *opts;
+  if (opts->device >= 0) {
+    if (opts->device >= ndevice) {
+      free(lb);
+      return lbmi_fail(LBMI_ERR_NODEVICE, "device %d of %d", opts->device,
+		       ndevice);
+    }
+    lb->device = opts->device;
+  }
+  else {
+    if (hipGetDevice(&lb->device) != hipSuccess) lb->device = 0;
+  }
+  if (hipSetDevice(lb->device) != hipSuccess) {
+    free(lb);
+    return lbmi_fail(LBMI_ERR_HIP, "hipSetDevice(%d) failed", lb->device);
+  }
+  if (hipGetDeviceProperties(&prop, lb->device) == hipSuccess) {
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      free(lb);
+      return lbmi_fail(LBMI_ERR_NODEVICE, "device arch %s: liblbmi is built "
+		       "for gfx950 (MI355X) only", prop.gcnArchName);
+    }
+  }
+
+  /* Kernel parameter block */
+  lb->kp.nvel = opts->nvel;
+  lb->kp.scheme = LBMI_RELAXATION_M10;
+  lb->kp.nhalo = opts->nhalo;
+  for (int d = 0; d < 3; d++) {
+    lb->kp.nlocal[d] = opts->nlocal[d];
+    lb->kp.nall[d] = opts->nlocal[d] + 2*opts->nhalo;
+  }
+  lb->kp.stry = lb->kp.nall[Z];
+  lb->kp.strx = lb->kp.nall[Y]*lb->kp.nall[Z];
+  lb->kp.nsite = (long long) lb->kp.nall[X]*lb->kp.strx;
+
+  {
+    double wv[LBMI_NVEL_MAX], na[LBMI_NVEL_MAX];
+    double * ma = (double *) malloc(sizeof(double)*LBMI_NVEL_MAX*LBMI_NVEL_MAX);
+    if (ma == NULL) { free(lb); return lbmi_fail(LBMI_ERR_ARGUMENT, "malloc"); }
+    lbmi_k_model(opts->nvel, &lb->cv[0][0], wv, na, ma);
+    free(ma);
+  }
+  lbmi_halo_selections(lb);
+
+  /* Defaults of the reference: rho0 = 1, eta = zeta = 1/6 (physics.c:33-56) */
+  lbmi_set_relaxation(lb, LBMI_RELAXATION_M10, 1.0, 1.0/6.0, 1.0/6.0);
+
+  if (hipStreamCreateWithFlags(&lb->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&lb->comm_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&lb->ev_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&lb->ev_halo, hipEventDisableTiming) != hipSuccess) {
+    free(lb);
+    return lbmi_fail(LBMI_ERR_HIP, "stream/event creation failed");
+  }
+
+  if (hipMalloc((void **) &lb->mom_work,
+		sizeof(double)*12*(size_t) lbmi_k_moments_nblk()) != hipSuccess ||
+      hipMalloc((void **) &lb->mom_out, sizeof(double)*16) != hipSuccess) {
+    free(lb);
+    return lbmi_fail(LBMI_ERR_HIP, "hipMalloc (moments workspace) failed");
+  }
+
+  *handle = lb;
+
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  lbmi_free  (lb_free, model.c:181-213; halo_swap_free)
+ *
+ *****************************************************************************/
+
+int lbmi_free(lbmi_t * lb) {
+
+  if (lb == NULL) return 0;
+
+  hipSetDevice(lb->device);
+  hipStreamSynchronize(lb->stream);
+  hipStreamSynchronize(lb->comm_stream);
+
+  lbmi_comm_free(lb);
+
+  if (lb->owns_f) {
+    hipFree(lb->f);
+    hipFree(lb->fprime);
+  }
+  hipFree(lb->mom_work);
+  hipFree(lb->mom_out);
+  if (lb->ev_created) {
+    for (int n = 0; n < LBMI_NEVENT; n++) {
+      hipEventDestroy(lb->ev0[n]);
+      hipEventDestroy(lb->ev1[n]);
+    }
+  }
+  hipEventDestroy(lb->ev_ready);
+  hipEventDestroy(lb->ev_halo);
+  hipStreamDestroy(lb->comm_stream);
+  hipStreamDestroy(lb->stream);
+  free(lb);
+
+  return 0;
+}
+
+int lbmi_nsite(const lbmi_t * lb, size_t * nsite) {
+  if (lb == NULL || nsite == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  *nsite = (size_t) lb->kp.nsite;
+  return 0;
+}
+
+int lbmi_nall(const lbmi_t * lb, int nall[3]) {
+  if (lb == NULL || nall == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  for (int d = 0; d < 3; d++) nall[d] = lb->kp.nall[d];
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  lbmi_set_relaxation
+ *
+ *  lb_collision_relaxation_times_set (collision.c:1181-1264) and the rates
+ *  the single-fluid kernel actually uses: lb_relaxation_time_shear_v
+ *  (:1287-1300), _bulk_v (:1339-1373), _ghosts_v (:1443-1538).
+ *
+ *****************************************************************************/
+
+int lbmi_set_relaxation(lbmi_t * lb, int scheme, double rho0,
+			double eta_shear, double eta_bulk) {
+
+  const double cs2 = (1.0/3.0);
+  double rtau, rtau_bulk;
+
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "lb is NULL");
+  if (!(rho0 > 0.0)) return lbmi_fail(LBMI_ERR_ARGUMENT, "rho0 = %g", rho0);
+
+  rtau = 1.0/(0.5 + eta_shear/(rho0*cs2));
+  rtau_bulk = 1.0/(0.5 + eta_bulk/(rho0*cs2));
+
+  switch (scheme) {
+  case LBMI_RELAXATION_M10:
+    lb->kp.rtau_shear = rtau;
+    lb->kp.rtau_bulk = rtau_bulk;
+    lb->kp.rtau_even = 1.0;
+    lb->kp.rtau_odd = 1.0;
+    break;
+  case LBMI_RELAXATION_BGK:
+    lb->kp.rtau_shear = rtau;
+    lb->kp.rtau_bulk = rtau;       /* no separate bulk viscosity */
+    lb->kp.rtau_even = rtau;
+    lb->kp.rtau_odd = rtau;
+    break;
+  case LBMI_RELAXATION_TRT:
+    if (lb->kp.nvel != 19) {
+      /* the reference leaves rtau_ghost[] uninitialised for d3q27
+       * (collision.c:1487-1534): reject rather than imitate */
+      return lbmi_fail(LBMI_ERR_UNSUPPORTED, "TRT is defined for d3q19 only");
+    }
+    {
+      double tau = eta_shear/(rho0*cs2);
+      double rodd = 0.5 + 2.0*tau/(tau + 3.0/8.0);
+      if (rodd > 2.0) rodd = 2.0;
+      lb->kp.rtau_shear = rtau;
+      lb->kp.rtau_bulk = rtau_bulk;
+      lb->kp.rtau_even = rtau;     /* modes 10, 14, 18 */
+      lb->kp.rtau_odd = rodd;      /* modes 11-13, 15-17 */
+    }
+    break;
+  default:
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "relaxation scheme %d", scheme);
+  }
+
+  lb->kp.scheme = scheme;
+
+  return 0;
+}
+
+int lbmi_set_body_force(lbmi_t * lb, const double fbody[3]) {
+  if (lb == NULL || fbody == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  for (int d = 0; d < 3; d++) lb->kp.fbody[d] = fbody[d];
+  return 0;
+}
+
+int lbmi_relaxation_rates(const lbmi_t * lb, double rtau[4]) {
+  if (lb == NULL || rtau == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  rtau[0] = lb->kp.rtau_shear;
+  rtau[1] = lb->kp.rtau_bulk;
+  rtau[2] = lb->kp.rtau_even;
+  rtau[3] = lb->kp.rtau_odd;
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  Stateless kernels
+ *
+ *****************************************************************************/
+
+static lbmi_hydro_dev_t lbmi_hydro_dev(const lbmi_hydro_t * hydro) {
+  lbmi_hydro_dev_t h = {NULL, NULL, NULL, NULL};
+  if (hydro) {
+    h.force = hydro->force;
+    h.status = hydro->status;
+    h.rho = hydro->rho;
+    h.u = hydro->u;
+  }
+  return h;
+}
+
+/* Event-pair timing of a kernel launch on the compute stream */
+
+static int lbmi_time_begin(lbmi_t * lb) {
+  if (!lb->timing) return 0;
+  if (!lb->ev_created) {
+    for (int n = 0; n < LBMI_NEVENT; n++) {
+      HIPCHECK(hipEventCreate(&lb->ev0[n]));
+      HIPCHECK(hipEventCreate(&lb->ev1[n]));
+    }
+    lb->ev_created = 1;
+  }
+  if (lb->nev == LBMI_NEVENT) {
+    double ms; int n;
+    int ifail = lbmi_timing_read(lb, &ms, &n);   /* drains into accumulators */
+    if (ifail) return ifail;
+    lb->ms_accum = ms; lb->launches_accum = n;
+  }
+  HIPCHECK(hipEventRecord(lb->ev0[lb->nev], lb->stream));
+  return 0;
+}
+
+static int lbmi_time_end(lbmi_t * lb) {
+  if (!lb->timing) return 0;
+  HIPCHECK(hipEventRecord(lb->ev1[lb->nev], lb->stream));
+  lb->nev += 1;
+  return 0;
+}
+
+int lbmi_timing(lbmi_t * lb, int on) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  lb->timing = (on != 0);
+  lb->nev = 0;
+  lb->ms_accum = 0.0;
+  lb->launches_accum = 0;
+  return 0;
+}
+
+int lbmi_timing_read(lbmi_t * lb, double * ms_total, int * nlaunch) {
+  if (lb == NULL || !ms_total || !nlaunch) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  HIPCHECK(hipSetDevice(lb->device));
+  HIPCHECK(hipStreamSynchronize(lb->stream));
+  {
+    double ms = lb->ms_accum;
+    int n = lb->launches_accum;
+    for (int k = 0; k < lb->nev; k++) {
+      float t = 0.0f;
+      HIPCHECK(hipEventElapsedTime(&t, lb->ev0[k], lb->ev1[k]));
+      ms += t;
+    }
+    n += lb->nev;
+    lb->nev = 0;
+    lb->ms_accum = 0.0;
+    lb->launches_accum = 0;
+    *ms_total = ms;
+    *nlaunch = n;
+  }
+  return 0;
+}
+
+int lbmi_collide(lbmi_t * lb, double * f, const lbmi_hydro_t * hydro) {
+  lbmi_hydro_dev_t h = lbmi_hydro_dev(hydro);
+  if (lb == NULL || f == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_collide(&lb->kp, f, &h, lb->stream));
+  return 0;
+}
+
+int lbmi_propagate(lbmi_t * lb, const double * f, double * fprime) {
+  if (lb == NULL || f == NULL || fprime == NULL || f == fprime) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_propagate: bad pointers");
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_propagate(&lb->kp, f, fprime, lb->stream));
+  return 0;
+}
+
+/* Which directions can be wrapped by index arithmetic on this rank */
+
+static int lbmi_wrapmask(const lbmi_t * lb) {
+  int mask = 2 | 4;                        /* Y and Z are never decomposed */
+  if (lb->opts.cartsz == 1 && !lb->have_comm) mask |= 1;
+  return mask;
+}
+
+int lbmi_propagate_collide(lbmi_t * lb, const double * f, double * fprime,
+			   const lbmi_hydro_t * hydro, int wrap) {
+  lbmi_hydro_dev_t h = lbmi_hydro_dev(hydro);
+  int ifail;
+  if (lb == NULL || f == NULL || fprime == NULL || f == fprime) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_propagate_collide: bad pointers");
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  ifail = lbmi_time_begin(lb);
+  if (ifail) return ifail;
+  KCHECK(lbmi_k_propagate_collide(&lb->kp, f, fprime, &h,
+				  wrap ? lbmi_wrapmask(lb) : 0,
+				  lb->kp.nhalo,
+				  lb->kp.nhalo + lb->kp.nlocal[X] - 1,
+				  lb->stream));
+  return lbmi_time_end(lb);
+}
+
+/*****************************************************************************
+ *
+ *  Halo swap
+ *
+ *  halo_swap_packed (halo_swap.c:709-1063): passes X, Y, Z in order; each
+ *  covers the full extent of the other two directions so that edges and
+ *  corners are completed by the later passes. On one rank a pass is a
+ *  device-side periodic copy; with cartsz > 1 the X pass goes through
+ *  packed device buffers and ncclSend/ncclRecv (RCCL over xGMI) instead of
+ *  the reference's pinned-host staging + MPI (halo_swap.c:762-881).
+ *
+ *****************************************************************************/
+
+static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
+			   double * data, hipStream_t st) {
+
+  size_t psz = (size_t) lb->kp.strx;
+  size_t nlo = psz*(size_t) sel->nlo;     /* arrives in / leaves for low halos */
+  size_t nhi = psz*(size_t) sel->nhi;
+  int prev = (lb->opts.cartrank + lb->opts.cartsz - 1) % lb->opts.cartsz;
+  int next = (lb->opts.cartrank + 1) % lb->opts.cartsz;
+
+  if (!lb->have_comm) {
+    return lbmi_fail(LBMI_ERR_STATE, "cartsz = %d but lbmi_comm_init() has "
+		     "not been called", lb->opts.cartsz);
+  }
+  if (nlo > lb->xbuf_doubles || nhi > lb->xbuf_doubles) {
+    return lbmi_fail(LBMI_ERR_STATE, "halo buffers too small");
+  }
+
+  /* sendlo: our first interior plane, components sel->hi -> prev's high halo
+   * sendhi: our last interior plane, components sel->lo  -> next's low halo */
+  KCHECK(lbmi_k_halo_pack_x(&lb->kp, sel, data, lb->sendlo, lb->sendhi, st));
+
+  NCCLCHECK(ncclGroupStart());
+  NCCLCHECK(ncclSend(lb->sendhi, nlo, ncclDouble, next, lb->comm, st));
+  NCCLCHECK(ncclRecv(lb->recvlo, nlo, ncclDouble, prev, lb->comm, st));
+  NCCLCHECK(ncclSend(lb->sendlo, nhi, ncclDouble, prev, lb->comm, st));
+  NCCLCHECK(ncclRecv(lb->recvhi, nhi, ncclDouble, next, lb->comm, st));
+  NCCLCHECK(ncclGroupEnd());
+
+  KCHECK(lbmi_k_halo_unpack_x(&lb->kp, sel, data, lb->recvlo, lb->recvhi, st));
+
+  return 0;
+}
+
+static int lbmi_halo_generic(lbmi_t * lb, const lbmi_halo_sel_t sel[3],
+			     double * data, hipStream_t st) {
+  int ifail;
+  if (lb->opts.cartsz > 1 || lb->have_comm) {
+    ifail = lbmi_x_exchange(lb, &sel[X], data, st);
+    if (ifail) return ifail;
+  }
+  else {
+    KCHECK(lbmi_k_halo_copy(&lb->kp, X, &sel[X], data, st));
+  }
+  KCHECK(lbmi_k_halo_copy(&lb->kp, Y, &sel[Y], data, st));
+  KCHECK(lbmi_k_halo_copy(&lb->kp, Z, &sel[Z], data, st));
+  return 0;
+}
+
+int lbmi_halo(lbmi_t * lb, double * f, int scheme) {
+  if (lb == NULL || f == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  HIPCHECK(hipSetDevice(lb->device));
+  if (scheme == LBMI_HALO_FULL) {
+    return lbmi_halo_generic(lb, lb->sel_full, f, lb->stream);
+  }
+  if (scheme == LBMI_HALO_REDUCED) {
+    return lbmi_halo_generic(lb, lb->sel_reduced, f, lb->stream);
+  }
+  return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
+}
+
+int lbmi_field_halo(lbmi_t * lb, int nel, double * data) {
+  lbmi_halo_sel_t sel[3];
+  if (lb == NULL || data == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (nel < 1 || nel > LBMI_NVEL_MAX) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "nel = %d (1..%d)", nel, LBMI_NVEL_MAX);
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  for (int d = 0; d < 3; d++) {
+    memset(&sel[d], 0, sizeof(sel[d]));
+    for (int n = 0; n < nel; n++) {
+      sel[d].lo[sel[d].nlo++] = (int8_t) n;
+      sel[d].hi[sel[d].nhi++] = (int8_t) n;
+    }
+  }
+  return lbmi_halo_generic(lb, sel, data, lb->stream);
+}
+
+/*****************************************************************************
+ *
+ *  lbmi_moments  (stats_distribution.c:55-117, 201-350)
+ *
+ *****************************************************************************/
+
+int lbmi_moments(lbmi_t * lb, const double * f, const char * status,
+		 double out[9]) {
+  if (lb == NULL || f == NULL || out == NULL) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_moments(&lb->kp, f, status, lb->mom_work, lb->mom_out,
+			lb->stream));
+  HIPCHECK(hipMemcpyAsync(out, lb->mom_out, 9*sizeof(double),
+			  hipMemcpyDeviceToHost, lb->stream));
+  HIPCHECK(hipStreamSynchronize(lb->stream));
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  The lb_t-like stateful surface
+ *
+ *****************************************************************************/
+
+int lbmi_lb_bind(lbmi_t * lb, double * f, double * fprime) {
+
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  HIPCHECK(hipSetDevice(lb->device));
+
+  if (lb->owns_f) {
+    hipFree(lb->f);
+    hipFree(lb->fprime);
+    lb->owns_f = 0;
+  }
+  lb->f = NULL;
+  lb->fprime = NULL;
+  lb->pending_halo = 0;
+  lb->pending_prop = 0;
+
+  if (f == NULL) {
+    size_t sz = sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel;
+    HIPCHECK(hipMalloc((void **) &lb->f, sz));
+    HIPCHECK(hipMalloc((void **) &lb->fprime, sz));
+    HIPCHECK(hipMemsetAsync(lb->f, 0, sz, lb->stream));
+    HIPCHECK(hipMemsetAsync(lb->fprime, 0, sz, lb->stream));
+    HIPCHECK(hipStreamSynchronize(lb->stream));
+    lb->owns_f = 1;
+  }
+  else {
+    if (fprime == NULL || fprime == f) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_lb_bind: fprime invalid");
+    }
+    lb->f = f;
+    lb->fprime = fprime;
+  }
+
+  return 0;
+}
+
+int lbmi_lb_pointers(lbmi_t * lb, double ** f, double ** fprime) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (f) *f = lb->f;
+  if (fprime) *fprime = lb->fprime;
+  return 0;
+}
+
+static void lbmi_swapf(lbmi_t * lb) {        /* lb_model_swapf */
+  double * tmp = lb->f;
+  lb->f = lb->fprime;
+  lb->fprime = tmp;
+}
+
+/* FUSED step: exchange of the X planes on the comm stream overlapped with
+ * the interior x-planes on the compute stream, boundary planes afterwards */
+
+static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
+
+  const int nh = lb->kp.nhalo;
+  const int xlo = nh;
+  const int xhi = nh + lb->kp.nlocal[X] - 1;
+  const int wrapmask = lbmi_wrapmask(lb);
+  int ifail;
+
+  ifail = lbmi_time_begin(lb);
+  if (ifail) return ifail;
+
+  if (lb->opts.cartsz == 1 && !lb->have_comm) {
+    KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
+				    xlo, xhi, lb->stream));
+  }
+  else {
+    /* comm stream: wait until the previous step has written f, then
+     * exchange the (reduced) boundary planes into the x halo planes */
+    HIPCHECK(hipEventRecord(lb->ev_ready, lb->stream));
+    HIPCHECK(hipStreamWaitEvent(lb->comm_stream, lb->ev_ready, 0));
+    ifail = lbmi_x_exchange(lb, &lb->sel_reduced[X], lb->f, lb->comm_stream);
+    if (ifail) return ifail;
+    HIPCHECK(hipEventRecord(lb->ev_halo, lb->comm_stream));
+
+    /* compute stream: interior planes need no x halo */
+    KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
+				    xlo + 1, xhi - 1, lb->stream));
+    HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_halo, 0));
+    KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
+				    xlo, xlo, lb->stream));
+    if (xhi > xlo) {
+      KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
+				      xhi, xhi, lb->stream));
+    }
+  }
+
+  ifail = lbmi_time_end(lb);
+  if (ifail) return ifail;
+
+  lbmi_swapf(lb);
+
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  lbmi_lb_collide  (lb_collide, collision.c:143-163)
+ *
+ *****************************************************************************/
+
+int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
+
+  lbmi_hydro_dev_t h = lbmi_hydro_dev(hydro);
+
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+  HIPCHECK(hipSetDevice(lb->device));
+
+  if (lb->pending_prop) {
+    /* FUSED: propagation(t) and, by index wrap / overlapped exchange, the
+     * halo swap(t), are done inside the collision(t+1) kernel */
+    if (!lb->pending_halo) {
+      return lbmi_fail(LBMI_ERR_STATE, "propagation pending without halo");
+    }
+    lb->pending_prop = 0;
+    lb->pending_halo = 0;
+    return lbmi_fused_step(lb, &h);
+  }
+
+  if (lb->pending_halo) {
+    return lbmi_fail(LBMI_ERR_STATE, "lb_collide after lb_halo without "
+		     "lb_propagation");
+  }
+
+  KCHECK(lbmi_k_collide(&lb->kp, lb->f, &h, lb->stream));
+
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  lbmi_lb_halo  (lb_halo, model.c:553-563)
+ *
+ *****************************************************************************/
+
+int lbmi_lb_halo(lbmi_t * lb) {
+
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+
+  if (lb->opts.mode == LBMI_MODE_FUSED) {
+    if (lb->pending_prop) {
+      return lbmi_fail(LBMI_ERR_STATE, "lb_halo while a propagation is pending");
+    }
+    lb->pending_halo = 1;
+    return 0;
+  }
+
+  return lbmi_halo(lb, lb->f, lb->opts.halo_scheme);
+}
+
+/*****************************************************************************
+ *
+ *  lbmi_lb_propagation  (lb_propagation, propagation.c:43-98)
+ *
+ *****************************************************************************/
+
+int lbmi_lb_propagation(lbmi_t * lb) {
+
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+
+  if (lb->opts.mode == LBMI_MODE_FUSED) {
+    if (lb->pending_prop) {
+      return lbmi_fail(LBMI_ERR_STATE, "two propagations without a collision");
+    }
+    if (!lb->pending_halo) {
+      /* A propagation that follows no halo swap (stale halos) cannot be
+       * deferred faithfully: run it now */
+      HIPCHECK(hipSetDevice(lb->device));
+      KCHECK(lbmi_k_propagate(&lb->kp, lb->f, lb->fprime, lb->stream));
+      lbmi_swapf(lb);
+      return 0;
+    }
+    lb->pending_prop = 1;
+    return 0;
+  }
+
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_propagate(&lb->kp, lb->f, lb->fprime, lb->stream));
+  lbmi_swapf(lb);
+
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  lbmi_lb_flush
+ *
+ *  Materialise a pending halo swap and propagation so that f is exactly
+ *  what the reference holds at this point of the time step.
+ *
+ *****************************************************************************/
+
+int lbmi_lb_flush(lbmi_t * lb) {
+
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+  HIPCHECK(hipSetDevice(lb->device));
+
+  if (lb->pending_halo) {
+    int ifail = lbmi_halo(lb, lb->f, lb->opts.halo_scheme);
+    if (ifail) return ifail;
+    lb->pending_halo = 0;
+  }
+  if (lb->pending_prop) {
+    KCHECK(lbmi_k_propagate(&lb->kp, lb->f, lb->fprime, lb->stream));
+    lbmi_swapf(lb);
+    lb->pending_prop = 0;
+  }
+
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  lbmi_lb_memcpy_*  (lb_memcpy, model.c:228-266)
+ *
+ *****************************************************************************/
+
+int lbmi_lb_memcpy_h2d(lbmi_t * lb, const double * f_host) {
+  size_t sz;
+  if (lb == NULL || f_host == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+  HIPCHECK(hipSetDevice(lb->device));
+  sz = sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel;
+  lb->pending_halo = 0;
+  lb->pending_prop = 0;
+  HIPCHECK(hipMemcpyAsync(lb->f, f_host, sz, hipMemcpyHostToDevice, lb->stream));
+  HIPCHECK(hipStreamSynchronize(lb->stream));
+  return 0;
+}
+
+int lbmi_lb_memcpy_d2h(lbmi_t * lb, double * f_host) {
+  size_t sz;
+  int ifail;
+  if (lb == NULL || f_host == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  ifail = lbmi_lb_flush(lb);
+  if (ifail) return ifail;
+  sz = sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel;
+  HIPCHECK(hipMemcpyAsync(f_host, lb->f, sz, hipMemcpyDeviceToHost, lb->stream));
+  HIPCHECK(hipStreamSynchronize(lb->stream));
+  return 0;
+}
+
+int lbmi_lb_moments(lbmi_t * lb, const char * status, double out[9]) {
+  int ifail;
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  ifail = lbmi_lb_flush(lb);
+  if (ifail) return ifail;
+  return lbmi_moments(lb, lb->f, status, out);
+}
+
+int lbmi_synchronize(lbmi_t * lb) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  HIPCHECK(hipSetDevice(lb->device));
+  HIPCHECK(hipStreamSynchronize(lb->comm_stream));
+  HIPCHECK(hipStreamSynchronize(lb->stream));
+  return 0;
+}
+
+int lbmi_stream(lbmi_t * lb, void ** stream) {
+  if (lb == NULL || stream == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  *stream = (void *) lb->stream;
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  RCCL ring over the X slabs. Replaces the MPI Cartesian communicator of
+ *  the reference (coords.c, halo_swap.c:742-784) for the one decomposed
+ *  direction.
+ *
+ *****************************************************************************/
+
+int lbmi_comm_unique_id(void * id) {
+  ncclUniqueId nid;
+  if (id == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (sizeof(ncclUniqueId) > LBMI_UNIQUE_ID_BYTES) {
+    return lbmi_fail(LBMI_ERR_RCCL, "ncclUniqueId is %zu bytes",
+		     sizeof(ncclUniqueId));
+  }
+  NCCLCHECK(ncclGetUniqueId(&nid));
+  memset(id, 0, LBMI_UNIQUE_ID_BYTES);
+  memcpy(id, &nid, sizeof(nid));
+  return 0;
+}
+
+int lbmi_comm_init(lbmi_t * lb, const void * id) {
+
+  ncclUniqueId nid;
+  size_t bytes;
+
+  if (lb == NULL || id == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->have_comm) return lbmi_fail(LBMI_ERR_STATE, "communicator exists");
+  HIPCHECK(hipSetDevice(lb->device));
+
+  memcpy(&nid, id, sizeof(nid));
+  NCCLCHECK(ncclCommInitRank(&lb->comm, lb->opts.cartsz, nid,
+			     lb->opts.cartrank));
+  lb->have_comm = 1;
+
+  /* four plane buffers large enough for every component (full scheme,
+   * or a generic field of up to LBMI_NVEL_MAX components) */
+  lb->xbuf_doubles = (size_t) lb->kp.strx*LBMI_NVEL_MAX;
+  bytes = sizeof(double)*lb->xbuf_doubles;
+  HIPCHECK(hipMalloc((void **) &lb->sendlo, bytes));
+  HIPCHECK(hipMalloc((void **) &lb->sendhi, bytes));
+  HIPCHECK(hipMalloc((void **) &lb->recvlo, bytes));
+  HIPCHECK(hipMalloc((void **) &lb->recvhi, bytes));
+
+  return 0;
+}
+
+int lbmi_comm_free(lbmi_t * lb) {
+  if (lb == NULL) return 0;
+  if (lb->have_comm) {
+    hipFree(lb->sendlo); hipFree(lb->sendhi);
+    hipFree(lb->recvlo); hipFree(lb->recvhi);
+    lb->sendlo = lb->sendhi = lb->recvlo = lb->recvhi = NULL;
+    ncclCommDestroy(lb->comm);
+    lb->have_comm = 0;
+  }
+  return 0;
+}

@@ -1,0 +1,98 @@
+/*
+ * lbmi_kernels.h -- internal interface between the ANSI C host code
+ * (lbmi_host.c) and the HIP kernels (lbmi_kernels.hip). Not installed.
+ */
+
+#ifndef LBMI_KERNELS_H
+#define LBMI_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBMI_NVEL_MAX 27
+
+/* Kernel parameter block: passed BY VALUE as a kernel argument (scalar
+ * registers / kernarg segment), never through __constant__ copies. */
+
+typedef struct lbmi_kparam_s {
+  int nvel;
+  int scheme;              /* lbmi_relaxation_t */
+  int nlocal[3];
+  int nhalo;
+  int nall[3];
+  int strx;                /* nall[Y]*nall[Z] */
+  int stry;                /* nall[Z] */
+  long long nsite;
+  double rtau_shear;
+  double rtau_bulk;
+  double rtau_even;        /* ghost modes 10, 14, 18 (d3q19); all for d3q27 */
+  double rtau_odd;         /* ghost modes 11-13, 15-17 (d3q19) */
+  double fbody[3];
+} lbmi_kparam_t;
+
+typedef struct lbmi_hydro_dev_s {
+  const double * force;
+  const char   * status;
+  double       * rho;
+  double       * u;
+} lbmi_hydro_dev_t;
+
+/* Halo pass description: components (populations) to copy to the low-side
+ * and to the high-side halo plane of direction dir. */
+
+typedef struct lbmi_halo_sel_s {
+  int nlo;
+  int nhi;
+  int8_t lo[LBMI_NVEL_MAX];   /* components wanted in the low halo plane  */
+  int8_t hi[LBMI_NVEL_MAX];   /* components wanted in the high halo plane */
+} lbmi_halo_sel_t;
+
+/* All launchers return hipError_t as int (0 = hipSuccess) */
+
+int lbmi_k_collide(const lbmi_kparam_t * kp, double * f,
+		   const lbmi_hydro_dev_t * h, void * stream);
+
+int lbmi_k_propagate(const lbmi_kparam_t * kp, const double * f,
+		     double * fprime, void * stream);
+
+/* xlo..xhi: 0-based x planes (in nall) to process, inclusive.
+ * wrapmask: bit d set = wrap direction d by index arithmetic. */
+int lbmi_k_propagate_collide(const lbmi_kparam_t * kp, const double * f,
+			     double * fprime, const lbmi_hydro_dev_t * h,
+			     int wrapmask, int xlo, int xhi, void * stream);
+
+/* In-place periodic halo copy for direction dir on an SoA field with
+ * components of stride nsite. */
+int lbmi_k_halo_copy(const lbmi_kparam_t * kp, int dir,
+		     const lbmi_halo_sel_t * sel, double * data,
+		     void * stream);
+
+/* X direction through buffers (multi-GPU): pack the first interior plane
+ * (components sel->hi: wanted by the lower neighbour's HIGH halo) into
+ * buf_lo and the last interior plane (components sel->lo) into buf_hi;
+ * unpack the reverse way. Buffer layout: [component k][plane site]. */
+int lbmi_k_halo_pack_x(const lbmi_kparam_t * kp, const lbmi_halo_sel_t * sel,
+		       const double * data, double * buf_lo, double * buf_hi,
+		       void * stream);
+int lbmi_k_halo_unpack_x(const lbmi_kparam_t * kp, const lbmi_halo_sel_t * sel,
+			 double * data, const double * buf_lo,
+			 const double * buf_hi, void * stream);
+
+/* Moments: partial (nblk x 12 doubles workspace) then final (out_dev[9]) */
+int lbmi_k_moments_nblk(void);
+int lbmi_k_moments(const lbmi_kparam_t * kp, const double * f,
+		   const char * status, double * work, double * out_dev,
+		   void * stream);
+
+/* Host model tables (same constexpr source as the device code) */
+int lbmi_k_model(int nvel, int8_t * cv, double * wv, double * na, double * ma);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,981 @@
+/*****************************************************************************
+ *
+ *  lbmi_kernels.hip
+ *
+ *  Hand-written HIP kernels for gfx950 (MI355X, CDNA4) for the lattice-
+ *  Boltzmann hot path of the reference (zazu29/ludwig v0.20.1):
+ *
+ *    k_collide            lb_collision_mrt1[_site]   collision.c:223-599
+ *    k_propagate          lb_propagation_kernel      propagation.c:162-212
+ *    k_propagate_collide  the two above fused: propagation(t)+collision(t+1)
+ *    k_halo_copy/pack/unpack  halo_swap_pack_rank1 / unpack_rank1 and the
+ *                         periodic self-wrap          halo_swap.c:709-1274
+ *    k_moments_*          stats_distribution_print + distribution_gm_kernel
+ *                                              stats_distribution.c:55-350
+ *
+ *  Design: the step is an HBM-bandwidth-bound 19/27-point
+ *  stencil in FP64. One lattice site per lane, 64-wide wavefronts along the
+ *  contiguous z direction of the reference's SoA layout, so that every
+ *  population is one fully coalesced 512-byte access per wave. No MFMA (not
+ *  a contraction), no LDS staging of f (each population value is consumed
+ *  by exactly one site: there is no reuse for LDS to capture). The velocity
+ *  set, weights and the mode matrix are compile-time constants folded into
+ *  the instruction stream; run-time parameters travel as a by-value kernel
+ *  argument. Blocks are remapped so that each XCD (private L2) owns one
+ *  contiguous chunk of the lattice.
+ *
+ *****************************************************************************/
+
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+#include "lbmi_kernels.h"
+
+namespace {
+
+enum {LBMI_M10 = 0, LBMI_BGK = 1, LBMI_TRT = 2};
+enum {BLOCK = 256};
+
+/* ---- compile-time model description -------------------------------------
+ *
+ * Velocity sets and weights: lb_d3q19.h:26-38, lb_d3q27.h:28-43.
+ * Mode matrix ma: lb_d3q19.c:107-153, lb_d3q27.c:150-195.
+ * Normalisers na[m] = 1/sum_p w_p ma[m][p]^2: lb_d3q19.c:69-77.
+ * Inverse mi[p][m] = w_p na[m] ma[m][p]: model.c:381-387.
+ */
+
+template <int NVEL> struct VSet;
+
+template <> struct VSet<19> {
+  static constexpr int cv_[19][3] = {
+    { 0, 0, 0},
+    { 1, 1, 0}, { 1, 0, 1}, { 1, 0, 0}, { 1, 0,-1}, { 1,-1, 0},
+    { 0, 1, 1}, { 0, 1, 0}, { 0, 1,-1}, { 0, 0, 1}, { 0, 0,-1},
+    { 0,-1, 1}, { 0,-1, 0}, { 0,-1,-1},
+    {-1, 1, 0}, {-1, 0, 1}, {-1, 0, 0}, {-1, 0,-1}, {-1,-1, 0}};
+  __host__ __device__ static constexpr int c(int p, int a) { return cv_[p][a]; }
+  __host__ __device__ static constexpr double w(int p) {
+    int c2 = c(p,0)*c(p,0) + c(p,1)*c(p,1) + c(p,2)*c(p,2);
+    return (c2 == 0) ? 12.0/36.0 : ((c2 == 1) ? 2.0/36.0 : 1.0/36.0);
+  }
+  __host__ __device__ static constexpr double ma(int m, int p) {
+    double cx = c(p,0), cy = c(p,1), cz = c(p,2);
+    double cs2 = 1.0/3.0;
+    double c2 = cx*cx + cy*cy + cz*cz;
+    double chi1 = (2.0*c2 - 3.0)*(3.0*cz*cz - c2);
+    double chi2 = (2.0*c2 - 3.0)*(cy*cy - cx*cx);
+    double chi3 = 3.0*c2*c2 - 6.0*c2 + 1;
+    switch (m) {
+    case  0: return 1.0;
+    case  1: return cx;
+    case  2: return cy;
+    case  3: return cz;
+    case  4: return cx*cx - cs2;
+    case  5: return cx*cy;
+    case  6: return cx*cz;
+    case  7: return cy*cy - cs2;
+    case  8: return cy*cz;
+    case  9: return cz*cz - cs2;
+    case 10: return chi1;
+    case 11: return chi1*cx;
+    case 12: return chi1*cy;
+    case 13: return chi1*cz;
+    case 14: return chi2;
+    case 15: return chi2*cx;
+    case 16: return chi2*cy;
+    case 17: return chi2*cz;
+    default: return chi3;
+    }
+  }
+};
+
+template <> struct VSet<27> {
+  /* p = 0 rest; then x slowest, z fastest from (-1,-1,-1), rest skipped */
+  __host__ __device__ static constexpr int c(int p, int a) {
+    if (p == 0) return 0;
+    int q = p - 1;
+    if (q >= 13) q += 1;
+    return (a == 0) ? (q/9 - 1) : ((a == 1) ? ((q/3) % 3 - 1) : (q % 3 - 1));
+  }
+  __host__ __device__ static constexpr double w(int p) {
+    int c2 = c(p,0)*c(p,0) + c(p,1)*c(p,1) + c(p,2)*c(p,2);
+    return (c2 == 0) ? 64.0/216.0 : ((c2 == 1) ? 16.0/216.0 :
+				     ((c2 == 2) ? 4.0/216.0 : 1.0/216.0));
+  }
+  __host__ __device__ static constexpr double ma(int m, int p) {
+    double cx = c(p,0), cy = c(p,1), cz = c(p,2);
+    double cs2 = 1.0/3.0;
+    double hx = cx*cx - cs2, hy = cy*cy - cs2, hz = cz*cz - cs2;
+    switch (m) {
+    case  0: return 1.0;
+    case  1: return cx;
+    case  2: return cy;
+    case  3: return cz;
+    case  4: return hx;
+    case  5: return cx*cy;
+    case  6: return cx*cz;
+    case  7: return hy;
+    case  8: return cy*cz;
+    case  9: return hz;
+    case 10: return 3.0*hx*cy;
+    case 11: return 3.0*hx*cz;
+    case 12: return 3.0*hy*cz;
+    case 13: return 3.0*hy*cx;
+    case 14: return 3.0*hz*cx;
+    case 15: return 3.0*hz*cy;
+    case 16: return cx*cy*cz;
+    case 17: return 9.0*hx*hy;
+    case 18: return 9.0*hy*hz;
+    case 19: return 9.0*hz*hx;
+    case 20: return 9.0*hx*cy*cz;
+    case 21: return 9.0*hy*cz*cx;
+    case 22: return 9.0*hz*cx*cy;
+    case 23: return 9.0*hx*hy*cz;
+    case 24: return 9.0*hy*hz*cx;
+    case 25: return 9.0*hz*hx*cy;
+    default: return 27.0*hx*hy*hz;
+    }
+  }
+};
+
+template <int NVEL> struct Model : VSet<NVEL> {
+  using V = VSet<NVEL>;
+  __host__ __device__ static constexpr double na(int m) {
+    double wip = 0.0;
+    for (int p = 0; p < NVEL; p++) wip += V::w(p)*V::ma(m,p)*V::ma(m,p);
+    return 1.0/wip;
+  }
+  __host__ __device__ static constexpr double mi(int p, int m) {
+    return V::w(p)*na(m)*V::ma(m,p);
+  }
+};
+
+/* Compile-time loop: the body sees the index as a constant expression, so
+ * every table look-up above folds and zero coefficients vanish. */
+
+template <int N> using IC = std::integral_constant<int, N>;
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F && f) {
+  if constexpr (B < E) {
+    f(IC<B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+/* ---- per-site collision ---------------------------------------------------
+ *
+ * lb_collision_mrt1_site, collision.c:259-599, fluctuations off, no free-
+ * energy stress, constant viscosity. The reference transforms f to all NVEL
+ * modes, relaxes, and transforms back with dense matrices. Here the same
+ * linear map is evaluated in a form that needs only what each scheme uses:
+ *
+ *   f' = keep f + MI_hydro (m'_hydro - keep m_hydro) + sum_k MI[:,k] e_k
+ *
+ * with keep = 1 - rtau_even. M10 (all ghost rates 1): keep = 0, e = 0, so
+ * f' is rebuilt from the 10 hydrodynamic moments alone. BGK: the stress
+ * enters only through its equilibrium. TRT (d3q19): e_k = (rtau_even -
+ * rtau_odd) m_k for the six odd ghost modes.
+ *
+ * REFERENCE QUIRK reproduced for parity: for d3q19 the reference's unrolled
+ * d3q19_f2mode_chunk forms mode 13 with coefficient 0 instead of
+ * ma[13][4] = -1 for population 4 (collision.c:2300), i.e. m13_ref =
+ * m13 + f4. With ghost rate r13 the surviving part (1 - r13) f4 is
+ * projected back through MI[:,13]. (No effect for M10.)
+ */
+
+struct Relax {
+  double rtau_s, rtau_b, rtau_e, rtau_o;
+};
+
+template <int NVEL, int SCHEME>
+__device__ __forceinline__
+void collide_site(double (&f)[NVEL], const double (&frc)[3], const Relax & rx,
+		  double & rho, double (&u)[3]) {
+
+  using M = Model<NVEL>;
+  constexpr bool keepf  = (SCHEME != LBMI_M10);
+  constexpr bool need_s = (SCHEME != LBMI_BGK);
+  constexpr bool odd    = (SCHEME == LBMI_TRT);
+  constexpr double r3 = 1.0/3.0;
+
+  /* rho and momentum: summed in p order with exact +-1 coefficients, as the
+   * reference's rows 0-3 of ma (collision.c:338-349) */
+  double g[3] = {0.0, 0.0, 0.0};
+  rho = 0.0;
+  static_for<0, NVEL>([&](auto P) {
+    constexpr int p = P;
+    rho += f[p];
+    static_for<0, 3>([&](auto A) {
+      constexpr int a = A;
+      if constexpr (M::c(p,a) ==  1) g[a] += f[p];
+      if constexpr (M::c(p,a) == -1) g[a] -= f[p];
+    });
+  });
+
+  double rrho = 1.0/rho;
+  u[0] = rrho*(g[0] + 0.5*frc[0]);            /* collision.c:376-382 */
+  u[1] = rrho*(g[1] + 0.5*frc[1]);
+  u[2] = rrho*(g[2] + 0.5*frc[2]);
+
+  /* second moment Pi_ab = sum_p f_p c_a c_b; S_ab = Pi_ab - delta_ab rho/3 */
+  double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   /* xx xy xz yy yz zz */
+  if constexpr (need_s) {
+    static_for<0, NVEL>([&](auto P) {
+      constexpr int p = P;
+      constexpr int cx = M::c(p,0), cy = M::c(p,1), cz = M::c(p,2);
+      if constexpr (cx*cx == 1) s[0] += f[p];
+      if constexpr (cx*cy == 1) s[1] += f[p];
+      if constexpr (cx*cy == -1) s[1] -= f[p];
+      if constexpr (cx*cz == 1) s[2] += f[p];
+      if constexpr (cx*cz == -1) s[2] -= f[p];
+      if constexpr (cy*cy == 1) s[3] += f[p];
+      if constexpr (cy*cz == 1) s[4] += f[p];
+      if constexpr (cy*cz == -1) s[4] -= f[p];
+      if constexpr (cz*cz == 1) s[5] += f[p];
+    });
+    s[0] -= r3*rho; s[3] -= r3*rho; s[5] -= r3*rho;
+  }
+
+  /* Stress relaxation, collision.c:408-474. ds = S' - keep S */
+  double ds[6];
+  {
+    const double keep = keepf ? (1.0 - rx.rtau_e) : 0.0;
+    const double seq[6] = {rho*u[0]*u[0], rho*u[0]*u[1], rho*u[0]*u[2],
+			   rho*u[1]*u[1], rho*u[1]*u[2], rho*u[2]*u[2]};
+    const double fc = 2.0 - rx.rtau_s;
+    const double uf[6] = {2.0*u[0]*frc[0], u[0]*frc[1] + frc[0]*u[1],
+			  u[0]*frc[2] + frc[0]*u[2], 2.0*u[1]*frc[1],
+			  u[1]*frc[2] + frc[1]*u[2], 2.0*u[2]*frc[2]};
+    if constexpr (need_s) {
+      double tr_s = s[0] + s[3] + s[5];
+      double tr_seq = seq[0] + seq[3] + seq[5];
+      double trp = r3*(tr_s - rx.rtau_b*(tr_s - tr_seq));
+      constexpr int diag[6] = {1, 0, 0, 1, 0, 1};
+      static_for<0, 6>([&](auto K) {
+	constexpr int k = K;
+	double sd  = s[k]   - (diag[k] ? r3*tr_s   : 0.0);
+	double sqd = seq[k] - (diag[k] ? r3*tr_seq : 0.0);
+	double sp  = sd - rx.rtau_s*(sd - sqd) + (diag[k] ? trp : 0.0)
+	  + fc*uf[k];
+	ds[k] = sp - keep*s[k];
+      });
+    }
+    else {
+      /* BGK: bulk = shear = ghost rate, S drops out of S' - keep S */
+      static_for<0, 6>([&](auto K) {
+	constexpr int k = K;
+	ds[k] = rx.rtau_s*seq[k] + fc*uf[k];
+      });
+    }
+  }
+
+  /* hydrodynamic part of the back projection:
+   * w_p [ (drho - 1.5 tr dS) + 3 dg.c + 4.5 dS_aa c_a^2 + 9 dS_ab c_a c_b ] */
+  const double keep = keepf ? (1.0 - rx.rtau_e) : 0.0;
+  const double drho = rho - keep*rho;
+  const double a0 = drho - 1.5*(ds[0] + ds[3] + ds[5]);
+  const double ag[3] = {3.0*(g[0] + frc[0] - keep*g[0]),
+			3.0*(g[1] + frc[1] - keep*g[1]),
+			3.0*(g[2] + frc[2] - keep*g[2])};
+  const double bd[3] = {4.5*ds[0], 4.5*ds[3], 4.5*ds[5]};
+  const double bo[3] = {9.0*ds[1], 9.0*ds[2], 9.0*ds[4]};  /* xy xz yz */
+
+  /* odd ghost modes (TRT, d3q19) and the mode-13 quirk */
+  double e[NVEL];
+  if constexpr (NVEL == 19 && keepf) {
+    static_for<10, 19>([&](auto K) { e[K] = 0.0; });
+    if constexpr (odd) {
+      const double dr = rx.rtau_e - rx.rtau_o;
+      static_for<11, 18>([&](auto K) {
+	constexpr int k = K;
+	if constexpr (k != 14) {
+	  double mk = 0.0;
+	  static_for<0, NVEL>([&](auto P) {
+	    constexpr int p = P;
+	    constexpr double c = M::ma(k, p);
+	    if constexpr (c == 1.0) mk += f[p];
+	    else if constexpr (c == -1.0) mk -= f[p];
+	    else if constexpr (c != 0.0) mk += c*f[p];
+	  });
+	  e[k] = dr*mk;
+	}
+      });
+    }
+    e[13] += (1.0 - rx.rtau_o)*f[4];          /* collision.c:2300 */
+  }
+
+  static_for<0, NVEL>([&](auto P) {
+    constexpr int p = P;
+    constexpr int cx = M::c(p,0), cy = M::c(p,1), cz = M::c(p,2);
+    double t = a0;
+    if constexpr (cx ==  1) t += ag[0];
+    if constexpr (cx == -1) t -= ag[0];
+    if constexpr (cy ==  1) t += ag[1];
+    if constexpr (cy == -1) t -= ag[1];
+    if constexpr (cz ==  1) t += ag[2];
+    if constexpr (cz == -1) t -= ag[2];
+    if constexpr (cx != 0) t += bd[0];
+    if constexpr (cy != 0) t += bd[1];
+    if constexpr (cz != 0) t += bd[2];
+    if constexpr (cx*cy ==  1) t += bo[0];
+    if constexpr (cx*cy == -1) t -= bo[0];
+    if constexpr (cx*cz ==  1) t += bo[1];
+    if constexpr (cx*cz == -1) t -= bo[1];
+    if constexpr (cy*cz ==  1) t += bo[2];
+    if constexpr (cy*cz == -1) t -= bo[2];
+    double fn = M::w(p)*t;
+    if constexpr (keepf) fn += keep*f[p];
+    if constexpr (NVEL == 19 && keepf) {
+      if constexpr (odd) {
+	static_for<11, 18>([&](auto K) {
+	  constexpr int k = K;
+	  if constexpr (k != 14 && M::mi(p,k) != 0.0) fn += M::mi(p,k)*e[k];
+	});
+      }
+      else {
+	if constexpr (M::mi(p,13) != 0.0) fn += M::mi(p,13)*e[13];
+      }
+    }
+    f[p] = fn;
+  });
+}
+
+/* ---- helpers -------------------------------------------------------------- */
+
+/* XCD-aware mapping of blockIdx to a logical block: blocks b and b + 8 run
+ * on the same XCD (round-robin dispatch), so give XCD (b & 7) the contiguous
+ * chunk [xcd*per, (xcd+1)*per) of the 1-d site range; neighbouring blocks
+ * then share their boundary cache lines in one L2. A different hardware
+ * placement only changes speed. Returns false for padding blocks. */
+
+__device__ __forceinline__ bool logical_block(unsigned nblk, unsigned & lb) {
+  unsigned per = (nblk + 7u) >> 3;
+  lb = (blockIdx.x & 7u)*per + (blockIdx.x >> 3);
+  return (blockIdx.x >> 3) < per && lb < nblk;
+}
+
+struct Site {
+  int i;         /* site index */
+  int x, y, z;   /* 0-based coordinates in nall */
+  bool interior; /* y and z inside the local domain (x is by construction) */
+};
+
+__device__ __forceinline__ Site decode(const lbmi_kparam_t & kp, int i) {
+  Site s;
+  s.i = i;
+  s.x = i / kp.strx;
+  int r = i - s.x*kp.strx;
+  s.y = r / kp.stry;
+  s.z = r - s.y*kp.stry;
+  s.interior = (s.y >= kp.nhalo) && (s.y < kp.nhalo + kp.nlocal[1]) &&
+    (s.z >= kp.nhalo) && (s.z < kp.nhalo + kp.nlocal[2]);
+  return s;
+}
+
+/* ---- k_collide: in-place collision of interior fluid sites ---------------- */
+
+template <int NVEL, int SCHEME>
+__global__ __launch_bounds__(BLOCK)
+void k_collide(lbmi_kparam_t kp, double * __restrict__ f,
+	       lbmi_hydro_dev_t h, int i0, int i1, unsigned nblk) {
+
+  unsigned lb;
+  if (!logical_block(nblk, lb)) return;
+  int i = i0 + (int) (lb*BLOCK + threadIdx.x);
+  if (i >= i1) return;
+
+  Site s = decode(kp, i);
+  if (!s.interior) return;
+  if (h.status && h.status[i] != 0) return;      /* collision.c:299-304 */
+
+  const size_t ns = (size_t) kp.nsite;
+  double fl[NVEL];
+  static_for<0, NVEL>([&](auto P) { fl[P] = f[ns*P + i]; });
+
+  double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
+  if (h.force) {
+    frc[0] += h.force[i];
+    frc[1] += h.force[ns + i];
+    frc[2] += h.force[2*ns + i];
+  }
+
+  Relax rx = {kp.rtau_shear, kp.rtau_bulk, kp.rtau_even, kp.rtau_odd};
+  double rho, u[3];
+  collide_site<NVEL, SCHEME>(fl, frc, rx, rho, u);
+
+  static_for<0, NVEL>([&](auto P) { f[ns*P + i] = fl[P]; });
+  if (h.rho) h.rho[i] = rho;
+  if (h.u) {
+    h.u[i] = u[0];
+    h.u[ns + i] = u[1];
+    h.u[2*ns + i] = u[2];
+  }
+}
+
+/* ---- k_propagate: pull streaming ------------------------------------------ */
+
+template <int NVEL>
+__global__ __launch_bounds__(BLOCK)
+void k_propagate(lbmi_kparam_t kp, const double * __restrict__ f,
+		 double * __restrict__ fp, int i0, int i1, unsigned nblk) {
+
+  using M = Model<NVEL>;
+  unsigned lb;
+  if (!logical_block(nblk, lb)) return;
+  int i = i0 + (int) (lb*BLOCK + threadIdx.x);
+  if (i >= i1) return;
+
+  Site s = decode(kp, i);
+  const size_t ns = (size_t) kp.nsite;
+  const int m = s.interior ? 1 : 0;         /* kernel_mask_v, kernel.c:374 */
+
+  static_for<0, NVEL>([&](auto P) {
+    constexpr int p = P;
+    int off = m*(M::c(p,0)*kp.strx + M::c(p,1)*kp.stry + M::c(p,2));
+    fp[ns*p + i] = f[ns*p + (i - off)];
+  });
+}
+
+/* ---- k_propagate_collide: the fused kernel --------------------------------
+ *
+ * fprime[i] = collide( f[i - c_p] ), one pass: 2*NVEL*8 bytes per site.
+ * WRAP: directions flagged in wrapmask are periodic and local to this
+ * GPU; a pull that would land in the halo is redirected to the periodic
+ * image inside the domain, so no halo swap is needed for them.
+ * y/z halo sites inside the processed x-planes copy in place (as
+ * lb_propagation_kernel does), which keeps every store stream contiguous. */
+
+template <int NVEL, int SCHEME, bool WRAP>
+__global__ __launch_bounds__(BLOCK)
+void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
+			 double * __restrict__ fp, lbmi_hydro_dev_t h,
+			 int wrapmask, int i0, int i1, unsigned nblk) {
+
+  using M = Model<NVEL>;
+  unsigned lb;
+  if (!logical_block(nblk, lb)) return;
+  int i = i0 + (int) (lb*BLOCK + threadIdx.x);
+  if (i >= i1) return;
+
+  Site s = decode(kp, i);
+  const size_t ns = (size_t) kp.nsite;
+  const int m = s.interior ? 1 : 0;
+
+  /* wrap corrections (in sites) for pulls across the low / high face */
+  int wlo[3] = {0, 0, 0};
+  int whi[3] = {0, 0, 0};
+  if constexpr (WRAP) {
+    const int nh = kp.nhalo;
+    if ((wrapmask & 1) && s.x == nh) wlo[0] = kp.nlocal[0]*kp.strx;
+    if ((wrapmask & 1) && s.x == nh + kp.nlocal[0] - 1) whi[0] = -kp.nlocal[0]*kp.strx;
+    if ((wrapmask & 2) && s.y == nh) wlo[1] = kp.nlocal[1]*kp.stry;
+    if ((wrapmask & 2) && s.y == nh + kp.nlocal[1] - 1) whi[1] = -kp.nlocal[1]*kp.stry;
+    if ((wrapmask & 4) && s.z == nh) wlo[2] = kp.nlocal[2];
+    if ((wrapmask & 4) && s.z == nh + kp.nlocal[2] - 1) whi[2] = -kp.nlocal[2];
+  }
+
+  double fl[NVEL];
+  static_for<0, NVEL>([&](auto P) {
+    constexpr int p = P;
+    constexpr int cx = M::c(p,0), cy = M::c(p,1), cz = M::c(p,2);
+    int off = cx*kp.strx + cy*kp.stry + cz;
+    if constexpr (WRAP) {
+      if constexpr (cx ==  1) off -= wlo[0];
+      if constexpr (cx == -1) off -= whi[0];
+      if constexpr (cy ==  1) off -= wlo[1];
+      if constexpr (cy == -1) off -= whi[1];
+      if constexpr (cz ==  1) off -= wlo[2];
+      if constexpr (cz == -1) off -= whi[2];
+    }
+    fl[p] = f[ns*p + (i - m*off)];
+  });
+
+  bool active = s.interior;
+  if (h.status) active = active && (h.status[i] == 0);
+
+  if (active) {
+    double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
+    if (h.force) {
+      frc[0] += h.force[i];
+      frc[1] += h.force[ns + i];
+      frc[2] += h.force[2*ns + i];
+    }
+    Relax rx = {kp.rtau_shear, kp.rtau_bulk, kp.rtau_even, kp.rtau_odd};
+    double rho, u[3];
+    collide_site<NVEL, SCHEME>(fl, frc, rx, rho, u);
+    if (h.rho) h.rho[i] = rho;
+    if (h.u) {
+      h.u[i] = u[0];
+      h.u[ns + i] = u[1];
+      h.u[2*ns + i] = u[2];
+    }
+  }
+
+  static_for<0, NVEL>([&](auto P) { fp[ns*P + i] = fl[P]; });
+}
+
+/* ---- halo kernels ----------------------------------------------------------
+ *
+ * One pass of halo_swap_packed (halo_swap.c:709-1063) for direction dir on
+ * one rank with periodic wrap: the first/last interior plane is copied to
+ * the opposite width-1 halo plane next to the interior, over the FULL
+ * extent (halo included) of the two other directions, so that running the
+ * passes in the order X, Y, Z completes edges and corners.
+ * grid.y enumerates (side, component); threads enumerate plane sites. */
+
+__device__ __forceinline__
+size_t plane_site(const lbmi_kparam_t & kp, int dir, int j, int coord) {
+  /* j-th site of the plane dir = coord, fastest index = fastest memory */
+  if (dir == 0) return (size_t) coord*kp.strx + j;
+  if (dir == 1) {
+    int x = j / kp.nall[2];
+    int z = j - x*kp.nall[2];
+    return (size_t) x*kp.strx + (size_t) coord*kp.stry + z;
+  }
+  /* dir == 2: j runs over (x, y), y fastest */
+  return (size_t) j*kp.stry + coord;
+}
+
+__device__ __forceinline__ int plane_size(const lbmi_kparam_t & kp, int dir) {
+  if (dir == 0) return kp.nall[1]*kp.nall[2];
+  if (dir == 1) return kp.nall[0]*kp.nall[2];
+  return kp.nall[0]*kp.nall[1];
+}
+
+__global__ __launch_bounds__(BLOCK)
+void k_halo_copy(lbmi_kparam_t kp, int dir, lbmi_halo_sel_t sel,
+		 double * __restrict__ data) {
+
+  int j = blockIdx.x*BLOCK + threadIdx.x;
+  if (j >= plane_size(kp, dir)) return;
+
+  int k = blockIdx.y;
+  const int nh = kp.nhalo;
+  int comp, src, dst;
+  if (k < sel.nlo) {
+    comp = sel.lo[k];                      /* low halo <- last interior */
+    src = nh + kp.nlocal[dir] - 1;
+    dst = nh - 1;
+  }
+  else {
+    comp = sel.hi[k - sel.nlo];            /* high halo <- first interior */
+    src = nh;
+    dst = nh + kp.nlocal[dir];
+  }
+  double * d = data + (size_t) kp.nsite*comp;
+  d[plane_site(kp, dir, j, dst)] = d[plane_site(kp, dir, j, src)];
+}
+
+/* X planes to/from contiguous buffers [k][plane site] for the RCCL ring:
+ * buf_lo carries the FIRST interior plane (wanted by the lower neighbour's
+ * high halo: components sel.hi), buf_hi the LAST interior plane
+ * (components sel.lo). */
+
+__global__ __launch_bounds__(BLOCK)
+void k_halo_pack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
+		   const double * __restrict__ data,
+		   double * __restrict__ buf_lo, double * __restrict__ buf_hi) {
+
+  int j = blockIdx.x*BLOCK + threadIdx.x;
+  int psz = kp.strx;
+  if (j >= psz) return;
+  int k = blockIdx.y;
+  const int nh = kp.nhalo;
+  if (k < sel.nhi) {
+    const double * d = data + (size_t) kp.nsite*sel.hi[k];
+    buf_lo[(size_t) k*psz + j] = d[(size_t) nh*kp.strx + j];
+  }
+  else {
+    int kk = k - sel.nhi;
+    const double * d = data + (size_t) kp.nsite*sel.lo[kk];
+    buf_hi[(size_t) kk*psz + j] = d[(size_t) (nh + kp.nlocal[0] - 1)*kp.strx + j];
+  }
+}
+
+/* buf_lo here is what arrived from the LOWER neighbour (its last interior
+ * plane, components sel.lo) -> our low halo plane; buf_hi arrived from the
+ * UPPER neighbour (its first interior plane, components sel.hi). */
+
+__global__ __launch_bounds__(BLOCK)
+void k_halo_unpack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
+		     double * __restrict__ data,
+		     const double * __restrict__ buf_lo,
+		     const double * __restrict__ buf_hi) {
+
+  int j = blockIdx.x*BLOCK + threadIdx.x;
+  int psz = kp.strx;
+  if (j >= psz) return;
+  int k = blockIdx.y;
+  const int nh = kp.nhalo;
+  if (k < sel.nlo) {
+    double * d = data + (size_t) kp.nsite*sel.lo[k];
+    d[(size_t) (nh - 1)*kp.strx + j] = buf_lo[(size_t) k*psz + j];
+  }
+  else {
+    int kk = k - sel.nlo;
+    double * d = data + (size_t) kp.nsite*sel.hi[kk];
+    d[(size_t) (nh + kp.nlocal[0])*kp.strx + j] = buf_hi[(size_t) kk*psz + j];
+  }
+}
+
+/* ---- moments ----------------------------------------------------------------
+ *
+ * Per interior fluid site: rho = sum_p f_p in p order (lb_0th_moment,
+ * model.c:819-833); volume, sum rho, sum rho^2, min, max
+ * (stats_distribution.c:82-98); momentum sum_p f_p c_p for p >= 1 with
+ * Kahan compensation (kahan_add_double, util_sum.c:30-40;
+ * distribution_gm_kernel, stats_distribution.c:311-322).
+ * Reduction: per-lane accumulators -> wavefront reduction by cross-lane
+ * shuffles (64 lanes) -> one LDS slot per wave -> per-block partial in
+ * global memory -> a single-block second kernel. No atomics: the result is
+ * bitwise reproducible for a given launch geometry. */
+
+struct Kahan { double sum, cs; };
+
+__device__ __forceinline__ void kadd(Kahan & k, double val) {
+  double y = val + k.cs;
+  double t = k.sum + y;
+  k.cs = y - (t - k.sum);
+  k.sum = t;
+}
+
+__device__ __forceinline__ void kmerge(Kahan & k, const Kahan & o) {
+  kadd(k, o.sum);                       /* kahan_add, util_sum.c:142-150 */
+  kadd(k, o.cs);
+}
+
+struct Partial {
+  double vol, srho, srho2, rmin, rmax;
+  Kahan g[3];
+};
+
+__device__ __forceinline__ double shfl_down_d(double v, int d) {
+  return __shfl_down(v, d, 64);
+}
+
+__device__ __forceinline__ void partial_merge_shfl(Partial & a, int d) {
+  Partial o;
+  o.vol = shfl_down_d(a.vol, d);
+  o.srho = shfl_down_d(a.srho, d);
+  o.srho2 = shfl_down_d(a.srho2, d);
+  o.rmin = shfl_down_d(a.rmin, d);
+  o.rmax = shfl_down_d(a.rmax, d);
+  for (int ia = 0; ia < 3; ia++) {
+    o.g[ia].sum = shfl_down_d(a.g[ia].sum, d);
+    o.g[ia].cs = shfl_down_d(a.g[ia].cs, d);
+  }
+  a.vol += o.vol;
+  a.srho += o.srho;
+  a.srho2 += o.srho2;
+  a.rmin = fmin(a.rmin, o.rmin);
+  a.rmax = fmax(a.rmax, o.rmax);
+  for (int ia = 0; ia < 3; ia++) kmerge(a.g[ia], o.g[ia]);
+}
+
+__device__ __forceinline__ void partial_zero(Partial & a) {
+  a.vol = 0.0; a.srho = 0.0; a.srho2 = 0.0;
+  a.rmin = 1.7976931348623157e308; a.rmax = -1.7976931348623157e308;
+  for (int ia = 0; ia < 3; ia++) { a.g[ia].sum = 0.0; a.g[ia].cs = 0.0; }
+}
+
+enum {MOM_NBLK = 1024, MOM_NW = 11};   /* doubles per partial record */
+
+__device__ __forceinline__ void partial_store(const Partial & a, double * w) {
+  w[0] = a.vol; w[1] = a.srho; w[2] = a.srho2; w[3] = a.rmin; w[4] = a.rmax;
+  for (int ia = 0; ia < 3; ia++) {
+    w[5 + 2*ia] = a.g[ia].sum; w[6 + 2*ia] = a.g[ia].cs;
+  }
+}
+
+__device__ __forceinline__ void partial_load(Partial & a, const double * w) {
+  a.vol = w[0]; a.srho = w[1]; a.srho2 = w[2]; a.rmin = w[3]; a.rmax = w[4];
+  for (int ia = 0; ia < 3; ia++) {
+    a.g[ia].sum = w[5 + 2*ia]; a.g[ia].cs = w[6 + 2*ia];
+  }
+}
+
+/* Block-level reduction of per-lane partials; result valid in thread 0 */
+
+__device__ __forceinline__ void block_reduce(Partial & acc) {
+  __shared__ double lds[(BLOCK/64)*MOM_NW];
+  for (int d = 32; d >= 1; d >>= 1) partial_merge_shfl(acc, d);
+  int wave = threadIdx.x >> 6;
+  int lane = threadIdx.x & 63;
+  if (lane == 0) partial_store(acc, lds + wave*MOM_NW);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < BLOCK/64; w++) {
+      Partial o;
+      partial_load(o, lds + w*MOM_NW);
+      acc.vol += o.vol; acc.srho += o.srho; acc.srho2 += o.srho2;
+      acc.rmin = fmin(acc.rmin, o.rmin); acc.rmax = fmax(acc.rmax, o.rmax);
+      for (int ia = 0; ia < 3; ia++) kmerge(acc.g[ia], o.g[ia]);
+    }
+  }
+}
+
+template <int NVEL>
+__global__ __launch_bounds__(BLOCK)
+void k_moments_partial(lbmi_kparam_t kp, const double * __restrict__ f,
+		       const char * __restrict__ status,
+		       double * __restrict__ work) {
+
+  using M = Model<NVEL>;
+  const size_t ns = (size_t) kp.nsite;
+  const int nh = kp.nhalo;
+  const int i0 = nh*kp.strx;
+  const int i1 = (nh + kp.nlocal[0])*kp.strx;
+
+  Partial acc;
+  partial_zero(acc);
+
+  for (int i = i0 + blockIdx.x*BLOCK + threadIdx.x; i < i1;
+       i += gridDim.x*BLOCK) {
+    Site s = decode(kp, i);
+    if (!s.interior) continue;
+    if (status && status[i] != 0) continue;
+    double fl[NVEL];
+    static_for<0, NVEL>([&](auto P) { fl[P] = f[ns*P + i]; });
+    double rho = 0.0;
+    static_for<0, NVEL>([&](auto P) { rho += fl[P]; });
+    acc.vol += 1.0;
+    acc.srho += rho;
+    acc.srho2 += rho*rho;
+    acc.rmin = fmin(acc.rmin, rho);
+    acc.rmax = fmax(acc.rmax, rho);
+    static_for<1, NVEL>([&](auto P) {
+      constexpr int p = P;
+      static_for<0, 3>([&](auto A) {
+	constexpr int a = A;
+	if constexpr (M::c(p,a) ==  1) kadd(acc.g[a],  fl[p]);
+	if constexpr (M::c(p,a) == -1) kadd(acc.g[a], -fl[p]);
+      });
+    });
+  }
+
+  block_reduce(acc);
+  if (threadIdx.x == 0) partial_store(acc, work + (size_t) blockIdx.x*MOM_NW);
+}
+
+__global__ __launch_bounds__(BLOCK)
+void k_moments_final(int npartial, const double * __restrict__ work,
+		     double * __restrict__ out) {
+  Partial acc;
+  partial_zero(acc);
+  for (int b = threadIdx.x; b < npartial; b += BLOCK) {
+    Partial o;
+    partial_load(o, work + (size_t) b*MOM_NW);
+    acc.vol += o.vol; acc.srho += o.srho; acc.srho2 += o.srho2;
+    acc.rmin = fmin(acc.rmin, o.rmin); acc.rmax = fmax(acc.rmax, o.rmax);
+    for (int ia = 0; ia < 3; ia++) kmerge(acc.g[ia], o.g[ia]);
+  }
+  block_reduce(acc);
+  if (threadIdx.x == 0) {
+    out[0] = acc.vol; out[1] = acc.srho; out[2] = acc.srho2;
+    out[3] = acc.rmin; out[4] = acc.rmax;
+    out[5] = acc.g[0].sum + acc.g[0].cs;    /* kahan_sum, util_sum.c:61 */
+    out[6] = acc.g[1].sum + acc.g[1].cs;
+    out[7] = acc.g[2].sum + acc.g[2].cs;
+    out[8] = 0.0;
+  }
+}
+
+/* ---- launch helpers --------------------------------------------------------- */
+
+inline unsigned grid_for(unsigned nblk) { return ((nblk + 7u)/8u)*8u; }
+
+template <int NVEL>
+int launch_collide(const lbmi_kparam_t & kp, double * f,
+		   const lbmi_hydro_dev_t & h, hipStream_t st) {
+  int i0 = kp.nhalo*kp.strx;
+  int i1 = (kp.nhalo + kp.nlocal[0])*kp.strx;
+  unsigned nblk = (unsigned) ((i1 - i0 + BLOCK - 1)/BLOCK);
+  dim3 grid(grid_for(nblk)), block(BLOCK);
+  switch (kp.scheme) {
+  case LBMI_M10:
+    hipLaunchKernelGGL((k_collide<NVEL, LBMI_M10>), grid, block, 0, st,
+		       kp, f, h, i0, i1, nblk);
+    break;
+  case LBMI_BGK:
+    hipLaunchKernelGGL((k_collide<NVEL, LBMI_BGK>), grid, block, 0, st,
+		       kp, f, h, i0, i1, nblk);
+    break;
+  case LBMI_TRT:
+    if constexpr (NVEL == 19) {
+      hipLaunchKernelGGL((k_collide<NVEL, LBMI_TRT>), grid, block, 0, st,
+			 kp, f, h, i0, i1, nblk);
+      break;
+    }
+    return (int) hipErrorInvalidValue;
+  default:
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
+template <int NVEL, bool WRAP>
+int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
+	      const lbmi_hydro_dev_t & h, int wrapmask, int i0, int i1,
+	      hipStream_t st) {
+  unsigned nblk = (unsigned) ((i1 - i0 + BLOCK - 1)/BLOCK);
+  dim3 grid(grid_for(nblk)), block(BLOCK);
+  switch (kp.scheme) {
+  case LBMI_M10:
+    hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_M10, WRAP>), grid,
+		       block, 0, st, kp, f, fp, h, wrapmask, i0, i1, nblk);
+    break;
+  case LBMI_BGK:
+    hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_BGK, WRAP>), grid,
+		       block, 0, st, kp, f, fp, h, wrapmask, i0, i1, nblk);
+    break;
+  case LBMI_TRT:
+    if constexpr (NVEL == 19) {
+      hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_TRT, WRAP>), grid,
+			 block, 0, st, kp, f, fp, h, wrapmask, i0, i1, nblk);
+      break;
+    }
+    return (int) hipErrorInvalidValue;
+  default:
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
+template <int NVEL>
+int model_tables(int8_t * cv, double * wv, double * na, double * ma) {
+  using M = Model<NVEL>;
+  for (int p = 0; p < NVEL; p++) {
+    for (int a = 0; a < 3; a++) cv[3*p + a] = (int8_t) M::c(p, a);
+    wv[p] = M::w(p);
+  }
+  for (int m = 0; m < NVEL; m++) {
+    na[m] = M::na(m);
+    for (int p = 0; p < NVEL; p++) ma[m*NVEL + p] = M::ma(m, p);
+  }
+  return 0;
+}
+
+} /* namespace */
+
+/* ---- C launchers ------------------------------------------------------------ */
+
+extern "C" int lbmi_k_collide(const lbmi_kparam_t * kp, double * f,
+			      const lbmi_hydro_dev_t * h, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  if (kp->nvel == 19) return launch_collide<19>(*kp, f, *h, st);
+  if (kp->nvel == 27) return launch_collide<27>(*kp, f, *h, st);
+  return (int) hipErrorInvalidValue;
+}
+
+extern "C" int lbmi_k_propagate(const lbmi_kparam_t * kp, const double * f,
+				double * fprime, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  int i0 = kp->nhalo*kp->strx;
+  int i1 = (kp->nhalo + kp->nlocal[0])*kp->strx;
+  unsigned nblk = (unsigned) ((i1 - i0 + BLOCK - 1)/BLOCK);
+  dim3 grid(grid_for(nblk)), block(BLOCK);
+  if (kp->nvel == 19) {
+    hipLaunchKernelGGL((k_propagate<19>), grid, block, 0, st, *kp, f, fprime,
+		       i0, i1, nblk);
+  }
+  else if (kp->nvel == 27) {
+    hipLaunchKernelGGL((k_propagate<27>), grid, block, 0, st, *kp, f, fprime,
+		       i0, i1, nblk);
+  }
+  else {
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_propagate_collide(const lbmi_kparam_t * kp,
+					const double * f, double * fprime,
+					const lbmi_hydro_dev_t * h,
+					int wrapmask, int xlo, int xhi,
+					void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  if (xhi < xlo) return 0;
+  int i0 = xlo*kp->strx;
+  int i1 = (xhi + 1)*kp->strx;
+  if (kp->nvel == 19) {
+    return wrapmask ? launch_pc<19, true>(*kp, f, fprime, *h, wrapmask, i0, i1, st)
+      : launch_pc<19, false>(*kp, f, fprime, *h, 0, i0, i1, st);
+  }
+  if (kp->nvel == 27) {
+    return wrapmask ? launch_pc<27, true>(*kp, f, fprime, *h, wrapmask, i0, i1, st)
+      : launch_pc<27, false>(*kp, f, fprime, *h, 0, i0, i1, st);
+  }
+  return (int) hipErrorInvalidValue;
+}
+
+extern "C" int lbmi_k_halo_copy(const lbmi_kparam_t * kp, int dir,
+				const lbmi_halo_sel_t * sel, double * data,
+				void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  int psz = (dir == 0) ? kp->nall[1]*kp->nall[2]
+    : ((dir == 1) ? kp->nall[0]*kp->nall[2] : kp->nall[0]*kp->nall[1]);
+  int ncomp = sel->nlo + sel->nhi;
+  if (ncomp == 0) return 0;
+  dim3 grid((psz + BLOCK - 1)/BLOCK, ncomp), block(BLOCK);
+  hipLaunchKernelGGL(k_halo_copy, grid, block, 0, st, *kp, dir, *sel, data);
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_halo_pack_x(const lbmi_kparam_t * kp,
+				  const lbmi_halo_sel_t * sel,
+				  const double * data, double * buf_lo,
+				  double * buf_hi, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  int ncomp = sel->nlo + sel->nhi;
+  if (ncomp == 0) return 0;
+  dim3 grid((kp->strx + BLOCK - 1)/BLOCK, ncomp), block(BLOCK);
+  hipLaunchKernelGGL(k_halo_pack_x, grid, block, 0, st, *kp, *sel, data,
+		     buf_lo, buf_hi);
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_halo_unpack_x(const lbmi_kparam_t * kp,
+				    const lbmi_halo_sel_t * sel,
+				    double * data, const double * buf_lo,
+				    const double * buf_hi, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  int ncomp = sel->nlo + sel->nhi;
+  if (ncomp == 0) return 0;
+  dim3 grid((kp->strx + BLOCK - 1)/BLOCK, ncomp), block(BLOCK);
+  hipLaunchKernelGGL(k_halo_unpack_x, grid, block, 0, st, *kp, *sel, data,
+		     buf_lo, buf_hi);
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_moments_nblk(void) { return MOM_NBLK; }
+
+extern "C" int lbmi_k_moments(const lbmi_kparam_t * kp, const double * f,
+			      const char * status, double * work,
+			      double * out_dev, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  int n = kp->nlocal[0]*kp->strx;
+  int nblk = (n + BLOCK - 1)/BLOCK;
+  if (nblk > MOM_NBLK) nblk = MOM_NBLK;
+  if (kp->nvel == 19) {
+    hipLaunchKernelGGL((k_moments_partial<19>), dim3(nblk), dim3(BLOCK), 0, st,
+		       *kp, f, status, work);
+  }
+  else if (kp->nvel == 27) {
+    hipLaunchKernelGGL((k_moments_partial<27>), dim3(nblk), dim3(BLOCK), 0, st,
+		       *kp, f, status, work);
+  }
+  else {
+    return (int) hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(BLOCK), 0, st, nblk, work,
+		     out_dev);
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_model(int nvel, int8_t * cv, double * wv, double * na,
+			    double * ma) {
+  if (nvel == 19) return model_tables<19>(cv, wv, na, ma);
+  if (nvel == 27) return model_tables<27>(cv, wv, na, ma);
+  return -1;
+}

@@ -1,0 +1,257 @@
+"""Host-side mirror of the reference's LB interface on top of liblbmi.so.
+
+Names follow the reference (zazu29/ludwig): lb_collide (collision.c:143),
+lb_halo / lb_halo_swap (model.c:553-595), lb_propagation (propagation.c:43),
+lb_memcpy (model.c:228), hydro_t fields rho/u/force (hydro.h:31-47),
+map_t status (map.h:22-40). PyTorch is used only as plumbing: device memory
+(torch tensors) and host<->device copies. All arithmetic happens in the HIP
+kernels behind the C-ABI; nothing here computes on the CPU.
+
+Array convention (the reference's SoA order, see include/lbmi.h):
+  f:      (nvel, nall_x, nall_y, nall_z) float64
+  force:  (3, nall_x, nall_y, nall_z),  u likewise;  rho: (nall_x, ...)
+  status: (nall_x, nall_y, nall_z) int8, 0 = MAP_FLUID
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import lib as _l
+
+M10, BGK, TRT = 0, 1, 2                    # lb_relaxation_enum_t
+EAGER, FUSED = 0, 1                        # lbmi_mode_t
+HALO_FULL, HALO_REDUCED = 0, 2             # lbmi_halo_t
+_SCHEMES = {"m10": M10, "bgk": BGK, "trt": TRT}
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise _l.LbmiError("no GPU visible to torch: ludwig_amd has no CPU path")
+    return torch
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class Hydro:
+    """Device arrays of hydro_t (+ map_t status) that lb_collide borrows."""
+
+    def __init__(self, nall, device, force=None, status=None, with_rho_u=True):
+        torch = _torch()
+        self.nall = tuple(nall)
+        self.device = device
+        self.force = None
+        self.status = None
+        self.rho = None
+        self.u = None
+        if force is not None:
+            self.force = torch.from_numpy(np.ascontiguousarray(
+                force, dtype=np.float64)).to(device)
+            assert tuple(self.force.shape) == (3,) + self.nall
+        if status is not None:
+            self.status = torch.from_numpy(np.ascontiguousarray(
+                status, dtype=np.int8)).to(device)
+            assert tuple(self.status.shape) == self.nall
+        if with_rho_u:
+            self.rho = torch.zeros(self.nall, dtype=torch.float64, device=device)
+            self.u = torch.zeros((3,) + self.nall, dtype=torch.float64,
+                                 device=device)
+        # the kernels run on the library's own stream: make sure torch's
+        # fills/copies have landed
+        torch.cuda.synchronize(device)
+
+    def ptrs(self):
+        h = _l.HydroPtrs()
+        h.force = _ptr(self.force)
+        h.status = _ptr(self.status)
+        h.rho = _ptr(self.rho)
+        h.u = _ptr(self.u)
+        return h
+
+
+class LB:
+    """lb_t: the distributions of one rank and the operators of a time step."""
+
+    def __init__(self, nvel=19, nlocal=(64, 64, 64), nhalo=1, mode=EAGER,
+                 halo_scheme=HALO_FULL, device=0, cartsz=1, cartrank=0):
+        torch = _torch()
+        self._lib = _l.library()
+        self._h = ctypes.c_void_p()
+        opts = _l.Options()
+        _l.check(self._lib.lbmi_options_default(ctypes.byref(opts)))
+        opts.nvel = nvel
+        opts.ndist = 1
+        opts.nlocal[:] = list(nlocal)
+        opts.nhalo = nhalo
+        opts.device = device
+        opts.mode = mode
+        opts.halo_scheme = halo_scheme
+        opts.cartsz = cartsz
+        opts.cartrank = cartrank
+        _l.check(self._lib.lbmi_create(ctypes.byref(opts), ctypes.byref(self._h)))
+        self.nvel = nvel
+        self.nlocal = tuple(nlocal)
+        self.nhalo = nhalo
+        self.mode = mode
+        self.nall = tuple(n + 2 * nhalo for n in nlocal)
+        self.nsite = self.nall[0] * self.nall[1] * self.nall[2]
+        self.device = torch.device("cuda", device)
+        # lb_data_create zero-initialises f and fprime (model.c:106-147)
+        self._a = torch.zeros((nvel,) + self.nall, dtype=torch.float64,
+                              device=self.device)
+        self._b = torch.zeros_like(self._a)
+        torch.cuda.synchronize(self.device)
+        _l.check(self._lib.lbmi_lb_bind(self._h, _ptr(self._a), _ptr(self._b)))
+
+    # -- life cycle ---------------------------------------------------------
+
+    def free(self):
+        if self._h:
+            self._lib.lbmi_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    # -- parameters ---------------------------------------------------------
+
+    def relaxation_set(self, scheme, eta=0.1, zeta=0.1, rho0=1.0):
+        """lb_collision_relaxation_set + relaxation_times_set."""
+        if isinstance(scheme, str):
+            scheme = _SCHEMES[scheme]
+        _l.check(self._lib.lbmi_set_relaxation(self._h, scheme, rho0, eta, zeta))
+
+    def body_force_set(self, fbody):
+        a = (ctypes.c_double * 3)(*[float(x) for x in fbody])
+        _l.check(self._lib.lbmi_set_body_force(self._h, a))
+
+    def relaxation_rates(self):
+        a = (ctypes.c_double * 4)()
+        _l.check(self._lib.lbmi_relaxation_rates(self._h, a))
+        return tuple(a)
+
+    # -- distributions ------------------------------------------------------
+
+    @property
+    def f(self):
+        """Device tensor currently playing the role of lb->target->f."""
+        pf = ctypes.c_void_p()
+        _l.check(self._lib.lbmi_lb_pointers(self._h, ctypes.byref(pf), None))
+        return self._a if pf.value == self._a.data_ptr() else self._b
+
+    @property
+    def fprime(self):
+        return self._b if self.f is self._a else self._a
+
+    def lb_memcpy_h2d(self, f_host):
+        f_host = np.ascontiguousarray(f_host, dtype=np.float64)
+        assert f_host.shape == (self.nvel,) + self.nall
+        _l.check(self._lib.lbmi_lb_memcpy_h2d(
+            self._h, f_host.ctypes.data_as(ctypes.c_void_p)))
+
+    def lb_memcpy_d2h(self):
+        out = np.empty((self.nvel,) + self.nall, dtype=np.float64)
+        _l.check(self._lib.lbmi_lb_memcpy_d2h(
+            self._h, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    # -- the time step (ludwig.c:802-860) ----------------------------------
+
+    def lb_collide(self, hydro=None):
+        h = hydro.ptrs() if hydro is not None else None
+        _l.check(self._lib.lbmi_lb_collide(
+            self._h, ctypes.byref(h) if h is not None else None))
+
+    def lb_halo(self):
+        _l.check(self._lib.lbmi_lb_halo(self._h))
+
+    def lb_propagation(self):
+        _l.check(self._lib.lbmi_lb_propagation(self._h))
+
+    def lb_flush(self):
+        _l.check(self._lib.lbmi_lb_flush(self._h))
+
+    def step(self, hydro=None):
+        self.lb_collide(hydro)
+        self.lb_halo()
+        self.lb_propagation()
+
+    def moments(self, status=None):
+        """Volume, sum rho, sum rho^2, min, max, g_x, g_y, g_z, 0 (interior,
+        fluid sites; this rank)."""
+        out = (ctypes.c_double * 9)()
+        _l.check(self._lib.lbmi_lb_moments(self._h, _ptr(status), out))
+        return np.array(out[:])
+
+    # -- stateless kernels on caller-owned tensors ---------------------------
+
+    def collide(self, f, hydro=None):
+        h = hydro.ptrs() if hydro is not None else None
+        _l.check(self._lib.lbmi_collide(
+            self._h, _ptr(f), ctypes.byref(h) if h is not None else None))
+
+    def halo(self, f, scheme=HALO_FULL):
+        _l.check(self._lib.lbmi_halo(self._h, _ptr(f), scheme))
+
+    def propagate(self, f, fprime):
+        _l.check(self._lib.lbmi_propagate(self._h, _ptr(f), _ptr(fprime)))
+
+    def propagate_collide(self, f, fprime, hydro=None, wrap=True):
+        h = hydro.ptrs() if hydro is not None else None
+        _l.check(self._lib.lbmi_propagate_collide(
+            self._h, _ptr(f), _ptr(fprime),
+            ctypes.byref(h) if h is not None else None, 1 if wrap else 0))
+
+    def field_halo(self, data):
+        nel = 1 if data.dim() == 3 else data.shape[0]
+        _l.check(self._lib.lbmi_field_halo(self._h, nel, _ptr(data)))
+
+    def moments_of(self, f, status=None):
+        out = (ctypes.c_double * 9)()
+        _l.check(self._lib.lbmi_moments(self._h, _ptr(f), _ptr(status), out))
+        return np.array(out[:])
+
+    # -- streams, timing, communicator -------------------------------------
+
+    def synchronize(self):
+        _l.check(self._lib.lbmi_synchronize(self._h))
+
+    def timing(self, on=True):
+        _l.check(self._lib.lbmi_timing(self._h, 1 if on else 0))
+
+    def timing_read(self):
+        ms = ctypes.c_double()
+        n = ctypes.c_int()
+        _l.check(self._lib.lbmi_timing_read(self._h, ctypes.byref(ms),
+                                            ctypes.byref(n)))
+        return ms.value, n.value
+
+    @staticmethod
+    def comm_unique_id():
+        buf = ctypes.create_string_buffer(_l.UNIQUE_ID_BYTES)
+        _l.check(_l.library().lbmi_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id):
+        buf = ctypes.create_string_buffer(bytes(unique_id), _l.UNIQUE_ID_BYTES)
+        _l.check(self._lib.lbmi_comm_init(self._h, buf))
+
+
+def model(nvel):
+    """cv, wv, na, ma as the reference builds them (lb_d3q19.c, lb_d3q27.c)."""
+    lib = _l.library()
+    cv = np.zeros((nvel, 3), dtype=np.int8)
+    wv = np.zeros(nvel)
+    na = np.zeros(nvel)
+    ma = np.zeros((nvel, nvel))
+    _l.check(lib.lbmi_model(nvel, cv.ctypes.data_as(ctypes.c_void_p),
+                            wv.ctypes.data_as(ctypes.c_void_p),
+                            na.ctypes.data_as(ctypes.c_void_p),
+                            ma.ctypes.data_as(ctypes.c_void_p)))
+    return {"nvel": nvel, "cv": cv, "wv": wv, "na": na, "ma": ma}

@@ -1,0 +1,353 @@
+"""Parity of the HIP path (through the C-ABI, ludwig_amd.LB) with the oracle
+and with the compiled-reference golden vectors. Needs an MI355X.
+
+Tolerances: bit-exact for pure data movement (halo, propagation); for the
+collision max|df|/max|f| <= 1e-12 and 1e-12 relative on conserved density and
+momentum (BASELINE.json north_star). The collision cannot be
+bit-exact: the reference sums dense 19x19 transforms without FMA on x86, the
+kernel evaluates the same linear map in factored form with FMA contraction.
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lb_oracle as lbo                       # noqa: E402
+from tests.common import (RTOL_CONSERVED, RTOL_F, golden_names, interior,  # noqa: E402
+                          load_golden, momentum_scale, relmax, shell1,
+                          status_from_meta, xplanes)
+from tests.regression_cases import (close_as_printed, initial_f,  # noqa: E402
+                                    load_expected)
+
+
+def make_lb(meta, mode=0, halo_scheme=0, **kw):
+    import ludwig_amd
+    lb = ludwig_amd.LB(meta["nvel"], tuple(meta["nlocal"]), meta["nhalo"],
+                       mode=mode, halo_scheme=halo_scheme, **kw)
+    lb.relaxation_set(meta["scheme"], meta["eta"], meta["zeta"], meta["rho0"])
+    lb.body_force_set(meta["fbody"])
+    return lb
+
+
+def make_hydro(lb, g, meta):
+    import ludwig_amd
+    st = status_from_meta(meta)
+    return ludwig_amd.Hydro(lb.nall, lb.device, force=g["force"],
+                            status=st if meta["solid"] else None)
+
+
+def oracle_param(meta):
+    return lbo.make_param(meta["nvel"], meta["nlocal"], meta["nhalo"],
+                          meta["scheme"], meta["eta"], meta["zeta"],
+                          meta["rho0"], meta["fbody"])
+
+
+def dev(lb, a):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(lb.device)
+    torch.cuda.synchronize(lb.device)
+    return t
+
+
+def host(lb, t):
+    lb.synchronize()
+    return t.cpu().numpy()
+
+
+# --- golden vectors, one operator at a time (EAGER) --------------------------
+
+@pytest.mark.parametrize("name", golden_names())
+def test_collide_vs_reference(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    h = meta["nhalo"]
+    lb = make_lb(meta)
+    hy = make_hydro(lb, g, meta)
+    lb.lb_memcpy_h2d(g["f0"])
+    lb.lb_collide(hy)
+    f = lb.lb_memcpy_d2h()
+    assert relmax(interior(f, h), interior(g["f_collide"], h)) < RTOL_F
+    rho = host(lb, hy.rho)
+    u = host(lb, hy.u)
+    st = status_from_meta(meta)
+    fluid = interior(st, h) == 0
+    assert relmax(interior(rho, h)[fluid], interior(g["rho"], h)[fluid]) < RTOL_F
+    assert relmax(interior(u, h)[:, fluid], interior(g["u"], h)[:, fluid]) < RTOL_F
+    if meta["solid"]:
+        # non-fluid sites untouched (collision.c:299-304)
+        assert np.array_equal(interior(f, h)[:, ~fluid],
+                              interior(g["f0"], h)[:, ~fluid])
+    lb.free()
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names()
+                                  if "f_halo" in load_golden(n)])
+def test_halo_full_exact(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    lb = make_lb(meta)
+    # start from the reference's own post-collision state (NaN -> 0 in the
+    # never-exchanged outer layers, see tests/common.py:shell1)
+    lb.lb_memcpy_h2d(np.nan_to_num(g["f_collide"]))
+    lb.lb_halo()
+    f = lb.lb_memcpy_d2h()
+    h = meta["nhalo"]
+    assert np.array_equal(shell1(f, h), shell1(g["f_halo"], h))
+    lb.free()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_halo_propagation_exact(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    h = meta["nhalo"]
+    lb = make_lb(meta)
+    lb.lb_memcpy_h2d(np.nan_to_num(g["f_collide"]))
+    lb.lb_halo()
+    lb.lb_propagation()
+    f = lb.lb_memcpy_d2h()
+    assert np.array_equal(xplanes(f, h), xplanes(np.nan_to_num(g["f_prop"]), h))
+    lb.free()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_reduced_halo_same_interior(name):
+    # test_model.c:546-647: only populations that re-enter are required
+    g = load_golden(name)
+    meta = g["meta"]
+    h = meta["nhalo"]
+    lb = make_lb(meta, halo_scheme=2)
+    lb.lb_memcpy_h2d(np.nan_to_num(g["f_collide"]))
+    lb.lb_halo()
+    lb.lb_propagation()
+    f = lb.lb_memcpy_d2h()
+    assert np.array_equal(interior(f, h), interior(g["f_prop"], h))
+    lb.free()
+
+
+# --- whole time steps: EAGER and FUSED against the reference -----------------
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["eager", "fused"])
+@pytest.mark.parametrize("halo_scheme", [0, 2], ids=["full", "reduced"])
+@pytest.mark.parametrize("name", golden_names())
+def test_steps_vs_reference(name, mode, halo_scheme):
+    g = load_golden(name)
+    meta = g["meta"]
+    h = meta["nhalo"]
+    lb = make_lb(meta, mode=mode, halo_scheme=halo_scheme)
+    hy = make_hydro(lb, g, meta)
+    lb.lb_memcpy_h2d(g["f0"])
+    for _ in range(meta["nsteps"]):
+        lb.lb_collide(hy)
+        lb.lb_halo()
+        lb.lb_propagation()
+    st = hy.status
+    mo = lb.moments(st)                       # flushes in FUSED mode
+    f = lb.lb_memcpy_d2h()
+    assert relmax(interior(f, h), interior(g["f_final"], h)) < RTOL_F
+    p = oracle_param(meta)
+    mg = lbo.moments(p, np.ascontiguousarray(np.nan_to_num(g["f_final"])),
+                     status_from_meta(meta))
+    assert mo[0] == mg[0]
+    assert abs(mo[1] - mg[1]) / mg[1] < RTOL_CONSERVED
+    gscale = momentum_scale(g["f_final"], lbo.model(meta["nvel"])["cv"], h)
+    assert np.max(np.abs(mo[5:8] - mg[5:8])) / gscale < RTOL_CONSERVED
+    assert abs(mo[3] - mg[3]) < 1e-13 and abs(mo[4] - mg[4]) < 1e-13
+    lb.free()
+
+
+@pytest.mark.parametrize("name", ["q19_m10", "q19_trt_ffield", "q27_bgk"])
+def test_fused_equals_eager_bitwise_inputs(name):
+    """FUSED must reproduce EAGER: same collision arithmetic on the same
+    pulled values. Agreement is checked at 1e-14 (identical in practice)."""
+    g = load_golden(name)
+    meta = g["meta"]
+    h = meta["nhalo"]
+    out = []
+    for mode in (0, 1):
+        lb = make_lb(meta, mode=mode)
+        hy = make_hydro(lb, g, meta)
+        lb.lb_memcpy_h2d(g["f0"])
+        for _ in range(7):
+            lb.step(hy)
+        out.append(interior(lb.lb_memcpy_d2h(), h).copy())
+        lb.free()
+    assert relmax(out[1], out[0]) < 1e-14
+
+
+def test_fused_state_errors():
+    import ludwig_amd
+    lb = ludwig_amd.LB(19, (4, 4, 4), 1, mode=1)
+    lb.lb_halo()
+    lb.lb_propagation()
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.lb_propagation()              # two propagations, no collision
+    lb.lb_flush()
+    lb.lb_collide(None)
+    lb.free()
+
+
+# --- stateless fused kernel with a real halo (wrap off) ----------------------
+
+@pytest.mark.parametrize("name", ["q19_m10_fbody", "q19_bgk_ffield", "q27_m10_ffield",
+                                  "q19_m10_nh2_ffield"])
+def test_propagate_collide_with_halo(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    h = meta["nhalo"]
+    p = oracle_param(meta)
+    lb = make_lb(meta)
+    hy = make_hydro(lb, g, meta)
+    # oracle: halo, propagate, collide
+    f = np.nan_to_num(g["f_collide"]).copy()
+    lbo.halo(p, f)
+    fp = np.zeros_like(f)
+    lbo.propagate(p, f, fp)
+    lbo.collide(p, fp, g["force"].copy(), status_from_meta(meta))
+    # device: halo kernel then fused kernel without index wrap
+    a = dev(lb, np.nan_to_num(g["f_collide"]))
+    b = dev(lb, np.zeros_like(f))
+    lb.halo(a, 0)
+    lb.propagate_collide(a, b, hy, wrap=False)
+    out = host(lb, b)
+    assert relmax(interior(out, h), interior(fp, h)) < RTOL_F
+    # and with index wrap on un-haloed input
+    a2 = dev(lb, np.nan_to_num(g["f_collide"]))
+    b2 = dev(lb, np.zeros_like(f))
+    lb.propagate_collide(a2, b2, hy, wrap=True)
+    out2 = host(lb, b2)
+    assert np.array_equal(interior(out2, h), interior(out, h))
+    lb.free()
+
+
+# --- bigger seeded cases against the oracle ---------------------------------
+
+CASES = [
+    (19, (32, 24, 16), 1, "m10", 0.1, 0.3, (0, 0, 0), False),
+    (19, (17, 9, 33), 1, "bgk", 0.07, 0.07, (1e-6, 0, -2e-6), True),
+    (19, (16, 16, 16), 2, "trt", 0.1, 0.2, (0, 1e-6, 0), True),
+    (27, (20, 12, 28), 1, "m10", 0.1, 0.3, (1e-6, 1e-6, 0), True),
+    (27, (8, 8, 8), 1, "bgk", 0.2, 0.2, (0, 0, 0), False),
+    (19, (1, 5, 3), 1, "m10", 0.1, 0.3, (0, 0, 0), False),     # degenerate x
+    (19, (2, 2, 2), 1, "bgk", 0.1, 0.1, (0, 0, 0), False),
+]
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["eager", "fused"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "q%d-%s-%s" % (c[0], "x".join(map(str, c[1])), c[3]))
+def test_seeded_vs_oracle(case, mode):
+    import ludwig_amd
+    nvel, nlocal, nhalo, scheme, eta, zeta, fbody, ffield = case
+    p = lbo.make_param(nvel, nlocal, nhalo, scheme, eta, zeta, 1.0, fbody)
+    f0 = lbo.init_synthetic(p)
+    nall = lbo.nall(p)
+    force = None
+    if ffield:
+        rng = np.random.default_rng(7)
+        force = 1e-6 * rng.standard_normal((3,) + nall)
+    nsteps = 6
+    # oracle
+    f = f0.copy()
+    fp = np.zeros_like(f)
+    for _ in range(nsteps):
+        f, fp = lbo.step(p, f, fp, force)
+    # device
+    lb = ludwig_amd.LB(nvel, nlocal, nhalo, mode=mode,
+                       halo_scheme=2 if mode else 0)
+    lb.relaxation_set(scheme, eta, zeta)
+    lb.body_force_set(fbody)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, force=force)
+    lb.lb_memcpy_h2d(f0)
+    for _ in range(nsteps):
+        lb.step(hy)
+    mo = lb.moments()
+    out = lb.lb_memcpy_d2h()
+    assert relmax(interior(out, nhalo), interior(f, nhalo)) < RTOL_F
+    mg = lbo.moments(p, f)
+    assert abs(mo[1] - mg[1]) / mg[1] < RTOL_CONSERVED
+    gscale = momentum_scale(f, lbo.model(nvel)["cv"], nhalo)
+    assert np.max(np.abs(mo[5:8] - mg[5:8])) / gscale < RTOL_CONSERVED
+    lb.free()
+
+
+def test_trt_d3q27_rejected():
+    import ludwig_amd
+    lb = ludwig_amd.LB(27, (4, 4, 4))
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.relaxation_set("trt", 0.1, 0.1)
+    lb.free()
+
+
+# --- generic field halo (hydro_u_halo) ---------------------------------------
+
+@pytest.mark.parametrize("nhalo", [1, 2])
+def test_field_halo(nhalo):
+    import ludwig_amd
+    nlocal = (6, 5, 4)
+    lb = ludwig_amd.LB(19, nlocal, nhalo)
+    p = lbo.make_param(19, nlocal, nhalo)
+    rng = np.random.default_rng(3)
+    u = rng.standard_normal((3,) + lbo.nall(p))
+    ref = u.copy()
+    lbo.halo(p, ref)
+    t = dev(lb, u)
+    lb.field_halo(t)
+    assert np.array_equal(host(lb, t), ref)
+    lb.free()
+
+
+# --- reference regression log on the device ---------------------------------
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["eager", "fused"])
+def test_regression_log_1dp(mode):
+    import ludwig_amd
+    case = load_expected()["serial-dist-1dp"]
+    m = lbo.model(19)
+    f0 = initial_f(case, m)
+    lb = ludwig_amd.LB(19, tuple(case["size"]), 1, mode=mode)
+    lb.relaxation_set(case["scheme"], case["eta"], case["zeta"])
+    hy = ludwig_amd.Hydro(lb.nall, lb.device)
+    lb.lb_memcpy_h2d(f0)
+    for _ in range(case["steps"]):
+        lb.step(hy)
+    mo = lb.moments()
+    exp = case["final"]
+    mean = mo[1] / mo[0]
+    var = abs(mo[2] / mo[0] - mean * mean)
+    assert close_as_printed(mo[1], exp["rho_total"], 2)
+    assert close_as_printed(mean, exp["rho_mean"], 11)
+    assert close_as_printed(mo[3], exp["rho_min"], 11)
+    assert close_as_printed(mo[4], exp["rho_max"], 11)
+    assert close_as_printed(var, exp["rho_var"], sig=8)
+    assert close_as_printed(mo[5], exp["momentum"][0], sig=8)
+    u = interior(host(lb, hy.u), 1)
+    assert close_as_printed(u[0].min(), exp["u_min"][0], sig=8)
+    assert close_as_printed(u[0].max(), exp["u_max"][0], sig=8)
+    lb.free()
+
+
+# --- RCCL ring on one GPU: rank 0 is its own neighbour ----------------------
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["eager", "fused"])
+def test_rccl_self_ring(mode):
+    """With a 1-rank communicator the X halo goes through pack ->
+    ncclSend/ncclRecv (to self) -> unpack instead of the device-side copy;
+    the result must be identical."""
+    import ludwig_amd
+    g = load_golden("q19_m10_fbody")
+    meta = g["meta"]
+    h = meta["nhalo"]
+    res = []
+    for use_comm in (False, True):
+        lb = make_lb(meta, mode=mode, halo_scheme=2 if mode else 0)
+        if use_comm:
+            lb.comm_init(ludwig_amd.LB.comm_unique_id())
+        hy = make_hydro(lb, g, meta)
+        lb.lb_memcpy_h2d(g["f0"])
+        for _ in range(meta["nsteps"]):
+            lb.step(hy)
+        res.append(interior(lb.lb_memcpy_d2h(), h).copy())
+        lb.free()
+    assert np.array_equal(res[0], res[1])
+    assert relmax(res[1], interior(g["f_final"], h)) < RTOL_F
