@@ -69,11 +69,16 @@ def status_from_meta(meta):
 
 
 def momentum_scale(f, cv, nhalo):
-    """Sum over interior sites of |g_a| (max over a): the natural scale for
-    errors in the total momentum. The synthetic states have a net momentum
-    that cancels to ~0 (sines over whole periods), so |sum g| itself is an
-    ill-conditioned denominator; sum |g| is what rounding errors scale with.
+    """sum over interior sites and populations of |f_p c_pa| (max over a):
+    the scale rounding errors in the total momentum are proportional to.
+
+    The synthetic states have a net momentum that cancels to ~0 (sines over
+    whole periods) and even the per-site momentum is ~1e-2 of the population
+    sum it is formed from, so |sum g| is an ill-conditioned denominator for a
+    relative error; sum |f c| is the condition-free one (it equals |sum g| up
+    to a factor ~1/u for a uniform flow).
     """
-    fi = interior(f, nhalo)
-    g = np.tensordot(cv.astype(np.float64).T, fi, axes=(1, 0))
-    return float(np.max(np.sum(np.abs(g), axis=(1, 2, 3))))
+    fi = np.abs(interior(f, nhalo))
+    c = np.abs(cv.astype(np.float64))
+    g = np.tensordot(c.T, fi, axes=(1, 0))
+    return float(np.max(np.sum(g, axis=(1, 2, 3))))
