@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--hydro", type=int, default=1,
                     help="1: lb_collide reads hydro->force and writes "
                     "hydro->rho,u as the reference does; 0: NULL hydro arrays")
+    ap.add_argument("--tune", default="", help="key=value,... (lbmi_tune)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=10)
     return ap.parse_args()
@@ -131,6 +132,9 @@ def main():
                        cartsz=world, cartrank=rank)
     zeta = 0.3 if args.scheme == "m10" else 0.1
     lb.relaxation_set(args.scheme, 0.1, zeta)
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        lb.tune(k, int(v))
 
     if world > 1:
         ids = [ludwig_amd.LB.comm_unique_id() if rank == 0 else None]

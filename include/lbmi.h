@@ -211,6 +211,11 @@ int lbmi_stream(lbmi_t * lb, void ** stream);
 int lbmi_timing(lbmi_t * lb, int on);
 int lbmi_timing_read(lbmi_t * lb, double * ms_total, int * nlaunch);
 
+/* Launch tuning of the fused kernel; results do not depend on it.
+ * "xcd_group": blocks per XCD interleave group (0 = one chunk per XCD);
+ * "lds_cap": dynamic LDS bytes per block, caps resident blocks per CU. */
+int lbmi_tune(lbmi_t * lb, const char * key, int value);
+
 /* ---- multi-GPU: 1-d slab decomposition along X over RCCL ---------------- */
 
 #define LBMI_UNIQUE_ID_BYTES 128

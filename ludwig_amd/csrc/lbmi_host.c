@@ -262,6 +262,11 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   lb->kp.stry = lb->kp.nall[Z];
   lb->kp.strx = lb->kp.nall[Y]*lb->kp.nall[Z];
   lb->kp.nsite = (long long) lb->kp.nall[X]*lb->kp.strx;
+  /* Reciprocals biased upwards by 2^-40 so that (int)((double) i*rstr) is
+   * exactly i/str for every 0 <= i < 2^31 (the product is >= q when
+   * i = q*str, and < q + 1 when i = q*str + str - 1 since q*str < 2^40) */
+  lb->kp.rstrx = (1.0/lb->kp.strx)*(1.0 + 1.0/1099511627776.0);
+  lb->kp.rstry = (1.0/lb->kp.stry)*(1.0 + 1.0/1099511627776.0);
 
   {
     double wv[LBMI_NVEL_MAX], na[LBMI_NVEL_MAX];
@@ -271,6 +276,15 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
     free(ma);
   }
   lbmi_halo_selections(lb);
+
+  /* Launch tuning of the fused kernel, measured on MI355X (profiles/,
+   * DESIGN.md): XCDs interleaved in groups of 16 blocks, and 64 KiB of
+   * (unused) dynamic LDS per 256-thread block so that 2 blocks = 8 waves
+   * are resident per CU: with more waves in flight the streamed lines of
+   * the 2 x nvel arrays overflow the 4 MiB L2 of an XCD before the
+   * neighbouring wave has used its share of them. */
+  lb->kp.xcd_group = 16;
+  lb->kp.lds_cap = 65536;
 
   /* Defaults of the reference: rho0 = 1, eta = zeta = 1/6 (physics.c:33-56) */
   lbmi_set_relaxation(lb, LBMI_RELAXATION_M10, 1.0, 1.0/6.0, 1.0/6.0);
@@ -493,6 +507,23 @@ int lbmi_timing_read(lbmi_t * lb, double * ms_total, int * nlaunch) {
     *nlaunch = n;
   }
   return 0;
+}
+
+int lbmi_tune(lbmi_t * lb, const char * key, int value) {
+  if (lb == NULL || key == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (strcmp(key, "xcd_group") == 0) {
+    if (value < 0 || value > 65536) return lbmi_fail(LBMI_ERR_ARGUMENT, "xcd_group");
+    lb->kp.xcd_group = value;
+    return 0;
+  }
+  if (strcmp(key, "lds_cap") == 0) {
+    if (value < 0 || value > 163840) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "lds_cap = %d (0..163840)", value);
+    }
+    lb->kp.lds_cap = value;
+    return 0;
+  }
+  return lbmi_fail(LBMI_ERR_ARGUMENT, "unknown tuning key %s", key);
 }
 
 int lbmi_collide(lbmi_t * lb, double * f, const lbmi_hydro_t * hydro) {

@@ -27,11 +27,16 @@ typedef struct lbmi_kparam_s {
   int strx;                /* nall[Y]*nall[Z] */
   int stry;                /* nall[Z] */
   long long nsite;
+  double rstrx;            /* (1/strx)(1 + 2^-40): exact index decode */
+  double rstry;
   double rtau_shear;
   double rtau_bulk;
   double rtau_even;        /* ghost modes 10, 14, 18 (d3q19); all for d3q27 */
   double rtau_odd;         /* ghost modes 11-13, 15-17 (d3q19) */
   double fbody[3];
+  /* launch tuning of the fused kernel (lbmi_tune) */
+  int xcd_group;           /* blocks per XCD interleave group; 0: chunked */
+  int lds_cap;             /* dynamic LDS bytes per block: occupancy cap */
 } lbmi_kparam_t;
 
 typedef struct lbmi_hydro_dev_s {

@@ -34,7 +34,53 @@
 namespace {
 
 enum {LBMI_M10 = 0, LBMI_BGK = 1, LBMI_TRT = 2};
-enum {BLOCK = 256};
+
+/* Tunables (defaults are the measured best; the -D overrides
+ * exist for the ablation runs recorded under profiles/) */
+#ifndef LBMI_BLOCK
+#define LBMI_BLOCK 256
+#endif
+#ifndef LBMI_XCD_REMAP
+#define LBMI_XCD_REMAP 1
+#endif
+#ifndef LBMI_NT
+#define LBMI_NT 0           /* bit 0: nontemporal loads, bit 1: stores */
+#endif
+#ifndef LBMI_ABL_NOCOLLIDE
+#define LBMI_ABL_NOCOLLIDE 0
+#endif
+#ifndef LBMI_HALO_LANES_COPY
+#define LBMI_HALO_LANES_COPY 0   /* 1: halo lanes copy in place (reference) */
+#endif
+#ifndef LBMI_ALIGN
+#define LBMI_ALIGN 16       /* block starts at multiples of this many sites */
+#endif
+#ifndef LBMI_SPT
+#define LBMI_SPT 1          /* sites per thread in the fused kernel */
+#endif
+#ifndef LBMI_WAVES
+#define LBMI_WAVES 1        /* __launch_bounds__ min waves per SIMD */
+#endif
+#ifndef LBMI_FAST_DECODE
+#define LBMI_FAST_DECODE 1
+#endif
+enum {BLOCK = LBMI_BLOCK, SPT = LBMI_SPT};
+
+/* streaming accesses of f: optionally with the nontemporal hint */
+__device__ __forceinline__ double ldf(const double * p) {
+#if LBMI_NT & 1
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void stf(double * p, double v) {
+#if LBMI_NT & 2
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 
 /* ---- compile-time model description -------------------------------------
  *
@@ -349,7 +395,21 @@ void collide_site(double (&f)[NVEL], const double (&frc)[3], const Relax & rx,
  * then share their boundary cache lines in one L2. A different hardware
  * placement only changes speed. Returns false for padding blocks. */
 
-__device__ __forceinline__ bool logical_block(unsigned nblk, unsigned & lb) {
+__device__ __forceinline__ bool logical_block(unsigned nblk, unsigned & lb,
+					      unsigned group = 0) {
+#if !LBMI_XCD_REMAP
+  lb = blockIdx.x;
+  return lb < nblk;
+#endif
+  if (group > 0) {
+    /* XCDs interleaved at a granularity of `group` blocks: all eight work
+     * in the same neighbourhood of every population array, which the HBM
+     * system serves better than eight far-apart windows per array */
+    unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    unsigned grp = j/group, within = j - grp*group;
+    lb = (grp*8u + xcd)*group + within;
+    return lb < nblk;
+  }
   unsigned per = (nblk + 7u) >> 3;
   lb = (blockIdx.x & 7u)*per + (blockIdx.x >> 3);
   return (blockIdx.x >> 3) < per && lb < nblk;
@@ -364,10 +424,18 @@ struct Site {
 __device__ __forceinline__ Site decode(const lbmi_kparam_t & kp, int i) {
   Site s;
   s.i = i;
+#if LBMI_FAST_DECODE
+  /* exact for 0 <= i < 2^31: rstr = (1/str)(1 + 2^-40), see lbmi_host.c */
+  s.x = (int) ((double) i*kp.rstrx);
+  int r = i - s.x*kp.strx;
+  s.y = (int) ((double) r*kp.rstry);
+  s.z = r - s.y*kp.stry;
+#else
   s.x = i / kp.strx;
   int r = i - s.x*kp.strx;
   s.y = r / kp.stry;
   s.z = r - s.y*kp.stry;
+#endif
   s.interior = (s.y >= kp.nhalo) && (s.y < kp.nhalo + kp.nlocal[1]) &&
     (s.z >= kp.nhalo) && (s.z < kp.nhalo + kp.nlocal[2]);
   return s;
@@ -446,19 +514,21 @@ void k_propagate(lbmi_kparam_t kp, const double * __restrict__ f,
  * y/z halo sites inside the processed x-planes copy in place (as
  * lb_propagation_kernel does), which keeps every store stream contiguous. */
 
-template <int NVEL, int SCHEME, bool WRAP>
-__global__ __launch_bounds__(BLOCK)
-void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
-			 double * __restrict__ fp, lbmi_hydro_dev_t h,
-			 int wrapmask, int i0, int i1, unsigned nblk) {
+template <int NVEL>
+struct PulledSite {
+  double fl[NVEL];
+  Site s;
+};
+
+/* phase 1: issue the NVEL pulls of site i */
+template <int NVEL, bool WRAP>
+__device__ __forceinline__
+void pc_pull(const lbmi_kparam_t & kp, const double * __restrict__ f,
+	     int wrapmask, int i, PulledSite<NVEL> & ps) {
 
   using M = Model<NVEL>;
-  unsigned lb;
-  if (!logical_block(nblk, lb)) return;
-  int i = i0 + (int) (lb*BLOCK + threadIdx.x);
-  if (i >= i1) return;
-
-  Site s = decode(kp, i);
+  ps.s = decode(kp, i);
+  const Site & s = ps.s;
   const size_t ns = (size_t) kp.nsite;
   const int m = s.interior ? 1 : 0;
 
@@ -475,7 +545,7 @@ void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
     if ((wrapmask & 4) && s.z == nh + kp.nlocal[2] - 1) whi[2] = -kp.nlocal[2];
   }
 
-  double fl[NVEL];
+#if LBMI_HALO_LANES_COPY
   static_for<0, NVEL>([&](auto P) {
     constexpr int p = P;
     constexpr int cx = M::c(p,0), cy = M::c(p,1), cz = M::c(p,2);
@@ -488,11 +558,45 @@ void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
       if constexpr (cz ==  1) off -= wlo[2];
       if constexpr (cz == -1) off -= whi[2];
     }
-    fl[p] = f[ns*p + (i - m*off)];
+    ps.fl[p] = ldf(&f[ns*p + (i - m*off)]);
   });
+#else
+  /* y/z halo lanes (2 per row) load nothing and store zeros: the halo of
+   * fprime is undefined until the next halo swap in any case, and writing
+   * them keeps every store stream contiguous (whole 64-byte sectors) */
+  static_for<0, NVEL>([&](auto P) { ps.fl[P] = 0.0; });
+  if (s.interior) {
+    static_for<0, NVEL>([&](auto P) {
+      constexpr int p = P;
+      constexpr int cx = M::c(p,0), cy = M::c(p,1), cz = M::c(p,2);
+      int off = cx*kp.strx + cy*kp.stry + cz;
+      if constexpr (WRAP) {
+	if constexpr (cx ==  1) off -= wlo[0];
+	if constexpr (cx == -1) off -= whi[0];
+	if constexpr (cy ==  1) off -= wlo[1];
+	if constexpr (cy == -1) off -= whi[1];
+	if constexpr (cz ==  1) off -= wlo[2];
+	if constexpr (cz == -1) off -= whi[2];
+      }
+      ps.fl[p] = ldf(&f[ns*p + (i - off)]);
+    });
+  }
+#endif
+}
 
-  bool active = s.interior;
+/* phase 2: collide (interior fluid sites) and store site i */
+template <int NVEL, int SCHEME>
+__device__ __forceinline__
+void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
+		      const lbmi_hydro_dev_t & h, int i,
+		      PulledSite<NVEL> & ps) {
+
+  const size_t ns = (size_t) kp.nsite;
+  bool active = ps.s.interior;
   if (h.status) active = active && (h.status[i] == 0);
+#if LBMI_ABL_NOCOLLIDE
+  active = false;
+#endif
 
   if (active) {
     double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
@@ -503,7 +607,7 @@ void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
     }
     Relax rx = {kp.rtau_shear, kp.rtau_bulk, kp.rtau_even, kp.rtau_odd};
     double rho, u[3];
-    collide_site<NVEL, SCHEME>(fl, frc, rx, rho, u);
+    collide_site<NVEL, SCHEME>(ps.fl, frc, rx, rho, u);
     if (h.rho) h.rho[i] = rho;
     if (h.u) {
       h.u[i] = u[0];
@@ -512,7 +616,35 @@ void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
     }
   }
 
-  static_for<0, NVEL>([&](auto P) { fp[ns*P + i] = fl[P]; });
+  static_for<0, NVEL>([&](auto P) { stf(&fp[ns*P + i], ps.fl[P]); });
+}
+
+template <int NVEL, int SCHEME, bool WRAP>
+__global__ __launch_bounds__(BLOCK, LBMI_WAVES)
+void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
+			 double * __restrict__ fp, lbmi_hydro_dev_t h,
+			 int wrapmask, int i0, int i1, unsigned nblk) {
+
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+
+  /* SPT sites per thread, BLOCK apart: the pulls of all of them are in
+   * flight before the first collision starts */
+  int i[SPT];
+  PulledSite<NVEL> ps[SPT];
+  /* blocks start at multiples of LBMI_ALIGN sites so that every store of a
+   * wave covers whole 64-byte sectors of every population array (nsite*8
+   * is a multiple of 64 for the sizes of interest); lanes before i0 idle */
+  const int i0a = (i0/LBMI_ALIGN)*LBMI_ALIGN;
+  static_for<0, SPT>([&](auto K) {
+    constexpr int k = K;
+    i[k] = i0a + (int) (lb*(BLOCK*SPT) + k*BLOCK + threadIdx.x);
+    if (i[k] >= i0 && i[k] < i1) pc_pull<NVEL, WRAP>(kp, f, wrapmask, i[k], ps[k]);
+  });
+  static_for<0, SPT>([&](auto K) {
+    constexpr int k = K;
+    if (i[k] >= i0 && i[k] < i1) pc_collide_store<NVEL, SCHEME>(kp, fp, h, i[k], ps[k]);
+  });
 }
 
 /* ---- halo kernels ----------------------------------------------------------
@@ -783,7 +915,10 @@ void k_moments_final(int npartial, const double * __restrict__ work,
 
 /* ---- launch helpers --------------------------------------------------------- */
 
-inline unsigned grid_for(unsigned nblk) { return ((nblk + 7u)/8u)*8u; }
+inline unsigned grid_for(unsigned nblk, unsigned group = 0) {
+  unsigned q = 8u*(group > 0 ? group : 1u);
+  return ((nblk + q - 1u)/q)*q;
+}
 
 template <int NVEL>
 int launch_collide(const lbmi_kparam_t & kp, double * f,
@@ -818,21 +953,38 @@ template <int NVEL, bool WRAP>
 int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
 	      const lbmi_hydro_dev_t & h, int wrapmask, int i0, int i1,
 	      hipStream_t st) {
-  unsigned nblk = (unsigned) ((i1 - i0 + BLOCK - 1)/BLOCK);
-  dim3 grid(grid_for(nblk)), block(BLOCK);
+  const int i0a = (i0/LBMI_ALIGN)*LBMI_ALIGN;
+  unsigned nblk = (unsigned) ((i1 - i0a + BLOCK*SPT - 1)/(BLOCK*SPT));
+  dim3 grid(grid_for(nblk, (unsigned) kp.xcd_group)), block(BLOCK);
+  /* dynamic LDS is not used by the kernel: it only caps the number of
+   * resident blocks per CU (160 KiB / lds_cap), see DESIGN.md */
+  const unsigned lds = (unsigned) kp.lds_cap;
+  if (lds > 65536u) {
+    /* above 64 KiB the limit must be raised per kernel */
+    const void * fn = nullptr;
+    if (kp.scheme == LBMI_M10) fn = (const void *) k_propagate_collide<NVEL, LBMI_M10, WRAP>;
+    if (kp.scheme == LBMI_BGK) fn = (const void *) k_propagate_collide<NVEL, LBMI_BGK, WRAP>;
+    if constexpr (NVEL == 19) {
+      if (kp.scheme == LBMI_TRT) fn = (const void *) k_propagate_collide<NVEL, LBMI_TRT, WRAP>;
+    }
+    if (fn) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+      if (e != hipSuccess) return (int) e;
+    }
+  }
   switch (kp.scheme) {
   case LBMI_M10:
     hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_M10, WRAP>), grid,
-		       block, 0, st, kp, f, fp, h, wrapmask, i0, i1, nblk);
+		       block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk);
     break;
   case LBMI_BGK:
     hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_BGK, WRAP>), grid,
-		       block, 0, st, kp, f, fp, h, wrapmask, i0, i1, nblk);
+		       block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk);
     break;
   case LBMI_TRT:
     if constexpr (NVEL == 19) {
       hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_TRT, WRAP>), grid,
-			 block, 0, st, kp, f, fp, h, wrapmask, i0, i1, nblk);
+			 block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk);
       break;
     }
     return (int) hipErrorInvalidValue;

@@ -222,6 +222,9 @@ class LB:
     def synchronize(self):
         _l.check(self._lib.lbmi_synchronize(self._h))
 
+    def tune(self, key, value):
+        _l.check(self._lib.lbmi_tune(self._h, key.encode(), int(value)))
+
     def timing(self, on=True):
         _l.check(self._lib.lbmi_timing(self._h, 1 if on else 0))
 

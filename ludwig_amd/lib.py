@@ -5,7 +5,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblbmi.so")
+# LBMI_LIB selects an alternative build (ablation variants, tools/)
+LIB_PATH = os.environ.get("LBMI_LIB", os.path.join(_HERE, "liblbmi.so"))
 UNIQUE_ID_BYTES = 128
 
 
@@ -72,6 +73,7 @@ SYMBOLS = [
     ("lbmi_stream", _i, [_vp, ctypes.POINTER(_vp)]),
     ("lbmi_timing", _i, [_vp, _i]),
     ("lbmi_timing_read", _i, [_vp, _pd, ctypes.POINTER(_i)]),
+    ("lbmi_tune", _i, [_vp, ctypes.c_char_p, _i]),
     ("lbmi_comm_unique_id", _i, [_vp]),
     ("lbmi_comm_init", _i, [_vp, _vp]),
     ("lbmi_comm_free", _i, [_vp]),
