@@ -157,6 +157,22 @@ int lbmi_collide(lbmi_t * lb, double * f, const lbmi_hydro_t * hydro);
  * rank: periodic wrap in all directions; cartsz > 1: X through RCCL). */
 int lbmi_halo(lbmi_t * lb, double * f, int scheme);
 
+/* The X pass of the halo swap split into its device-side halves, for
+ * callers that bring their own transport (e.g. GPU-aware MPI in place of
+ * halo_swap.c:762-881): pack the two boundary planes into contiguous device
+ * buffers, exchange them, unpack into the halo planes, then run the local
+ * Y and Z passes. Buffer layout [component][plane site]; message lengths in
+ * doubles from lbmi_halo_x_count().
+ *   sendlo: first interior plane  -> lower neighbour's recvhi
+ *   sendhi: last interior plane   -> upper neighbour's recvlo          */
+int lbmi_halo_x_count(lbmi_t * lb, int scheme, size_t * nsendlo,
+		      size_t * nsendhi);
+int lbmi_halo_x_pack(lbmi_t * lb, const double * f, int scheme,
+		     double * sendlo, double * sendhi);
+int lbmi_halo_x_unpack(lbmi_t * lb, double * f, int scheme,
+		       const double * recvlo, const double * recvhi);
+int lbmi_halo_yz(lbmi_t * lb, double * f, int scheme);
+
 /* lb_propagation_kernel (propagation.c:162-212): fprime <- pull(f). The
  * caller swaps the pointers (lb_model_swapf, propagation.c:223-252). */
 int lbmi_propagate(lbmi_t * lb, const double * f, double * fprime);

@@ -642,6 +642,57 @@ int lbmi_halo(lbmi_t * lb, double * f, int scheme) {
   return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
 }
 
+static const lbmi_halo_sel_t * lbmi_sel(const lbmi_t * lb, int scheme) {
+  if (scheme == LBMI_HALO_FULL) return lb->sel_full;
+  if (scheme == LBMI_HALO_REDUCED) return lb->sel_reduced;
+  return NULL;
+}
+
+int lbmi_halo_x_count(lbmi_t * lb, int scheme, size_t * nsendlo,
+		      size_t * nsendhi) {
+  const lbmi_halo_sel_t * sel;
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  sel = lbmi_sel(lb, scheme);
+  if (sel == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
+  /* sendlo feeds the neighbour's HIGH halo (components hi), sendhi its LOW */
+  if (nsendlo) *nsendlo = (size_t) lb->kp.strx*(size_t) sel[X].nhi;
+  if (nsendhi) *nsendhi = (size_t) lb->kp.strx*(size_t) sel[X].nlo;
+  return 0;
+}
+
+int lbmi_halo_x_pack(lbmi_t * lb, const double * f, int scheme,
+		     double * sendlo, double * sendhi) {
+  const lbmi_halo_sel_t * sel;
+  if (lb == NULL || !f || !sendlo || !sendhi) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  sel = lbmi_sel(lb, scheme);
+  if (sel == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_halo_pack_x(&lb->kp, &sel[X], f, sendlo, sendhi, lb->stream));
+  return 0;
+}
+
+int lbmi_halo_x_unpack(lbmi_t * lb, double * f, int scheme,
+		       const double * recvlo, const double * recvhi) {
+  const lbmi_halo_sel_t * sel;
+  if (lb == NULL || !f || !recvlo || !recvhi) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  sel = lbmi_sel(lb, scheme);
+  if (sel == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_halo_unpack_x(&lb->kp, &sel[X], f, recvlo, recvhi, lb->stream));
+  return 0;
+}
+
+int lbmi_halo_yz(lbmi_t * lb, double * f, int scheme) {
+  const lbmi_halo_sel_t * sel;
+  if (lb == NULL || !f) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  sel = lbmi_sel(lb, scheme);
+  if (sel == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_halo_copy(&lb->kp, Y, &sel[Y], f, lb->stream));
+  KCHECK(lbmi_k_halo_copy(&lb->kp, Z, &sel[Z], f, lb->stream));
+  return 0;
+}
+
 int lbmi_field_halo(lbmi_t * lb, int nel, double * data) {
   lbmi_halo_sel_t sel[3];
   if (lb == NULL || data == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");

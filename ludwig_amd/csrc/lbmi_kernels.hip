@@ -75,7 +75,9 @@ __device__ __forceinline__ double ldf(const double * p) {
 #endif
 }
 __device__ __forceinline__ void stf(double * p, double v) {
-#if LBMI_NT & 2
+#if LBMI_NT & 4
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif LBMI_NT & 2
   __builtin_nontemporal_store(v, p);
 #else
   *p = v;

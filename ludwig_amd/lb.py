@@ -199,6 +199,24 @@ class LB:
     def halo(self, f, scheme=HALO_FULL):
         _l.check(self._lib.lbmi_halo(self._h, _ptr(f), scheme))
 
+    def halo_x_count(self, scheme=HALO_FULL):
+        a = ctypes.c_size_t()
+        b = ctypes.c_size_t()
+        _l.check(self._lib.lbmi_halo_x_count(self._h, scheme, ctypes.byref(a),
+                                             ctypes.byref(b)))
+        return a.value, b.value
+
+    def halo_x_pack(self, f, sendlo, sendhi, scheme=HALO_FULL):
+        _l.check(self._lib.lbmi_halo_x_pack(self._h, _ptr(f), scheme,
+                                            _ptr(sendlo), _ptr(sendhi)))
+
+    def halo_x_unpack(self, f, recvlo, recvhi, scheme=HALO_FULL):
+        _l.check(self._lib.lbmi_halo_x_unpack(self._h, _ptr(f), scheme,
+                                              _ptr(recvlo), _ptr(recvhi)))
+
+    def halo_yz(self, f, scheme=HALO_FULL):
+        _l.check(self._lib.lbmi_halo_yz(self._h, _ptr(f), scheme))
+
     def propagate(self, f, fprime):
         _l.check(self._lib.lbmi_propagate(self._h, _ptr(f), _ptr(fprime)))
 

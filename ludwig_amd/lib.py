@@ -56,6 +56,11 @@ SYMBOLS = [
     ("lbmi_relaxation_rates", _i, [_vp, _pd]),
     ("lbmi_collide", _i, [_vp, _vp, ctypes.POINTER(HydroPtrs)]),
     ("lbmi_halo", _i, [_vp, _vp, _i]),
+    ("lbmi_halo_x_count", _i, [_vp, _i, ctypes.POINTER(ctypes.c_size_t),
+                               ctypes.POINTER(ctypes.c_size_t)]),
+    ("lbmi_halo_x_pack", _i, [_vp, _vp, _i, _vp, _vp]),
+    ("lbmi_halo_x_unpack", _i, [_vp, _vp, _i, _vp, _vp]),
+    ("lbmi_halo_yz", _i, [_vp, _vp, _i]),
     ("lbmi_propagate", _i, [_vp, _vp, _vp]),
     ("lbmi_propagate_collide", _i, [_vp, _vp, _vp, ctypes.POINTER(HydroPtrs), _i]),
     ("lbmi_field_halo", _i, [_vp, _i, _vp]),

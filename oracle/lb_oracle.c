@@ -369,6 +369,13 @@ int lbo_collide(const lbo_param_t * p, double * f, const double * force,
  */
 
 int lbo_halo(const lbo_param_t * p, int nel, double * data) {
+  return lbo_halo_dirs(p, nel, data, 7);
+}
+
+/* dirmask: bit d set = run the pass for direction d (X = 1, Y = 2, Z = 4);
+ * a slab-decomposed test does X through its own exchange and Y, Z here. */
+
+int lbo_halo_dirs(const lbo_param_t * p, int nel, double * data, int dirmask) {
 
   int nall[3];
   ptrdiff_t str[3];
@@ -379,6 +386,7 @@ int lbo_halo(const lbo_param_t * p, int nel, double * data) {
   nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
 
   for (int id = 0; id < 3; id++) {
+    if (!(dirmask & (1 << id))) continue;
     int d1 = (id + 1) % 3;
     int d2 = (id + 2) % 3;
     /* plane coordinates (0-based, in nall): source lo/hi, destination */
@@ -386,7 +394,7 @@ int lbo_halo(const lbo_param_t * p, int nel, double * data) {
     int src_hi = nh + p->nlocal[id] - 1;  /* last interior plane */
     int dst_lo = nh - 1;                  /* halo plane below */
     int dst_hi = nh + p->nlocal[id];      /* halo plane above */
-
+    {
     #pragma omp parallel for schedule(static)
     for (int n = 0; n < nel; n++) {
       double * d = data + nsite*n;
@@ -397,6 +405,7 @@ int lbo_halo(const lbo_param_t * p, int nel, double * data) {
 	  d[off + str[id]*dst_hi] = d[off + str[id]*src_lo];
 	}
       }
+    }
     }
   }
 

@@ -54,6 +54,7 @@ int lbo_nsite(const lbo_param_t * p);
 int lbo_collide(const lbo_param_t * p, double * f, const double * force,
 		const char * status, double * rho, double * u);
 int lbo_halo(const lbo_param_t * p, int nel, double * data);
+int lbo_halo_dirs(const lbo_param_t * p, int nel, double * data, int dirmask);
 int lbo_propagate(const lbo_param_t * p, const double * f, double * fprime);
 int lbo_moments(const lbo_param_t * p, const double * f, const char * status,
 		double out[9]);

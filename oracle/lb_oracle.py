@@ -66,6 +66,7 @@ def lib():
         _lib.lbo_nsite.argtypes = [pp]
         _lib.lbo_collide.argtypes = [pp, dp, dp, dp, dp, dp]
         _lib.lbo_halo.argtypes = [pp, ctypes.c_int, dp]
+        _lib.lbo_halo_dirs.argtypes = [pp, ctypes.c_int, dp, ctypes.c_int]
         _lib.lbo_propagate.argtypes = [pp, dp, dp]
         _lib.lbo_moments.argtypes = [pp, dp, dp, dp]
         _lib.lbo_init_synthetic.argtypes = [pp, dp, dp, dp]
@@ -131,6 +132,13 @@ def halo(p, data):
     nel = data.shape[0]
     assert data.dtype == np.float64 and data.shape == (nel,) + nall(p)
     rc = lib().lbo_halo(ctypes.byref(p), nel, _ptr(data))
+    assert rc == 0
+
+
+def halo_yz(p, data):
+    """Only the local Y and Z passes (X comes from a neighbour rank)."""
+    nel = data.shape[0]
+    rc = lib().lbo_halo_dirs(ctypes.byref(p), nel, _ptr(data), 6)
     assert rc == 0
 
 

@@ -351,3 +351,95 @@ def test_rccl_self_ring(mode):
         lb.free()
     assert np.array_equal(res[0], res[1])
     assert relmax(res[1], interior(g["f_final"], h)) < RTOL_F
+
+
+# --- slab decomposition, in one process: N handles, buffers swapped by hand ---
+
+def _slab_setup(nvel, ntotal, nslab, scheme_name, fbody):
+    import torch
+    import ludwig_amd
+    lbs, fa, fb = [], [], []
+    for r in range(nslab):
+        dec = ludwig_amd.SlabDecomposition(ntotal, nslab, r)
+        lb = ludwig_amd.LB(nvel, dec.nlocal, 1, cartsz=nslab, cartrank=r)
+        lb.relaxation_set(scheme_name, 0.1, 0.3)
+        lb.body_force_set(fbody)
+        p = lbo.make_param(nvel, dec.nlocal, 1, scheme_name, 0.1, 0.3, 1.0, fbody)
+        f0 = lbo.init_synthetic(p, ntotal, dec.noffset)
+        lbs.append(lb)
+        fa.append(dev(lb, f0))
+        fb.append(torch.zeros_like(fa[-1]))
+    torch.cuda.synchronize()
+    return lbs, fa, fb
+
+
+def _slab_exchange(lbs, fa, halo_scheme):
+    """pack on every slab, hand the buffers round the periodic ring, unpack:
+    what lbmi_x_exchange does with ncclSend/ncclRecv."""
+    import torch
+    n = len(lbs)
+    bufs = []
+    for r, lb in enumerate(lbs):
+        nlo, nhi = lb.halo_x_count(halo_scheme)
+        sendlo = torch.empty(nlo, dtype=torch.float64, device=lb.device)
+        sendhi = torch.empty(nhi, dtype=torch.float64, device=lb.device)
+        torch.cuda.synchronize()
+        lb.halo_x_pack(fa[r], sendlo, sendhi, halo_scheme)
+        lb.synchronize()
+        bufs.append((sendlo, sendhi))
+    for r, lb in enumerate(lbs):
+        recvlo = bufs[(r - 1) % n][1]      # prev's last interior plane
+        recvhi = bufs[(r + 1) % n][0]      # next's first interior plane
+        lb.halo_x_unpack(fa[r], recvlo, recvhi, halo_scheme)
+        lb.synchronize()
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["eager", "fused"])
+@pytest.mark.parametrize("halo_scheme", [0, 2], ids=["full", "reduced"])
+@pytest.mark.parametrize("nvel,nslab", [(19, 2), (19, 3), (27, 2)])
+def test_slabs_equal_single_domain(nvel, nslab, halo_scheme, fused):
+    ntotal = (4 * nslab, 5, 6)
+    fbody = (1e-6, 0.0, -1e-6)
+    nsteps = 4
+    lbs, fa, fb = _slab_setup(nvel, ntotal, nslab, "m10", fbody)
+
+    if not fused:
+        for _ in range(nsteps):
+            for r, lb in enumerate(lbs):
+                lb.collide(fa[r])
+                lb.synchronize()
+            _slab_exchange(lbs, fa, halo_scheme)
+            for r, lb in enumerate(lbs):
+                lb.halo_yz(fa[r], halo_scheme)
+                lb.propagate(fa[r], fb[r])
+                lb.synchronize()
+            fa, fb = fb, fa
+    else:
+        # collide(0); then [exchange X; fused pull+collide with y/z wrap] x
+        # (nsteps-1); then exchange, y/z halo, propagate
+        for r, lb in enumerate(lbs):
+            lb.collide(fa[r])
+            lb.synchronize()
+        for _ in range(nsteps - 1):
+            _slab_exchange(lbs, fa, halo_scheme)
+            for r, lb in enumerate(lbs):
+                lb.propagate_collide(fa[r], fb[r], None, wrap=True)
+                lb.synchronize()
+            fa, fb = fb, fa
+        _slab_exchange(lbs, fa, halo_scheme)
+        for r, lb in enumerate(lbs):
+            lb.halo_yz(fa[r], halo_scheme)
+            lb.propagate(fa[r], fb[r])
+            lb.synchronize()
+        fa, fb = fb, fa
+
+    got = np.concatenate([interior(host(lbs[r], fa[r]), 1)
+                          for r in range(nslab)], axis=1)
+    p = lbo.make_param(nvel, ntotal, 1, "m10", 0.1, 0.3, 1.0, fbody)
+    f = lbo.init_synthetic(p)
+    fp = np.zeros_like(f)
+    for _ in range(nsteps):
+        f, fp = lbo.step(p, f, fp)
+    assert relmax(got, interior(f, 1)) < RTOL_F
+    for lb in lbs:
+        lb.free()
