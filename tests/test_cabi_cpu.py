@@ -106,3 +106,11 @@ def test_slab_decomposition():
     assert len(lo) == len(hi) == 9
     with pytest.raises(ValueError):
         ludwig_amd.SlabDecomposition((100, 8, 8), 8, 0)
+
+
+def test_shim_compiles_against_reference():
+    """integration/ludwig_shim.c is valid C against the reference headers
+    (lb_t, hydro_t, map_t, ... as they are in zazu29/ludwig v0.20.1)."""
+    import __graft_entry__ as g
+    if not g.check_shim():
+        pytest.skip("/root/reference not present on this machine")
