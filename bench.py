@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--hydro", type=int, default=1,
                     help="1: lb_collide reads hydro->force and writes "
                     "hydro->rho,u as the reference does; 0: NULL hydro arrays")
+    ap.add_argument("--selfring", type=int, default=0,
+                    help="1 GPU only: route the X halo through a 1-rank RCCL "
+                    "ring (exercises the N>1 step path: pack, send/recv, "
+                    "unpack, interior/boundary split)")
     ap.add_argument("--tune", default="", help="key=value,... (lbmi_tune)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -136,10 +140,22 @@ def main():
         k, v = kv.split("=")
         lb.tune(k, int(v))
 
-    if world > 1:
-        ids = [ludwig_amd.LB.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        lb.comm_init(ids[0])
+    # RCCL prints a version banner on stdout when a communicator is created;
+    # the contract is ONE JSON line on stdout, so park fd 1 on stderr meanwhile
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if world > 1:
+            ids = [ludwig_amd.LB.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            lb.comm_init(ids[0])
+        elif args.selfring:
+            lb.comm_init(ludwig_amd.LB.comm_unique_id())
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     m = ludwig_amd.lb.model(args.nvel)
     synthetic.fill_device(lb, m["cv"], m["wv"], ntotal,
@@ -234,7 +250,8 @@ def main():
                             % (args.nvel, args.scheme.upper(), *ntotal),
                 "mode": args.mode,
                 "hydro_io": bool(args.hydro),
-                "decomposition": "x-slab %d_1_1" % world,
+                "decomposition": "x-slab %d_1_1" % world
+                                 + (" (1-rank RCCL ring)" if args.selfring else ""),
                 "halo": "index wrap (1 GPU); reduced X planes over RCCL (N>1)",
             },
             "roofline": roofline,

@@ -229,7 +229,9 @@ int lbmi_timing_read(lbmi_t * lb, double * ms_total, int * nlaunch);
 
 /* Launch tuning of the fused kernel; results do not depend on it.
  * "xcd_group": blocks per XCD interleave group (0 = one chunk per XCD);
- * "lds_cap": dynamic LDS bytes per block, caps resident blocks per CU. */
+ * "lds_cap": dynamic LDS bytes per block, caps resident blocks per CU;
+ * "x_packed": 1 = RCCL X exchange through packed staging buffers (one
+ * message per direction) instead of the default zero-copy plane sends. */
 int lbmi_tune(lbmi_t * lb, const char * key, int value);
 
 /* ---- multi-GPU: 1-d slab decomposition along X over RCCL ---------------- */

@@ -58,6 +58,7 @@ struct lbmi_s {
   int have_comm;
   double * sendlo, * sendhi, * recvlo, * recvhi;   /* device buffers */
   size_t xbuf_doubles;
+  int x_packed;                      /* 1: pack/unpack through buffers */
 
   /* kernel timing */
   int timing;
@@ -285,6 +286,7 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
    * neighbouring wave has used its share of them. */
   lb->kp.xcd_group = 16;
   lb->kp.lds_cap = 65536;
+  lb->x_packed = 1;
 
   /* Defaults of the reference: rho0 = 1, eta = zeta = 1/6 (physics.c:33-56) */
   lbmi_set_relaxation(lb, LBMI_RELAXATION_M10, 1.0, 1.0/6.0, 1.0/6.0);
@@ -516,6 +518,10 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
     lb->kp.xcd_group = value;
     return 0;
   }
+  if (strcmp(key, "x_packed") == 0) {
+    lb->x_packed = (value != 0);
+    return 0;
+  }
   if (strcmp(key, "lds_cap") == 0) {
     if (value < 0 || value > 163840) {
       return lbmi_fail(LBMI_ERR_ARGUMENT, "lds_cap = %d (0..163840)", value);
@@ -564,7 +570,7 @@ int lbmi_propagate_collide(lbmi_t * lb, const double * f, double * fprime,
   KCHECK(lbmi_k_propagate_collide(&lb->kp, f, fprime, &h,
 				  wrap ? lbmi_wrapmask(lb) : 0,
 				  lb->kp.nhalo,
-				  lb->kp.nhalo + lb->kp.nlocal[X] - 1,
+				  lb->kp.nhalo + lb->kp.nlocal[X] - 1, 0, -1,
 				  lb->stream));
   return lbmi_time_end(lb);
 }
@@ -586,8 +592,8 @@ static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
 			   double * data, hipStream_t st) {
 
   size_t psz = (size_t) lb->kp.strx;
-  size_t nlo = psz*(size_t) sel->nlo;     /* arrives in / leaves for low halos */
-  size_t nhi = psz*(size_t) sel->nhi;
+  size_t ns = (size_t) lb->kp.nsite;
+  int nh = lb->kp.nhalo;
   int prev = (lb->opts.cartrank + lb->opts.cartsz - 1) % lb->opts.cartsz;
   int next = (lb->opts.cartrank + 1) % lb->opts.cartsz;
 
@@ -595,22 +601,56 @@ static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
     return lbmi_fail(LBMI_ERR_STATE, "cartsz = %d but lbmi_comm_init() has "
 		     "not been called", lb->opts.cartsz);
   }
-  if (nlo > lb->xbuf_doubles || nhi > lb->xbuf_doubles) {
-    return lbmi_fail(LBMI_ERR_STATE, "halo buffers too small");
+
+  if (!lb->x_packed) {
+    /* Zero-copy: X is the slowest index, so the boundary plane of ONE
+     * component is a contiguous run of strx doubles. Every component goes
+     * straight from the interior plane of this rank into the halo plane of
+     * the neighbour: no pack/unpack kernels, no staging buffers. The order
+     * of the operations towards one peer is the same on both sides (lo
+     * components first, then hi), which is what matches sends to receives,
+     * also when prev == next (2 ranks) or prev == next == self (1 rank). */
+    size_t last = (size_t) (nh + lb->kp.nlocal[X] - 1)*psz;
+    size_t first = (size_t) nh*psz;
+    size_t halo_lo = (size_t) (nh - 1)*psz;
+    size_t halo_hi = (size_t) (nh + lb->kp.nlocal[X])*psz;
+    NCCLCHECK(ncclGroupStart());
+    for (int k = 0; k < sel->nlo; k++) {
+      double * d = data + ns*(size_t) sel->lo[k];
+      NCCLCHECK(ncclSend(d + last, psz, ncclDouble, next, lb->comm, st));
+      NCCLCHECK(ncclRecv(d + halo_lo, psz, ncclDouble, prev, lb->comm, st));
+    }
+    for (int k = 0; k < sel->nhi; k++) {
+      double * d = data + ns*(size_t) sel->hi[k];
+      NCCLCHECK(ncclSend(d + first, psz, ncclDouble, prev, lb->comm, st));
+      NCCLCHECK(ncclRecv(d + halo_hi, psz, ncclDouble, next, lb->comm, st));
+    }
+    NCCLCHECK(ncclGroupEnd());
+    return 0;
   }
 
-  /* sendlo: our first interior plane, components sel->hi -> prev's high halo
-   * sendhi: our last interior plane, components sel->lo  -> next's low halo */
-  KCHECK(lbmi_k_halo_pack_x(&lb->kp, sel, data, lb->sendlo, lb->sendhi, st));
+  /* Packed variant: one message per direction through staging buffers */
+  {
+    size_t nlo = psz*(size_t) sel->nlo;   /* arrives in / leaves for low halos */
+    size_t nhi = psz*(size_t) sel->nhi;
 
-  NCCLCHECK(ncclGroupStart());
-  NCCLCHECK(ncclSend(lb->sendhi, nlo, ncclDouble, next, lb->comm, st));
-  NCCLCHECK(ncclRecv(lb->recvlo, nlo, ncclDouble, prev, lb->comm, st));
-  NCCLCHECK(ncclSend(lb->sendlo, nhi, ncclDouble, prev, lb->comm, st));
-  NCCLCHECK(ncclRecv(lb->recvhi, nhi, ncclDouble, next, lb->comm, st));
-  NCCLCHECK(ncclGroupEnd());
+    if (nlo > lb->xbuf_doubles || nhi > lb->xbuf_doubles) {
+      return lbmi_fail(LBMI_ERR_STATE, "halo buffers too small");
+    }
 
-  KCHECK(lbmi_k_halo_unpack_x(&lb->kp, sel, data, lb->recvlo, lb->recvhi, st));
+    /* sendlo: first interior plane, components sel->hi -> prev's high halo
+     * sendhi: last interior plane, components sel->lo  -> next's low halo */
+    KCHECK(lbmi_k_halo_pack_x(&lb->kp, sel, data, lb->sendlo, lb->sendhi, st));
+
+    NCCLCHECK(ncclGroupStart());
+    NCCLCHECK(ncclSend(lb->sendhi, nlo, ncclDouble, next, lb->comm, st));
+    NCCLCHECK(ncclRecv(lb->recvlo, nlo, ncclDouble, prev, lb->comm, st));
+    NCCLCHECK(ncclSend(lb->sendlo, nhi, ncclDouble, prev, lb->comm, st));
+    NCCLCHECK(ncclRecv(lb->recvhi, nhi, ncclDouble, next, lb->comm, st));
+    NCCLCHECK(ncclGroupEnd());
+
+    KCHECK(lbmi_k_halo_unpack_x(&lb->kp, sel, data, lb->recvlo, lb->recvhi, st));
+  }
 
   return 0;
 }
@@ -800,27 +840,28 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
 
   if (lb->opts.cartsz == 1 && !lb->have_comm) {
     KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				    xlo, xhi, lb->stream));
+				    xlo, xhi, 0, -1, lb->stream));
   }
   else {
-    /* comm stream: wait until the previous step has written f, then
-     * exchange the (reduced) boundary planes into the x halo planes */
+    /* The interior planes need no x halo: enqueue them first so that the
+     * compute stream never idles while the host is busy enqueueing the
+     * exchange (an RCCL group costs ~15 us of host time). ev_ready marks
+     * "previous step complete", i.e. the boundary planes of f are final. */
     HIPCHECK(hipEventRecord(lb->ev_ready, lb->stream));
+    KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
+				    xlo + 1, xhi - 1, 0, -1, lb->stream));
+
+    /* comm stream: exchange the boundary planes into the x halo planes */
     HIPCHECK(hipStreamWaitEvent(lb->comm_stream, lb->ev_ready, 0));
     ifail = lbmi_x_exchange(lb, &lb->sel_reduced[X], lb->f, lb->comm_stream);
     if (ifail) return ifail;
     HIPCHECK(hipEventRecord(lb->ev_halo, lb->comm_stream));
 
-    /* compute stream: interior planes need no x halo */
-    KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				    xlo + 1, xhi - 1, lb->stream));
+    /* both boundary planes in one launch, after the halo has arrived */
     HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_halo, 0));
     KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				    xlo, xlo, lb->stream));
-    if (xhi > xlo) {
-      KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				      xhi, xhi, lb->stream));
-    }
+				    xlo, xlo, xhi, (xhi > xlo) ? xhi : xhi - 1,
+				    lb->stream));
   }
 
   ifail = lbmi_time_end(lb);

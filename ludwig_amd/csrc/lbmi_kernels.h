@@ -64,11 +64,13 @@ int lbmi_k_collide(const lbmi_kparam_t * kp, double * f,
 int lbmi_k_propagate(const lbmi_kparam_t * kp, const double * f,
 		     double * fprime, void * stream);
 
-/* xlo..xhi: 0-based x planes (in nall) to process, inclusive.
+/* xlo..xhi and xlo2..xhi2: 0-based x planes (in nall) to process,
+ * inclusive, in ONE launch; an empty range has xhi < xlo.
  * wrapmask: bit d set = wrap direction d by index arithmetic. */
 int lbmi_k_propagate_collide(const lbmi_kparam_t * kp, const double * f,
 			     double * fprime, const lbmi_hydro_dev_t * h,
-			     int wrapmask, int xlo, int xhi, void * stream);
+			     int wrapmask, int xlo, int xhi, int xlo2, int xhi2,
+			     void * stream);
 
 /* In-place periodic halo copy for direction dir on an SoA field with
  * components of stride nsite. */

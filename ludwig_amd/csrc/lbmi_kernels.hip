@@ -625,10 +625,19 @@ template <int NVEL, int SCHEME, bool WRAP>
 __global__ __launch_bounds__(BLOCK, LBMI_WAVES)
 void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
 			 double * __restrict__ fp, lbmi_hydro_dev_t h,
-			 int wrapmask, int i0, int i1, unsigned nblk) {
+			 int wrapmask, int i0, int i1, unsigned nblk,
+			 int j0, int j1, unsigned nblk_first) {
 
   unsigned lb;
   if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+
+  /* two site ranges in one launch (the two boundary x-planes of a slab):
+   * logical blocks [0, nblk_first) cover [i0, i1), the rest [j0, j1) */
+  if (lb >= nblk_first) {
+    lb -= nblk_first;
+    i0 = j0;
+    i1 = j1;
+  }
 
   /* SPT sites per thread, BLOCK apart: the pulls of all of them are in
    * flight before the first collision starts */
@@ -954,13 +963,19 @@ int launch_collide(const lbmi_kparam_t & kp, double * f,
 template <int NVEL, bool WRAP>
 int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
 	      const lbmi_hydro_dev_t & h, int wrapmask, int i0, int i1,
-	      hipStream_t st) {
+	      int j0, int j1, hipStream_t st) {
   const int i0a = (i0/LBMI_ALIGN)*LBMI_ALIGN;
-  unsigned nblk = (unsigned) ((i1 - i0a + BLOCK*SPT - 1)/(BLOCK*SPT));
+  const int j0a = (j0/LBMI_ALIGN)*LBMI_ALIGN;
+  unsigned nblk_first = (unsigned) ((i1 - i0a + BLOCK*SPT - 1)/(BLOCK*SPT));
+  unsigned nblk = nblk_first;
+  if (j1 > j0) nblk += (unsigned) ((j1 - j0a + BLOCK*SPT - 1)/(BLOCK*SPT));
   dim3 grid(grid_for(nblk, (unsigned) kp.xcd_group)), block(BLOCK);
   /* dynamic LDS is not used by the kernel: it only caps the number of
    * resident blocks per CU (160 KiB / lds_cap), see DESIGN.md */
-  const unsigned lds = (unsigned) kp.lds_cap;
+  unsigned lds = (unsigned) kp.lds_cap;
+  /* a launch that fits on the chip in one round anyway (the boundary planes
+   * of a slab) is latency-bound: give it the full occupancy */
+  if (nblk <= 1024u) lds = 0u;
   if (lds > 65536u) {
     /* above 64 KiB the limit must be raised per kernel */
     const void * fn = nullptr;
@@ -977,16 +992,19 @@ int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
   switch (kp.scheme) {
   case LBMI_M10:
     hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_M10, WRAP>), grid,
-		       block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk);
+		       block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk,
+		       j0, j1, nblk_first);
     break;
   case LBMI_BGK:
     hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_BGK, WRAP>), grid,
-		       block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk);
+		       block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk,
+		       j0, j1, nblk_first);
     break;
   case LBMI_TRT:
     if constexpr (NVEL == 19) {
       hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_TRT, WRAP>), grid,
-			 block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk);
+			 block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk,
+		       j0, j1, nblk_first);
       break;
     }
     return (int) hipErrorInvalidValue;
@@ -1047,18 +1065,26 @@ extern "C" int lbmi_k_propagate_collide(const lbmi_kparam_t * kp,
 					const double * f, double * fprime,
 					const lbmi_hydro_dev_t * h,
 					int wrapmask, int xlo, int xhi,
-					void * stream) {
+					int xlo2, int xhi2, void * stream) {
   hipStream_t st = (hipStream_t) stream;
-  if (xhi < xlo) return 0;
+  if (xhi < xlo) {
+    if (xhi2 < xlo2) return 0;
+    xlo = xlo2; xhi = xhi2; xlo2 = 0; xhi2 = -1;
+  }
   int i0 = xlo*kp->strx;
   int i1 = (xhi + 1)*kp->strx;
+  int j0 = 0, j1 = 0;
+  if (xhi2 >= xlo2) {
+    j0 = xlo2*kp->strx;
+    j1 = (xhi2 + 1)*kp->strx;
+  }
   if (kp->nvel == 19) {
-    return wrapmask ? launch_pc<19, true>(*kp, f, fprime, *h, wrapmask, i0, i1, st)
-      : launch_pc<19, false>(*kp, f, fprime, *h, 0, i0, i1, st);
+    return wrapmask ? launch_pc<19, true>(*kp, f, fprime, *h, wrapmask, i0, i1, j0, j1, st)
+      : launch_pc<19, false>(*kp, f, fprime, *h, 0, i0, i1, j0, j1, st);
   }
   if (kp->nvel == 27) {
-    return wrapmask ? launch_pc<27, true>(*kp, f, fprime, *h, wrapmask, i0, i1, st)
-      : launch_pc<27, false>(*kp, f, fprime, *h, 0, i0, i1, st);
+    return wrapmask ? launch_pc<27, true>(*kp, f, fprime, *h, wrapmask, i0, i1, j0, j1, st)
+      : launch_pc<27, false>(*kp, f, fprime, *h, 0, i0, i1, j0, j1, st);
   }
   return (int) hipErrorInvalidValue;
 }

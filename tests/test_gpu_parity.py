@@ -329,8 +329,9 @@ def test_regression_log_1dp(mode):
 
 # --- RCCL ring on one GPU: rank 0 is its own neighbour ----------------------
 
+@pytest.mark.parametrize("packed", [0, 1], ids=["zerocopy", "packed"])
 @pytest.mark.parametrize("mode", [0, 1], ids=["eager", "fused"])
-def test_rccl_self_ring(mode):
+def test_rccl_self_ring(mode, packed):
     """With a 1-rank communicator the X halo goes through pack ->
     ncclSend/ncclRecv (to self) -> unpack instead of the device-side copy;
     the result must be identical."""
@@ -343,6 +344,7 @@ def test_rccl_self_ring(mode):
         lb = make_lb(meta, mode=mode, halo_scheme=2 if mode else 0)
         if use_comm:
             lb.comm_init(ludwig_amd.LB.comm_unique_id())
+            lb.tune("x_packed", packed)
         hy = make_hydro(lb, g, meta)
         lb.lb_memcpy_h2d(g["f0"])
         for _ in range(meta["nsteps"]):
