@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--size", type=int, nargs=3, default=[256, 256, 256])
     ap.add_argument("--nvel", type=int, default=19)
     ap.add_argument("--scheme", default="m10", choices=["m10", "bgk", "trt"])
-    ap.add_argument("--mode", default="fused", choices=["fused", "eager"])
+    ap.add_argument("--mode", default="fused",
+                    choices=["fused", "eager", "inplace"])
     ap.add_argument("--hydro", type=int, default=1,
                     help="1: lb_collide reads hydro->force and writes "
                     "hydro->rho,u as the reference does; 0: NULL hydro arrays")
@@ -130,7 +131,8 @@ def main():
 
     ntotal = tuple(args.size)
     dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, nhalo=1)
-    mode = ludwig_amd.FUSED if args.mode == "fused" else ludwig_amd.EAGER
+    mode = {"fused": ludwig_amd.FUSED, "eager": ludwig_amd.EAGER,
+            "inplace": ludwig_amd.INPLACE}[args.mode]
     lb = ludwig_amd.LB(args.nvel, dec.nlocal, 1, mode=mode,
                        halo_scheme=ludwig_amd.HALO_REDUCED, device=local_rank,
                        cartsz=world, cartrank=rank)
@@ -213,7 +215,7 @@ def main():
         algo_bytes = pop_bytes + (56 if args.hydro else 0)
         local_sites = dec.nlocal[0] * dec.nlocal[1] * dec.nlocal[2]
         roofline = None
-        if nlaunch > 0 and args.mode == "fused":
+        if nlaunch > 0 and args.mode in ("fused", "inplace"):
             t_launch = 1e-3 * kms / nlaunch
             achieved = 1e-9 * algo_bytes * local_sites / t_launch
             roofline = {

@@ -92,10 +92,19 @@ typedef enum lbmi_halo_e {
  *        lbmi_lb_memcpy_d2h, lbmi_lb_moments and lbmi_lb_f) materialises
  *        the pending halo + propagation so that any reader sees the same
  *        f as in EAGER mode. Requires an all-fluid or bounce-back-free step
- *        (nothing may modify f between lb_collide and lb_propagation). */
+ *        (nothing may modify f between lb_collide and lb_propagation).
+ * INPLACE: as FUSED, but f is streamed IN PLACE (AA pattern): lb_collide
+ *        alternates between a local collision that stores into swapped
+ *        slots and a pull + collide + push kernel, both reading and writing
+ *        the same addresses of the ONE array f (fprime is only touched by
+ *        lbmi_lb_flush). The second kernel performs the propagation of its
+ *        own step early, so the lb_halo / lb_propagation calls that follow
+ *        it only acknowledge. Same legality conditions as FUSED, and
+ *        cartsz == 1 (with slabs it falls back to FUSED). */
 typedef enum lbmi_mode_e {
   LBMI_MODE_EAGER = 0,
-  LBMI_MODE_FUSED = 1
+  LBMI_MODE_FUSED = 1,
+  LBMI_MODE_INPLACE = 2
 } lbmi_mode_t;
 
 typedef struct lbmi_options_s {

@@ -48,6 +48,9 @@ struct lbmi_s {
   int owns_f;
   int pending_halo;                  /* FUSED: lb_halo recorded */
   int pending_prop;                  /* FUSED: lb_propagation recorded */
+  int layout_swapped;                /* INPLACE: population p lives in slot opp(p) */
+  int early_prop;                    /* INPLACE: k_aa_odd already propagated this step */
+  int halo_seen;                     /* INPLACE: lb_halo called while early_prop */
 
   /* moments workspace */
   double * mom_work;
@@ -197,7 +200,8 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "cartsz/cartrank = %d/%d",
 		     opts->cartsz, opts->cartrank);
   }
-  if (opts->mode != LBMI_MODE_EAGER && opts->mode != LBMI_MODE_FUSED) {
+  if (opts->mode != LBMI_MODE_EAGER && opts->mode != LBMI_MODE_FUSED &&
+      opts->mode != LBMI_MODE_INPLACE) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "mode = %d", opts->mode);
   }
   if (opts->halo_scheme != LBMI_HALO_FULL &&
@@ -790,6 +794,9 @@ int lbmi_lb_bind(lbmi_t * lb, double * f, double * fprime) {
   lb->fprime = NULL;
   lb->pending_halo = 0;
   lb->pending_prop = 0;
+  lb->layout_swapped = 0;
+  lb->early_prop = 0;
+  lb->halo_seen = 0;
 
   if (f == NULL) {
     size_t sz = sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel;
@@ -822,6 +829,19 @@ static void lbmi_swapf(lbmi_t * lb) {        /* lb_model_swapf */
   double * tmp = lb->f;
   lb->f = lb->fprime;
   lb->fprime = tmp;
+}
+
+/* INPLACE is honoured on a single rank without a communicator; with slabs
+ * the same calls run the FUSED two-array path */
+
+static int lbmi_inplace(const lbmi_t * lb) {
+  return (lb->opts.mode == LBMI_MODE_INPLACE && lb->opts.cartsz == 1 &&
+	  !lb->have_comm);
+}
+
+static int lbmi_deferred(const lbmi_t * lb) {
+  return (lb->opts.mode == LBMI_MODE_FUSED ||
+	  lb->opts.mode == LBMI_MODE_INPLACE);
 }
 
 /* FUSED step: exchange of the X planes on the comm stream overlapped with
@@ -886,6 +906,48 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   HIPCHECK(hipSetDevice(lb->device));
 
+  if (lbmi_inplace(lb)) {
+    int ifail;
+    if (lb->early_prop) {
+      return lbmi_fail(LBMI_ERR_STATE, "lb_collide: lb_propagation of the "
+		       "previous step has not been called");
+    }
+    if (lb->pending_prop) {
+      /* P(t) C(t+1) P(t+1) in place */
+      if (!lb->pending_halo) {
+	return lbmi_fail(LBMI_ERR_STATE, "propagation pending without halo");
+      }
+      ifail = lbmi_time_begin(lb);
+      if (ifail) return ifail;
+      KCHECK(lbmi_k_aa_odd(&lb->kp, lb->f, &h, 7, lb->layout_swapped,
+			   lb->stream));
+      ifail = lbmi_time_end(lb);
+      if (ifail) return ifail;
+      lb->pending_prop = 0;
+      lb->pending_halo = 0;
+      lb->layout_swapped = 0;
+      lb->early_prop = 1;
+      lb->halo_seen = 0;
+      return 0;
+    }
+    if (lb->pending_halo) {
+      return lbmi_fail(LBMI_ERR_STATE, "lb_collide after lb_halo without "
+		       "lb_propagation");
+    }
+    if (lb->layout_swapped) {
+      KCHECK(lbmi_k_aa_unswap(&lb->kp, lb->f, lb->stream));
+      lb->layout_swapped = 0;
+    }
+    /* C(t) in place, stored into swapped slots */
+    ifail = lbmi_time_begin(lb);
+    if (ifail) return ifail;
+    KCHECK(lbmi_k_aa_even(&lb->kp, lb->f, &h, lb->stream));
+    ifail = lbmi_time_end(lb);
+    if (ifail) return ifail;
+    lb->layout_swapped = 1;
+    return 0;
+  }
+
   if (lb->pending_prop) {
     /* FUSED: propagation(t) and, by index wrap / overlapped exchange, the
      * halo swap(t), are done inside the collision(t+1) kernel */
@@ -918,7 +980,11 @@ int lbmi_lb_halo(lbmi_t * lb) {
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
 
-  if (lb->opts.mode == LBMI_MODE_FUSED) {
+  if (lbmi_deferred(lb)) {
+    if (lb->early_prop) {
+      lb->halo_seen = 1;               /* k_aa_odd has wrapped by index */
+      return 0;
+    }
     if (lb->pending_prop) {
       return lbmi_fail(LBMI_ERR_STATE, "lb_halo while a propagation is pending");
     }
@@ -940,7 +1006,13 @@ int lbmi_lb_propagation(lbmi_t * lb) {
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
 
-  if (lb->opts.mode == LBMI_MODE_FUSED) {
+  if (lbmi_deferred(lb)) {
+    if (lb->early_prop) {
+      /* done inside k_aa_odd: f is canonical now */
+      lb->early_prop = 0;
+      lb->halo_seen = 0;
+      return 0;
+    }
     if (lb->pending_prop) {
       return lbmi_fail(LBMI_ERR_STATE, "two propagations without a collision");
     }
@@ -948,6 +1020,10 @@ int lbmi_lb_propagation(lbmi_t * lb) {
       /* A propagation that follows no halo swap (stale halos) cannot be
        * deferred faithfully: run it now */
       HIPCHECK(hipSetDevice(lb->device));
+      if (lb->layout_swapped) {
+	KCHECK(lbmi_k_aa_unswap(&lb->kp, lb->f, lb->stream));
+	lb->layout_swapped = 0;
+      }
       KCHECK(lbmi_k_propagate(&lb->kp, lb->f, lb->fprime, lb->stream));
       lbmi_swapf(lb);
       return 0;
@@ -978,6 +1054,25 @@ int lbmi_lb_flush(lbmi_t * lb) {
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   HIPCHECK(hipSetDevice(lb->device));
 
+  if (lb->early_prop) {
+    /* k_aa_odd has already applied P(t+1); the caller is between
+     * lb_collide and lb_propagation, where f must be the post-collision
+     * state: undo the propagation (exactly: it is a permutation) */
+    KCHECK(lbmi_k_unpropagate_wrap(&lb->kp, lb->f, lb->fprime, 7, lb->stream));
+    lbmi_swapf(lb);
+    lb->early_prop = 0;
+    if (lb->halo_seen) {
+      int ifail = lbmi_halo(lb, lb->f, lb->opts.halo_scheme);
+      if (ifail) return ifail;
+      lb->halo_seen = 0;
+    }
+    return 0;
+  }
+  if (lb->layout_swapped) {
+    KCHECK(lbmi_k_aa_unswap(&lb->kp, lb->f, lb->stream));
+    lb->layout_swapped = 0;
+  }
+
   if (lb->pending_halo) {
     int ifail = lbmi_halo(lb, lb->f, lb->opts.halo_scheme);
     if (ifail) return ifail;
@@ -1006,6 +1101,9 @@ int lbmi_lb_memcpy_h2d(lbmi_t * lb, const double * f_host) {
   sz = sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel;
   lb->pending_halo = 0;
   lb->pending_prop = 0;
+  lb->layout_swapped = 0;
+  lb->early_prop = 0;
+  lb->halo_seen = 0;
   HIPCHECK(hipMemcpyAsync(lb->f, f_host, sz, hipMemcpyHostToDevice, lb->stream));
   HIPCHECK(hipStreamSynchronize(lb->stream));
   return 0;

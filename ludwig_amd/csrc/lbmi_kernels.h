@@ -72,6 +72,18 @@ int lbmi_k_propagate_collide(const lbmi_kparam_t * kp, const double * f,
 			     int wrapmask, int xlo, int xhi, int xlo2, int xhi2,
 			     void * stream);
 
+/* In-place streaming (AA pattern), single GPU, all directions wrapped by
+ * index: even = collide in place into swapped slots; odd = pull (from the
+ * swapped or the normal layout) + collide + push into the normal layout. */
+int lbmi_k_aa_even(const lbmi_kparam_t * kp, double * f,
+		   const lbmi_hydro_dev_t * h, void * stream);
+int lbmi_k_aa_odd(const lbmi_kparam_t * kp, double * f,
+		  const lbmi_hydro_dev_t * h, int wrapmask, int swapped_in,
+		  void * stream);
+int lbmi_k_aa_unswap(const lbmi_kparam_t * kp, double * f, void * stream);
+int lbmi_k_unpropagate_wrap(const lbmi_kparam_t * kp, const double * f,
+			    double * fprime, int wrapmask, void * stream);
+
 /* In-place periodic halo copy for direction dir on an SoA field with
  * components of stride nsite. */
 int lbmi_k_halo_copy(const lbmi_kparam_t * kp, int dir,

@@ -451,9 +451,9 @@ void k_collide(lbmi_kparam_t kp, double * __restrict__ f,
 	       lbmi_hydro_dev_t h, int i0, int i1, unsigned nblk) {
 
   unsigned lb;
-  if (!logical_block(nblk, lb)) return;
-  int i = i0 + (int) (lb*BLOCK + threadIdx.x);
-  if (i >= i1) return;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
 
   Site s = decode(kp, i);
   if (!s.interior) return;
@@ -492,9 +492,9 @@ void k_propagate(lbmi_kparam_t kp, const double * __restrict__ f,
 
   using M = Model<NVEL>;
   unsigned lb;
-  if (!logical_block(nblk, lb)) return;
-  int i = i0 + (int) (lb*BLOCK + threadIdx.x);
-  if (i >= i1) return;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
 
   Site s = decode(kp, i);
   const size_t ns = (size_t) kp.nsite;
@@ -655,6 +655,218 @@ void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
   static_for<0, SPT>([&](auto K) {
     constexpr int k = K;
     if (i[k] >= i0 && i[k] < i1) pc_collide_store<NVEL, SCHEME>(kp, fp, h, i[k], ps[k]);
+  });
+}
+
+/* ---- in-place streaming: the AA pattern --------------------------------------
+ *
+ * One array, two alternating kernels (Bailey et al. 2009). Every thread reads
+ * and writes the SAME set of addresses, so f is updated in place: HBM sees
+ * nvel read-modify-write streams instead of nvel read + nvel write streams,
+ * which the memory system serves ~10 % faster (profiles/r01_probes.txt).
+ *
+ *   k_aa_even:  C(t)                 read (x, slot p), collide, write the
+ *                                    post-collision p to (x, slot opp(p)).
+ *   k_aa_odd :  P(t) C(t+1) P(t+1)   read p from (x - c_p, slot opp(p))
+ *                                    [= pull-propagation of the swapped
+ *                                    layout], collide, write p to
+ *                                    (x + c_p, slot p) [= push-propagation
+ *                                    into the normal layout].
+ *
+ * With R(x) = {(x - c_p, opp(p))} and W(x) = {(x + c_p, p)} the substitution
+ * q = opp(p) shows W(x) = R(x): no location is shared between threads.
+ * opp(p) = nvel - p for p >= 1 (cv[p] = -cv[nvel - p] in both velocity sets,
+ * tests/unit/test_lb_model.c:103-140). Periodic directions are wrapped by
+ * index arithmetic on both the pull and the push; y/z halo lanes idle (their
+ * lines are resident from the neighbouring lanes' loads, so the gaps in the
+ * store streams cost nothing here). SWAPPED_IN = false lets k_aa_odd start
+ * from the normal layout (after a flush).
+ */
+
+template <int NVEL> __host__ __device__ constexpr int opp(int p) {
+  return (p == 0) ? 0 : NVEL - p;
+}
+
+struct WrapAdj { int wlo[3]; int whi[3]; };
+
+__device__ __forceinline__
+WrapAdj wrap_adjust(const lbmi_kparam_t & kp, const Site & s, int wrapmask) {
+  WrapAdj w = {{0, 0, 0}, {0, 0, 0}};
+  const int nh = kp.nhalo;
+  if ((wrapmask & 1) && s.x == nh) w.wlo[0] = kp.nlocal[0]*kp.strx;
+  if ((wrapmask & 1) && s.x == nh + kp.nlocal[0] - 1) w.whi[0] = -kp.nlocal[0]*kp.strx;
+  if ((wrapmask & 2) && s.y == nh) w.wlo[1] = kp.nlocal[1]*kp.stry;
+  if ((wrapmask & 2) && s.y == nh + kp.nlocal[1] - 1) w.whi[1] = -kp.nlocal[1]*kp.stry;
+  if ((wrapmask & 4) && s.z == nh) w.wlo[2] = kp.nlocal[2];
+  if ((wrapmask & 4) && s.z == nh + kp.nlocal[2] - 1) w.whi[2] = -kp.nlocal[2];
+  return w;
+}
+
+template <int NVEL, int SCHEME>
+__device__ __forceinline__
+void site_collide_hydro(const lbmi_kparam_t & kp, const lbmi_hydro_dev_t & h,
+			int i, double (&fl)[NVEL]) {
+  const size_t ns = (size_t) kp.nsite;
+  double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
+  if (h.force) {
+    frc[0] += h.force[i];
+    frc[1] += h.force[ns + i];
+    frc[2] += h.force[2*ns + i];
+  }
+  Relax rx = {kp.rtau_shear, kp.rtau_bulk, kp.rtau_even, kp.rtau_odd};
+  double rho, u[3];
+  collide_site<NVEL, SCHEME>(fl, frc, rx, rho, u);
+  if (h.rho) h.rho[i] = rho;
+  if (h.u) {
+    h.u[i] = u[0];
+    h.u[ns + i] = u[1];
+    h.u[2*ns + i] = u[2];
+  }
+}
+
+template <int NVEL, int SCHEME>
+__global__ __launch_bounds__(BLOCK, LBMI_WAVES)
+void k_aa_even(lbmi_kparam_t kp, double * __restrict__ f, lbmi_hydro_dev_t h,
+	       int i0, int i1, unsigned nblk) {
+
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+
+  Site s = decode(kp, i);
+  if (!s.interior) return;
+
+  const size_t ns = (size_t) kp.nsite;
+  double fl[NVEL];
+  static_for<0, NVEL>([&](auto P) { fl[P] = f[ns*P + i]; });
+
+  bool fluid = true;
+  if (h.status) fluid = (h.status[i] == 0);
+#if LBMI_ABL_NOCOLLIDE
+  fluid = false;
+#endif
+  if (fluid) site_collide_hydro<NVEL, SCHEME>(kp, h, i, fl);
+
+  static_for<0, NVEL>([&](auto P) {
+    constexpr int p = P;
+    f[ns*opp<NVEL>(p) + i] = fl[p];
+  });
+}
+
+template <int NVEL, int SCHEME, bool SWAPPED_IN>
+__global__ __launch_bounds__(BLOCK, LBMI_WAVES)
+void k_aa_odd(lbmi_kparam_t kp, double * __restrict__ f, lbmi_hydro_dev_t h,
+	      int wrapmask, int i0, int i1, unsigned nblk) {
+
+  using M = Model<NVEL>;
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+
+  Site s = decode(kp, i);
+  if (!s.interior) return;
+
+  const size_t ns = (size_t) kp.nsite;
+  const WrapAdj w = wrap_adjust(kp, s, wrapmask);
+
+  /* pull: population p of this site sits at x - c_p (periodic image if that
+   * is across a wrapped face), in slot opp(p) if the layout is swapped */
+  double fl[NVEL];
+  static_for<0, NVEL>([&](auto P) {
+    constexpr int p = P;
+    constexpr int cx = M::c(p,0), cy = M::c(p,1), cz = M::c(p,2);
+    constexpr int slot = SWAPPED_IN ? opp<NVEL>(p) : p;
+    int off = cx*kp.strx + cy*kp.stry + cz;
+    if constexpr (cx ==  1) off -= w.wlo[0];
+    if constexpr (cx == -1) off -= w.whi[0];
+    if constexpr (cy ==  1) off -= w.wlo[1];
+    if constexpr (cy == -1) off -= w.whi[1];
+    if constexpr (cz ==  1) off -= w.wlo[2];
+    if constexpr (cz == -1) off -= w.whi[2];
+    fl[p] = f[ns*slot + (i - off)];
+  });
+
+  bool fluid = true;
+  if (h.status) fluid = (h.status[i] == 0);
+#if LBMI_ABL_NOCOLLIDE
+  fluid = false;
+#endif
+  if (fluid) site_collide_hydro<NVEL, SCHEME>(kp, h, i, fl);
+
+  /* push: post-collision p goes to x + c_p, slot p. Across the high face
+   * (c = +1 at the last site) subtract the extent, across the low face
+   * (c = -1 at the first site) add it: whi = -extent, wlo = +extent. */
+  static_for<0, NVEL>([&](auto P) {
+    constexpr int p = P;
+    constexpr int cx = M::c(p,0), cy = M::c(p,1), cz = M::c(p,2);
+    int off = cx*kp.strx + cy*kp.stry + cz;
+    if constexpr (cx ==  1) off += w.whi[0];
+    if constexpr (cx == -1) off += w.wlo[0];
+    if constexpr (cy ==  1) off += w.whi[1];
+    if constexpr (cy == -1) off += w.wlo[1];
+    if constexpr (cz ==  1) off += w.whi[2];
+    if constexpr (cz == -1) off += w.wlo[2];
+    f[ns*p + (i + off)] = fl[p];
+  });
+}
+
+/* swapped <-> normal slot layout, in place (its own inverse) */
+
+template <int NVEL>
+__global__ __launch_bounds__(BLOCK)
+void k_aa_unswap(lbmi_kparam_t kp, double * __restrict__ f, int i0, int i1,
+		 unsigned nblk) {
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+  Site s = decode(kp, i);
+  if (!s.interior) return;
+  const size_t ns = (size_t) kp.nsite;
+  static_for<1, (NVEL + 1)/2>([&](auto P) {
+    constexpr int p = P;
+    constexpr int q = opp<NVEL>(p);
+    double a = f[ns*p + i];
+    double b = f[ns*q + i];
+    f[ns*p + i] = b;
+    f[ns*q + i] = a;
+  });
+}
+
+/* fprime[p][x] = f[p][x + c_p] with periodic wrap by index: the inverse of
+ * the propagation (used to hand back a post-collision state when a flush
+ * arrives after k_aa_odd has already propagated) */
+
+template <int NVEL>
+__global__ __launch_bounds__(BLOCK)
+void k_unpropagate_wrap(lbmi_kparam_t kp, const double * __restrict__ f,
+			double * __restrict__ fp, int wrapmask, int i0,
+			int i1, unsigned nblk) {
+  using M = Model<NVEL>;
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+  Site s = decode(kp, i);
+  const size_t ns = (size_t) kp.nsite;
+  if (!s.interior) {
+    static_for<0, NVEL>([&](auto P) { fp[ns*P + i] = f[ns*P + i]; });
+    return;
+  }
+  const WrapAdj w = wrap_adjust(kp, s, wrapmask);
+  static_for<0, NVEL>([&](auto P) {
+    constexpr int p = P;
+    constexpr int cx = M::c(p,0), cy = M::c(p,1), cz = M::c(p,2);
+    int off = cx*kp.strx + cy*kp.stry + cz;
+    if constexpr (cx ==  1) off += w.whi[0];
+    if constexpr (cx == -1) off += w.wlo[0];
+    if constexpr (cy ==  1) off += w.whi[1];
+    if constexpr (cy == -1) off += w.wlo[1];
+    if constexpr (cz ==  1) off += w.whi[2];
+    if constexpr (cz == -1) off += w.wlo[2];
+    fp[ns*p + i] = f[ns*p + (i + off)];
   });
 }
 
@@ -936,20 +1148,22 @@ int launch_collide(const lbmi_kparam_t & kp, double * f,
 		   const lbmi_hydro_dev_t & h, hipStream_t st) {
   int i0 = kp.nhalo*kp.strx;
   int i1 = (kp.nhalo + kp.nlocal[0])*kp.strx;
-  unsigned nblk = (unsigned) ((i1 - i0 + BLOCK - 1)/BLOCK);
-  dim3 grid(grid_for(nblk)), block(BLOCK);
+  int i0a = (i0/LBMI_ALIGN)*LBMI_ALIGN;
+  unsigned nblk = (unsigned) ((i1 - i0a + BLOCK - 1)/BLOCK);
+  dim3 grid(grid_for(nblk, (unsigned) kp.xcd_group)), block(BLOCK);
+  unsigned lds = (kp.lds_cap <= 65536 && nblk > 1024u) ? (unsigned) kp.lds_cap : 0u;
   switch (kp.scheme) {
   case LBMI_M10:
-    hipLaunchKernelGGL((k_collide<NVEL, LBMI_M10>), grid, block, 0, st,
+    hipLaunchKernelGGL((k_collide<NVEL, LBMI_M10>), grid, block, lds, st,
 		       kp, f, h, i0, i1, nblk);
     break;
   case LBMI_BGK:
-    hipLaunchKernelGGL((k_collide<NVEL, LBMI_BGK>), grid, block, 0, st,
+    hipLaunchKernelGGL((k_collide<NVEL, LBMI_BGK>), grid, block, lds, st,
 		       kp, f, h, i0, i1, nblk);
     break;
   case LBMI_TRT:
     if constexpr (NVEL == 19) {
-      hipLaunchKernelGGL((k_collide<NVEL, LBMI_TRT>), grid, block, 0, st,
+      hipLaunchKernelGGL((k_collide<NVEL, LBMI_TRT>), grid, block, lds, st,
 			 kp, f, h, i0, i1, nblk);
       break;
     }
@@ -1014,6 +1228,76 @@ int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
   return (int) hipGetLastError();
 }
 
+struct Range1D {
+  int i0, i1;
+  unsigned nblk, grid, lds;
+};
+
+inline Range1D interior_range(const lbmi_kparam_t & kp) {
+  Range1D r;
+  r.i0 = kp.nhalo*kp.strx;
+  r.i1 = (kp.nhalo + kp.nlocal[0])*kp.strx;
+  int i0a = (r.i0/LBMI_ALIGN)*LBMI_ALIGN;
+  r.nblk = (unsigned) ((r.i1 - i0a + BLOCK - 1)/BLOCK);
+  r.grid = grid_for(r.nblk, (unsigned) kp.xcd_group);
+  r.lds = (kp.lds_cap <= 65536 && r.nblk > 1024u) ? (unsigned) kp.lds_cap : 0u;
+  return r;
+}
+
+template <int NVEL>
+int launch_aa_even(const lbmi_kparam_t & kp, double * f,
+		   const lbmi_hydro_dev_t & h, hipStream_t st) {
+  Range1D r = interior_range(kp);
+  dim3 grid(r.grid), block(BLOCK);
+  switch (kp.scheme) {
+  case LBMI_M10:
+    hipLaunchKernelGGL((k_aa_even<NVEL, LBMI_M10>), grid, block, r.lds, st,
+		       kp, f, h, r.i0, r.i1, r.nblk);
+    break;
+  case LBMI_BGK:
+    hipLaunchKernelGGL((k_aa_even<NVEL, LBMI_BGK>), grid, block, r.lds, st,
+		       kp, f, h, r.i0, r.i1, r.nblk);
+    break;
+  case LBMI_TRT:
+    if constexpr (NVEL == 19) {
+      hipLaunchKernelGGL((k_aa_even<NVEL, LBMI_TRT>), grid, block, r.lds, st,
+			 kp, f, h, r.i0, r.i1, r.nblk);
+      break;
+    }
+    return (int) hipErrorInvalidValue;
+  default:
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
+template <int NVEL, bool SWAPPED_IN>
+int launch_aa_odd(const lbmi_kparam_t & kp, double * f,
+		  const lbmi_hydro_dev_t & h, int wrapmask, hipStream_t st) {
+  Range1D r = interior_range(kp);
+  dim3 grid(r.grid), block(BLOCK);
+  switch (kp.scheme) {
+  case LBMI_M10:
+    hipLaunchKernelGGL((k_aa_odd<NVEL, LBMI_M10, SWAPPED_IN>), grid, block,
+		       r.lds, st, kp, f, h, wrapmask, r.i0, r.i1, r.nblk);
+    break;
+  case LBMI_BGK:
+    hipLaunchKernelGGL((k_aa_odd<NVEL, LBMI_BGK, SWAPPED_IN>), grid, block,
+		       r.lds, st, kp, f, h, wrapmask, r.i0, r.i1, r.nblk);
+    break;
+  case LBMI_TRT:
+    if constexpr (NVEL == 19) {
+      hipLaunchKernelGGL((k_aa_odd<NVEL, LBMI_TRT, SWAPPED_IN>), grid, block,
+			 r.lds, st, kp, f, h, wrapmask, r.i0, r.i1, r.nblk);
+      break;
+    }
+    return (int) hipErrorInvalidValue;
+  default:
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
 template <int NVEL>
 int model_tables(int8_t * cv, double * wv, double * na, double * ma) {
   using M = Model<NVEL>;
@@ -1045,14 +1329,16 @@ extern "C" int lbmi_k_propagate(const lbmi_kparam_t * kp, const double * f,
   hipStream_t st = (hipStream_t) stream;
   int i0 = kp->nhalo*kp->strx;
   int i1 = (kp->nhalo + kp->nlocal[0])*kp->strx;
-  unsigned nblk = (unsigned) ((i1 - i0 + BLOCK - 1)/BLOCK);
-  dim3 grid(grid_for(nblk)), block(BLOCK);
+  int i0a = (i0/LBMI_ALIGN)*LBMI_ALIGN;
+  unsigned nblk = (unsigned) ((i1 - i0a + BLOCK - 1)/BLOCK);
+  dim3 grid(grid_for(nblk, (unsigned) kp->xcd_group)), block(BLOCK);
+  unsigned lds = (kp->lds_cap <= 65536 && nblk > 1024u) ? (unsigned) kp->lds_cap : 0u;
   if (kp->nvel == 19) {
-    hipLaunchKernelGGL((k_propagate<19>), grid, block, 0, st, *kp, f, fprime,
+    hipLaunchKernelGGL((k_propagate<19>), grid, block, lds, st, *kp, f, fprime,
 		       i0, i1, nblk);
   }
   else if (kp->nvel == 27) {
-    hipLaunchKernelGGL((k_propagate<27>), grid, block, 0, st, *kp, f, fprime,
+    hipLaunchKernelGGL((k_propagate<27>), grid, block, lds, st, *kp, f, fprime,
 		       i0, i1, nblk);
   }
   else {
@@ -1087,6 +1373,68 @@ extern "C" int lbmi_k_propagate_collide(const lbmi_kparam_t * kp,
       : launch_pc<27, false>(*kp, f, fprime, *h, 0, i0, i1, j0, j1, st);
   }
   return (int) hipErrorInvalidValue;
+}
+
+extern "C" int lbmi_k_aa_even(const lbmi_kparam_t * kp, double * f,
+			      const lbmi_hydro_dev_t * h, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  if (kp->nvel == 19) return launch_aa_even<19>(*kp, f, *h, st);
+  if (kp->nvel == 27) return launch_aa_even<27>(*kp, f, *h, st);
+  return (int) hipErrorInvalidValue;
+}
+
+extern "C" int lbmi_k_aa_odd(const lbmi_kparam_t * kp, double * f,
+			     const lbmi_hydro_dev_t * h, int wrapmask,
+			     int swapped_in, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  if (kp->nvel == 19) {
+    return swapped_in ? launch_aa_odd<19, true>(*kp, f, *h, wrapmask, st)
+      : launch_aa_odd<19, false>(*kp, f, *h, wrapmask, st);
+  }
+  if (kp->nvel == 27) {
+    return swapped_in ? launch_aa_odd<27, true>(*kp, f, *h, wrapmask, st)
+      : launch_aa_odd<27, false>(*kp, f, *h, wrapmask, st);
+  }
+  return (int) hipErrorInvalidValue;
+}
+
+extern "C" int lbmi_k_aa_unswap(const lbmi_kparam_t * kp, double * f,
+				void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  Range1D r = interior_range(*kp);
+  dim3 grid(r.grid), block(BLOCK);
+  if (kp->nvel == 19) {
+    hipLaunchKernelGGL((k_aa_unswap<19>), grid, block, r.lds, st, *kp, f,
+		       r.i0, r.i1, r.nblk);
+  }
+  else if (kp->nvel == 27) {
+    hipLaunchKernelGGL((k_aa_unswap<27>), grid, block, r.lds, st, *kp, f,
+		       r.i0, r.i1, r.nblk);
+  }
+  else {
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_unpropagate_wrap(const lbmi_kparam_t * kp,
+				       const double * f, double * fprime,
+				       int wrapmask, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  Range1D r = interior_range(*kp);
+  dim3 grid(r.grid), block(BLOCK);
+  if (kp->nvel == 19) {
+    hipLaunchKernelGGL((k_unpropagate_wrap<19>), grid, block, r.lds, st, *kp,
+		       f, fprime, wrapmask, r.i0, r.i1, r.nblk);
+  }
+  else if (kp->nvel == 27) {
+    hipLaunchKernelGGL((k_unpropagate_wrap<27>), grid, block, r.lds, st, *kp,
+		       f, fprime, wrapmask, r.i0, r.i1, r.nblk);
+  }
+  else {
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
 }
 
 extern "C" int lbmi_k_halo_copy(const lbmi_kparam_t * kp, int dir,

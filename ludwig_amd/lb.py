@@ -20,7 +20,7 @@ import numpy as np
 from . import lib as _l
 
 M10, BGK, TRT = 0, 1, 2                    # lb_relaxation_enum_t
-EAGER, FUSED = 0, 1                        # lbmi_mode_t
+EAGER, FUSED, INPLACE = 0, 1, 2            # lbmi_mode_t
 HALO_FULL, HALO_REDUCED = 0, 2             # lbmi_halo_t
 _SCHEMES = {"m10": M10, "bgk": BGK, "trt": TRT}
 

@@ -128,7 +128,7 @@ def test_reduced_halo_same_interior(name):
 
 # --- whole time steps: EAGER and FUSED against the reference -----------------
 
-@pytest.mark.parametrize("mode", [0, 1], ids=["eager", "fused"])
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["eager", "fused", "inplace"])
 @pytest.mark.parametrize("halo_scheme", [0, 2], ids=["full", "reduced"])
 @pytest.mark.parametrize("name", golden_names())
 def test_steps_vs_reference(name, mode, halo_scheme):
@@ -165,7 +165,7 @@ def test_fused_equals_eager_bitwise_inputs(name):
     meta = g["meta"]
     h = meta["nhalo"]
     out = []
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         lb = make_lb(meta, mode=mode)
         hy = make_hydro(lb, g, meta)
         lb.lb_memcpy_h2d(g["f0"])
@@ -174,6 +174,62 @@ def test_fused_equals_eager_bitwise_inputs(name):
         out.append(interior(lb.lb_memcpy_d2h(), h).copy())
         lb.free()
     assert relmax(out[1], out[0]) < 1e-14
+    assert relmax(out[2], out[0]) < 1e-14
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["fused", "inplace"])
+@pytest.mark.parametrize("name", ["q19_bgk_ffield", "q27_m10_ffield", "q19_m10_solid"])
+def test_flush_at_every_call_point(name, mode):
+    """A device-to-host copy (which flushes) placed after ANY call of ANY
+    step must return what EAGER holds at that point, and must not disturb
+    the run. Probe points: after lb_collide (0), lb_halo (1),
+    lb_propagation (2) of steps 0..3."""
+    g = load_golden(name)
+    meta = g["meta"]
+    h = meta["nhalo"]
+    nsteps = 4
+
+    def run(run_mode, probe):
+        lb = make_lb(meta, mode=run_mode)
+        hy = make_hydro(lb, g, meta)
+        lb.lb_memcpy_h2d(g["f0"])
+        seen = None
+        for n in range(nsteps):
+            for k, call in enumerate((lambda: lb.lb_collide(hy), lb.lb_halo,
+                                      lb.lb_propagation)):
+                call()
+                if probe == (n, k):
+                    seen = interior(lb.lb_memcpy_d2h(), h).copy()
+        final = interior(lb.lb_memcpy_d2h(), h).copy()
+        lb.free()
+        return seen, final
+
+    for n in range(nsteps):
+        for k in range(3):
+            ref_seen, ref_final = run(0, (n, k))
+            seen, final = run(mode, (n, k))
+            assert relmax(seen, ref_seen) < 1e-14, (n, k)
+            assert relmax(final, ref_final) < 1e-14, (n, k)
+
+
+def test_inplace_keeps_one_array():
+    """INPLACE streams within f: the array behind lb.f does not change from
+    step to step and fprime is never written by the step kernels."""
+    import ludwig_amd
+    g = load_golden("q19_m10")
+    meta = g["meta"]
+    lb = make_lb(meta, mode=ludwig_amd.INPLACE)
+    lb.lb_memcpy_h2d(g["f0"])
+    ptr0 = lb.f.data_ptr()
+    lb.fprime.fill_(-7.0)
+    import torch
+    torch.cuda.synchronize()
+    for _ in range(6):
+        lb.step(None)
+        assert lb.f.data_ptr() == ptr0
+    lb.synchronize()
+    assert float(lb.fprime.min()) == -7.0 and float(lb.fprime.max()) == -7.0
+    lb.free()
 
 
 def test_fused_state_errors():
@@ -234,7 +290,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", [0, 1], ids=["eager", "fused"])
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["eager", "fused", "inplace"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "q%d-%s-%s" % (c[0], "x".join(map(str, c[1])), c[3]))
 def test_seeded_vs_oracle(case, mode):
     import ludwig_amd
@@ -299,7 +355,7 @@ def test_field_halo(nhalo):
 
 # --- reference regression log on the device ---------------------------------
 
-@pytest.mark.parametrize("mode", [0, 1], ids=["eager", "fused"])
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["eager", "fused", "inplace"])
 def test_regression_log_1dp(mode):
     import ludwig_amd
     case = load_expected()["serial-dist-1dp"]

@@ -61,7 +61,20 @@ __global__ void k_streams(const double * __restrict__ f, double * __restrict__ f
 #pragma unroll
       for (int k = 0; k < SPT; k++) v[p][k] = 1.0 + p + k;
   }
-  if constexpr (MODE == 1) {
+  if constexpr (MODE == 3) {
+    // in-place: write back (modified) to the addresses just read, as the
+    // AA-pattern does; f and fp are the same array
+    double * fw = const_cast<double *>(f);
+#pragma unroll
+    for (int p = 0; p < NS; p++) {
+      long long sh = SHIFT ? ((p % 3) - 1) + 258*(((p/3) % 3) - 1) : 0;
+#pragma unroll
+      for (int k = 0; k < SPT; k++) {
+	long long i = base + 64*k;
+	if (i < i1) fw[nsite*p + i - sh] = v[p][k]*1.0000001;
+      }
+    }
+  } else if constexpr (MODE == 1) {
 #pragma unroll
     for (int k = 0; k < SPT; k++) {
       double s = 0.0;
@@ -109,7 +122,7 @@ void run(const char * name, hipStream_t st, const double * a, double * b, size_t
   auto kern = k_streams<NS, MODE, SPT, SHIFT>;
   if (lds > 65536) CHECK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
   double ms = time_it(st, 10, [&]{ hipLaunchKernelGGL(kern, dim3(grid), dim3(bs), lds, st, a, b, nsite, i0, i1, nblk, group); });
-  double nstream = (MODE == 0) ? 2.0*NS : (double) NS;
+  double nstream = (MODE == 0 || MODE == 3) ? 2.0*NS : (double) NS;
   double gb = nstream*8.0*(double) (i1 - i0)*1e-9;
   printf("%-28s NS=%2d spt=%d bs=%4d lds=%6u g=%3u i0%%16=%2d  %7.3f ms %8.1f GB/s\n", name, NS, SPT, bs, lds, group, (int) (i0 % 16), ms, gb/ms*1e3);
 }
@@ -126,16 +139,12 @@ int main() {
   hipStream_t st;
   CHECK(hipStreamCreate(&st));
 
-  // alignment of the block starts relative to 128-B lines (16 sites)
   for (int rep = 0; rep < 2; rep++) {
-    for (int ioff : {0, 4, 8, 12, 1, 15}) {
-      run<19, 2, 1, 0>("write-only", st, a, b, nsite, 256, 65536, 16, ioff);
-    }
-    for (int ioff : {0, 4, 8, 12, 1, 15}) {
-      run<19, 0, 1, 1>("copy shift", st, a, b, nsite, 256, 65536, 16, ioff);
-    }
-    for (int ioff : {0, 4, 8}) {
-      run<19, 1, 1, 1>("read-only shift", st, a, b, nsite, 256, 65536, 16, ioff);
+    for (unsigned lds : {0u, 32768u, 65536u}) {
+      run<19, 0, 1, 1>("copy shift (2 arrays)", st, a, b, nsite, 256, lds, 16, 0);
+      run<19, 3, 1, 0>("in-place aligned", st, a, b, nsite, 256, lds, 16, 0);
+      run<19, 3, 1, 1>("in-place shifted", st, a, b, nsite, 256, lds, 16, 0);
+      run<27, 3, 1, 1>("in-place shifted", st, a, b, nsite, 256, lds, 16, 0);
     }
   }
   return 0;
