@@ -46,6 +46,11 @@ def parse():
     ap.add_argument("--hydro", type=int, default=1,
                     help="1: lb_collide reads hydro->force and writes "
                     "hydro->rho,u as the reference does; 0: NULL hydro arrays")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="weak: --size is the per-GPU box, stacked along X")
+    ap.add_argument("--nhalo", type=int, default=1)
+    ap.add_argument("--force-field", type=int, default=0,
+                    help="1: per-site force F = 1e-5 cos(2 pi x/L) (BASELINE config 4)")
     ap.add_argument("--selfring", type=int, default=0,
                     help="1 GPU only: route the X halo through a 1-rank RCCL "
                     "ring (exercises the N>1 step path: pack, send/recv, "
@@ -130,10 +135,12 @@ def main():
             dist.barrier()
 
     ntotal = tuple(args.size)
-    dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, nhalo=1)
+    if args.scaling == "weak":
+        ntotal = (args.size[0] * world, args.size[1], args.size[2])
+    dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, nhalo=args.nhalo)
     mode = {"fused": ludwig_amd.FUSED, "eager": ludwig_amd.EAGER,
             "inplace": ludwig_amd.INPLACE}[args.mode]
-    lb = ludwig_amd.LB(args.nvel, dec.nlocal, 1, mode=mode,
+    lb = ludwig_amd.LB(args.nvel, dec.nlocal, args.nhalo, mode=mode,
                        halo_scheme=ludwig_amd.HALO_REDUCED, device=local_rank,
                        cartsz=world, cartrank=rank)
     zeta = 0.3 if args.scheme == "m10" else 0.1
@@ -167,6 +174,17 @@ def main():
         hydro = ludwig_amd.Hydro(lb.nall, lb.device)
         hydro.force = torch.zeros((3,) + lb.nall, dtype=torch.float64,
                                   device=lb.device)   # hydro_f_zero
+        if args.force_field:
+            # stands in for the thermodynamic force of config 4
+            h = args.nhalo
+            for a in range(3):
+                n = lb.nlocal[a]
+                off = dec.noffset[a]
+                c = 1e-5 * torch.cos(2.0 * np.pi * (torch.arange(
+                    n, dtype=torch.float64, device=lb.device) + off) / ntotal[a])
+                shape = [1, 1, 1]
+                shape[a] = n
+                hydro.force[a][h:-h, h:-h, h:-h] = c.reshape(shape)
         torch.cuda.synchronize()
 
     def allsum(v):
@@ -242,7 +260,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 5),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",

@@ -1151,7 +1151,7 @@ int launch_collide(const lbmi_kparam_t & kp, double * f,
   int i0a = (i0/LBMI_ALIGN)*LBMI_ALIGN;
   unsigned nblk = (unsigned) ((i1 - i0a + BLOCK - 1)/BLOCK);
   dim3 grid(grid_for(nblk, (unsigned) kp.xcd_group)), block(BLOCK);
-  unsigned lds = (kp.lds_cap <= 65536 && nblk > 1024u) ? (unsigned) kp.lds_cap : 0u;
+  unsigned lds = (kp.lds_cap <= 65536 && nblk > 4096u) ? (unsigned) kp.lds_cap : 0u;
   switch (kp.scheme) {
   case LBMI_M10:
     hipLaunchKernelGGL((k_collide<NVEL, LBMI_M10>), grid, block, lds, st,
@@ -1187,9 +1187,10 @@ int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
   /* dynamic LDS is not used by the kernel: it only caps the number of
    * resident blocks per CU (160 KiB / lds_cap), see DESIGN.md */
   unsigned lds = (unsigned) kp.lds_cap;
-  /* a launch that fits on the chip in one round anyway (the boundary planes
-   * of a slab) is latency-bound: give it the full occupancy */
-  if (nblk <= 1024u) lds = 0u;
+  /* a launch that fits on the chip in two rounds anyway (the boundary
+   * planes of a slab, a 64^3 lattice) is latency-bound and L2/MALL
+   * resident: give it the full occupancy */
+  if (nblk <= 4096u) lds = 0u;
   if (lds > 65536u) {
     /* above 64 KiB the limit must be raised per kernel */
     const void * fn = nullptr;
@@ -1240,7 +1241,7 @@ inline Range1D interior_range(const lbmi_kparam_t & kp) {
   int i0a = (r.i0/LBMI_ALIGN)*LBMI_ALIGN;
   r.nblk = (unsigned) ((r.i1 - i0a + BLOCK - 1)/BLOCK);
   r.grid = grid_for(r.nblk, (unsigned) kp.xcd_group);
-  r.lds = (kp.lds_cap <= 65536 && r.nblk > 1024u) ? (unsigned) kp.lds_cap : 0u;
+  r.lds = (kp.lds_cap <= 65536 && r.nblk > 4096u) ? (unsigned) kp.lds_cap : 0u;
   return r;
 }
 
@@ -1332,7 +1333,7 @@ extern "C" int lbmi_k_propagate(const lbmi_kparam_t * kp, const double * f,
   int i0a = (i0/LBMI_ALIGN)*LBMI_ALIGN;
   unsigned nblk = (unsigned) ((i1 - i0a + BLOCK - 1)/BLOCK);
   dim3 grid(grid_for(nblk, (unsigned) kp->xcd_group)), block(BLOCK);
-  unsigned lds = (kp->lds_cap <= 65536 && nblk > 1024u) ? (unsigned) kp->lds_cap : 0u;
+  unsigned lds = (kp->lds_cap <= 65536 && nblk > 4096u) ? (unsigned) kp->lds_cap : 0u;
   if (kp->nvel == 19) {
     hipLaunchKernelGGL((k_propagate<19>), grid, block, lds, st, *kp, f, fprime,
 		       i0, i1, nblk);

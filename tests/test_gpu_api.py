@@ -1,0 +1,102 @@
+"""GPU tests of the remaining C-ABI surface: tuning knobs do not change
+results, error paths, moments on caller-owned arrays, timing counters."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lb_oracle as lbo                       # noqa: E402
+from tests.common import interior, relmax                  # noqa: E402
+
+
+def _run(tune, mode, nvel=19, nlocal=(20, 9, 14), nsteps=5):
+    import ludwig_amd
+    p = lbo.make_param(nvel, nlocal, 1, "m10", 0.1, 0.3, 1.0, (1e-6, 0, 0))
+    f0 = lbo.init_synthetic(p)
+    lb = ludwig_amd.LB(nvel, nlocal, 1, mode=mode)
+    lb.relaxation_set("m10", 0.1, 0.3)
+    lb.body_force_set((1e-6, 0, 0))
+    for k, v in tune.items():
+        lb.tune(k, v)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device)
+    lb.lb_memcpy_h2d(f0)
+    for _ in range(nsteps):
+        lb.step(hy)
+    out = interior(lb.lb_memcpy_d2h(), 1).copy()
+    lb.synchronize()
+    u = interior(hy.u.cpu().numpy(), 1).copy()
+    lb.free()
+    return out, u
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["eager", "fused", "inplace"])
+def test_tuning_does_not_change_results(mode):
+    base, ubase = _run({"xcd_group": 0, "lds_cap": 0}, mode)
+    for tune in ({"xcd_group": 16, "lds_cap": 65536},
+                 {"xcd_group": 3, "lds_cap": 40000},
+                 {"xcd_group": 1, "lds_cap": 98304}):
+        out, u = _run(tune, mode)
+        assert np.array_equal(out, base)
+        assert np.array_equal(u, ubase)
+
+
+def test_tune_rejects_unknown_key():
+    import ludwig_amd
+    lb = ludwig_amd.LB(19, (4, 4, 4))
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.tune("no_such_knob", 1)
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.tune("lds_cap", 1 << 20)
+    lb.free()
+
+
+def test_moments_match_oracle_with_status():
+    import ludwig_amd
+    import torch
+    nlocal = (12, 10, 8)
+    p = lbo.make_param(27, nlocal, 2, "m10")
+    f = lbo.init_synthetic(p)
+    st = np.zeros(lbo.nall(p), dtype=np.int8)
+    st[3:6, 4:7, 2:9] = 1
+    ref = lbo.moments(p, f, st)
+    lb = ludwig_amd.LB(27, nlocal, 2)
+    t = torch.from_numpy(f).to(lb.device)
+    s = torch.from_numpy(st).to(lb.device)
+    torch.cuda.synchronize()
+    mo = lb.moments_of(t, s)
+    assert mo[0] == ref[0]
+    assert abs(mo[1] - ref[1]) / ref[1] < 1e-14
+    assert abs(mo[2] - ref[2]) / ref[2] < 1e-14
+    assert mo[3] == ref[3] and mo[4] == ref[4]        # min / max exact
+    assert np.max(np.abs(mo[5:8] - ref[5:8])) < 1e-13
+    # bitwise reproducible run to run (no atomics)
+    assert np.array_equal(mo, lb.moments_of(t, s))
+    lb.free()
+
+
+def test_timing_counts_fused_launches():
+    import ludwig_amd
+    lb = ludwig_amd.LB(19, (16, 16, 16), 1, mode=ludwig_amd.FUSED)
+    lb.lb_memcpy_h2d(lbo.init_synthetic(lbo.make_param(19, (16, 16, 16))))
+    lb.step()
+    lb.timing(True)
+    for _ in range(7):
+        lb.step()
+    ms, n = lb.timing_read()
+    assert n == 7 and ms > 0.0
+    lb.free()
+
+
+def test_unbound_handle_is_a_state_error():
+    import ctypes
+    from ludwig_amd import lib as L
+    lib = L.library()
+    o = L.Options()
+    h = ctypes.c_void_p()
+    lib.lbmi_options_default(ctypes.byref(o))
+    o.nlocal[:] = [4, 4, 4]
+    assert lib.lbmi_create(ctypes.byref(o), ctypes.byref(h)) == 0
+    assert lib.lbmi_lb_collide(h, None) == -6          # LBMI_ERR_STATE
+    assert b"no distributions bound" in lib.lbmi_last_error()
+    assert lib.lbmi_free(h) == 0

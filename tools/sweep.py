@@ -19,6 +19,7 @@ from ludwig_amd import synthetic  # noqa: E402
 
 def main():
     hydro_on, steps, nvel = 0, 30, 19
+    mode_name = "fused"
     size = (256, 256, 256)
     grid = {"g": [0], "lds": [0]}
     args = sys.argv[1:]
@@ -28,6 +29,8 @@ def main():
             hydro_on = int(args.pop(0))
         elif a == "--steps":
             steps = int(args.pop(0))
+        elif a == "--mode":
+            mode_name = args.pop(0)
         elif a == "--nvel":
             nvel = int(args.pop(0))
         elif a == "--size":
@@ -35,7 +38,9 @@ def main():
         else:
             k, v = a.split("=")
             grid[k] = [int(x) for x in v.split(",")]
-    lb = ludwig_amd.LB(nvel, size, 1, mode=ludwig_amd.FUSED,
+    mode = {"fused": ludwig_amd.FUSED, "inplace": ludwig_amd.INPLACE,
+            "eager": ludwig_amd.EAGER}[mode_name]
+    lb = ludwig_amd.LB(nvel, size, 1, mode=mode,
                        halo_scheme=ludwig_amd.HALO_REDUCED)
     lb.relaxation_set("m10", 0.1, 0.3)
     m = ludwig_amd.lb.model(nvel)
@@ -63,9 +68,10 @@ def main():
             ms, n = lb.timing_read()
             lb.timing(False)
             t = ms / n
-            print("%-22s hydro=%d g=%-4d lds=%-6d  %.4f ms  %8.1f MLUPS  %6.0f GB/s(304B)"
-                  % (tag, hydro_on, g, lds, t, sites / t * 1e-3,
-                     304e-9 * sites / (t * 1e-3)), flush=True)
+            bpl = 16 * nvel + (56 if hydro_on else 0)
+            print("%-22s %s hydro=%d g=%-4d lds=%-6d  %.4f ms  %8.1f MLUPS  %6.0f GB/s(%dB)"
+                  % (tag, mode_name, hydro_on, g, lds, t, sites / t * 1e-3,
+                     bpl * 1e-9 * sites / (t * 1e-3), bpl), flush=True)
     lb.free()
 
 
