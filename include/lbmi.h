@@ -225,6 +225,23 @@ int lbmi_lb_memcpy_h2d(lbmi_t * lb, const double * f_host);
 int lbmi_lb_memcpy_d2h(lbmi_t * lb, double * f_host);
 int lbmi_lb_moments(lbmi_t * lb, const char * status, double out[9]);
 
+/* ---- rows "next" of the scope table ----------------------- */
+
+/* hydro_u_zero / hydro_f_zero / hydro_rho0 (hydro.c:279-370, kernel
+ * hydro_field_set): every site (halo included) of an SoA device field of
+ * ncomp = 1..3 components is set to values[]. hydro_u_halo (hydro.c:190)
+ * is lbmi_field_halo(lb, 3, u). */
+int lbmi_hydro_field_set(lbmi_t * lb, double * field, int ncomp,
+			 const double * values);
+
+/* The on-disk record stream of the distribution files, lb_io_aggr_pack /
+ * lb_io_aggr_unpack with lb_write_buf / lb_read_buf (model.c:1385-1430,
+ * 1479-1550): nvel doubles in p order per interior site, sites in
+ * (ic, jc, kc) order. records: DEVICE buffer of nlocal[X]*nlocal[Y]*
+ * nlocal[Z]*nvel doubles. pack flushes a deferred state first. */
+int lbmi_lb_records_pack(lbmi_t * lb, double * records);
+int lbmi_lb_records_unpack(lbmi_t * lb, const double * records);
+
 /* ---- streams / synchronisation ----------------------------------------- */
 
 int lbmi_synchronize(lbmi_t * lb);

@@ -1129,6 +1129,50 @@ int lbmi_lb_moments(lbmi_t * lb, const char * status, double out[9]) {
   return lbmi_moments(lb, lb->f, status, out);
 }
 
+/*****************************************************************************
+ *
+ *  Rows "next": hydro housekeeping and the distribution record stream
+ *
+ *****************************************************************************/
+
+int lbmi_hydro_field_set(lbmi_t * lb, double * field, int ncomp,
+			 const double * values) {
+  if (lb == NULL || field == NULL || values == NULL) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  }
+  if (ncomp < 1 || ncomp > 3) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "ncomp = %d (1..3)", ncomp);
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_field_set(&lb->kp, ncomp, field, values, lb->stream));
+  return 0;
+}
+
+int lbmi_lb_records_pack(lbmi_t * lb, double * records) {
+  int ifail;
+  if (lb == NULL || records == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  ifail = lbmi_lb_flush(lb);
+  if (ifail) return ifail;
+  KCHECK(lbmi_k_records(&lb->kp, lb->f, records, 1, lb->stream));
+  return 0;
+}
+
+int lbmi_lb_records_unpack(lbmi_t * lb, const double * records) {
+  if (lb == NULL || records == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+  HIPCHECK(hipSetDevice(lb->device));
+  /* reading a checkpoint replaces the state: nothing stays pending */
+  lb->pending_halo = 0;
+  lb->pending_prop = 0;
+  lb->early_prop = 0;
+  lb->halo_seen = 0;
+  if (lb->layout_swapped) {
+    lb->layout_swapped = 0;
+  }
+  KCHECK(lbmi_k_records(&lb->kp, lb->f, (double *) records, 0, lb->stream));
+  return 0;
+}
+
 int lbmi_synchronize(lbmi_t * lb) {
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   HIPCHECK(hipSetDevice(lb->device));

@@ -101,6 +101,15 @@ int lbmi_k_halo_unpack_x(const lbmi_kparam_t * kp, const lbmi_halo_sel_t * sel,
 			 double * data, const double * buf_lo,
 			 const double * buf_hi, void * stream);
 
+/* Record stream of the distribution files: pack != 0: f -> rec, else
+ * rec -> f (interior sites only). rec: ninterior*nvel doubles (device). */
+int lbmi_k_records(const lbmi_kparam_t * kp, double * f, double * rec,
+		   int pack, void * stream);
+
+/* hydro_field_set: all nsite sites of ncomp (1..3) components := v[] */
+int lbmi_k_field_set(const lbmi_kparam_t * kp, int ncomp, double * field,
+		     const double * v, void * stream);
+
 /* Moments: partial (nblk x 12 doubles workspace) then final (out_dev[9]) */
 int lbmi_k_moments_nblk(void);
 int lbmi_k_moments(const lbmi_kparam_t * kp, const double * f,

@@ -974,6 +974,85 @@ void k_halo_unpack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
   }
 }
 
+/* ---- record stream (the distribution file format) -------------------------
+ *
+ * lb_io_aggr_pack with lb_write_buf (model.c:1385-1402, 1479-1510): one
+ * record of nvel doubles (p order) per INTERIOR site, sites in (ic,jc,kc)
+ * order, independent of the memory order. On the device this is an
+ * SoA-with-halo <-> dense AoS transposition: a block takes RB consecutive
+ * interior sites, moves them through an LDS tile so that BOTH sides are
+ * coalesced (population-major reads of 512 B per wave, contiguous record
+ * writes), 2*nvel*8 bytes per site of HBM traffic. */
+
+enum {RB = 256};
+
+__device__ __forceinline__
+size_t interior_site(const lbmi_kparam_t & kp, long long ib) {
+  /* ib-th interior site in (x, y, z) order -> site index */
+  int nz = kp.nlocal[2], ny = kp.nlocal[1];
+  long long xy = ib / nz;
+  int z = (int) (ib - xy*nz);
+  int x = (int) (xy / ny);
+  int y = (int) (xy - (long long) x*ny);
+  return (size_t) (x + kp.nhalo)*kp.strx + (size_t) (y + kp.nhalo)*kp.stry
+    + (size_t) (z + kp.nhalo);
+}
+
+template <int NVEL, bool PACK>
+__global__ __launch_bounds__(RB)
+void k_records(lbmi_kparam_t kp, double * __restrict__ f,
+	       double * __restrict__ rec, long long ninterior) {
+
+  /* tile[site][p], row length NVEL + 1 doubles against bank conflicts */
+  __shared__ double tile[RB*(NVEL + 1)];
+  const size_t ns = (size_t) kp.nsite;
+  const long long ib0 = (long long) blockIdx.x*RB;
+  const int nhere = (int) ((ninterior - ib0 < RB) ? (ninterior - ib0) : RB);
+  const int t = threadIdx.x;
+
+  if constexpr (PACK) {
+    if (t < nhere) {
+      size_t i = interior_site(kp, ib0 + t);
+      static_for<0, NVEL>([&](auto P) {
+	tile[t*(NVEL + 1) + P] = f[ns*P + i];
+      });
+    }
+    __syncthreads();
+    for (int k = t; k < nhere*NVEL; k += RB) {
+      int site = k / NVEL;
+      int p = k - site*NVEL;
+      rec[ib0*NVEL + k] = tile[site*(NVEL + 1) + p];
+    }
+  }
+  else {
+    for (int k = t; k < nhere*NVEL; k += RB) {
+      int site = k / NVEL;
+      int p = k - site*NVEL;
+      tile[site*(NVEL + 1) + p] = rec[ib0*NVEL + k];
+    }
+    __syncthreads();
+    if (t < nhere) {
+      size_t i = interior_site(kp, ib0 + t);
+      static_for<0, NVEL>([&](auto P) {
+	f[ns*P + i] = tile[t*(NVEL + 1) + P];
+      });
+    }
+  }
+}
+
+/* hydro_field_set (hydro.c:279-330: hydro_u_zero, hydro_f_zero): every site,
+ * halo included, of an SoA field of ncomp components gets a constant */
+
+__global__ __launch_bounds__(BLOCK)
+void k_field_set(long long nsite, int ncomp, double * __restrict__ field,
+		 double v0, double v1, double v2) {
+  long long i = (long long) blockIdx.x*BLOCK + threadIdx.x;
+  if (i >= nsite) return;
+  field[i] = v0;
+  if (ncomp > 1) field[nsite + i] = v1;
+  if (ncomp > 2) field[2*nsite + i] = v2;
+}
+
 /* ---- moments ----------------------------------------------------------------
  *
  * Per interior fluid site: rho = sum_p f_p in p order (lb_0th_moment,
@@ -1474,6 +1553,36 @@ extern "C" int lbmi_k_halo_unpack_x(const lbmi_kparam_t * kp,
   dim3 grid((kp->strx + BLOCK - 1)/BLOCK, ncomp), block(BLOCK);
   hipLaunchKernelGGL(k_halo_unpack_x, grid, block, 0, st, *kp, *sel, data,
 		     buf_lo, buf_hi);
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_records(const lbmi_kparam_t * kp, double * f,
+			      double * rec, int pack, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  long long nint = (long long) kp->nlocal[0]*kp->nlocal[1]*kp->nlocal[2];
+  dim3 grid((unsigned) ((nint + RB - 1)/RB)), block(RB);
+  if (kp->nvel == 19) {
+    if (pack) hipLaunchKernelGGL((k_records<19, true>), grid, block, 0, st, *kp, f, rec, nint);
+    else hipLaunchKernelGGL((k_records<19, false>), grid, block, 0, st, *kp, f, rec, nint);
+  }
+  else if (kp->nvel == 27) {
+    if (pack) hipLaunchKernelGGL((k_records<27, true>), grid, block, 0, st, *kp, f, rec, nint);
+    else hipLaunchKernelGGL((k_records<27, false>), grid, block, 0, st, *kp, f, rec, nint);
+  }
+  else {
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_field_set(const lbmi_kparam_t * kp, int ncomp,
+				double * field, const double * v,
+				void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  if (ncomp < 1 || ncomp > 3) return (int) hipErrorInvalidValue;
+  dim3 grid((unsigned) ((kp->nsite + BLOCK - 1)/BLOCK)), block(BLOCK);
+  hipLaunchKernelGGL(k_field_set, grid, block, 0, st, kp->nsite, ncomp, field,
+		     v[0], (ncomp > 1) ? v[1] : 0.0, (ncomp > 2) ? v[2] : 0.0);
   return (int) hipGetLastError();
 }
 

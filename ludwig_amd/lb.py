@@ -235,6 +235,36 @@ class LB:
         _l.check(self._lib.lbmi_moments(self._h, _ptr(f), _ptr(status), out))
         return np.array(out[:])
 
+    # -- rows "next": hydro housekeeping, record stream ----------------------
+
+    def hydro_field_set(self, field, values):
+        """hydro_u_zero / hydro_f_zero (hydro.c:279-330) on a device field."""
+        ncomp = 1 if field.dim() == 3 else field.shape[0]
+        a = (ctypes.c_double * 3)(*([float(v) for v in values] + [0.0] * 3)[:3])
+        _l.check(self._lib.lbmi_hydro_field_set(self._h, _ptr(field), ncomp, a))
+
+    def lb_io_aggr_pack(self):
+        """lb_io_aggr_pack (model.c:1479): the binary record stream as a
+        host array (nx, ny, nz, nvel)."""
+        torch = _torch()
+        rec = torch.empty(self.nlocal + (self.nvel,), dtype=torch.float64,
+                          device=self.device)
+        torch.cuda.synchronize(self.device)
+        _l.check(self._lib.lbmi_lb_records_pack(self._h, _ptr(rec)))
+        self.synchronize()
+        return rec.cpu().numpy()
+
+    def lb_io_aggr_unpack(self, records):
+        """lb_io_aggr_unpack (model.c:1520): restore the interior of f from
+        a record stream."""
+        torch = _torch()
+        rec = torch.from_numpy(np.ascontiguousarray(records, dtype=np.float64))
+        assert tuple(rec.shape) == self.nlocal + (self.nvel,)
+        rec = rec.to(self.device)
+        torch.cuda.synchronize(self.device)
+        _l.check(self._lib.lbmi_lb_records_unpack(self._h, _ptr(rec)))
+        self.synchronize()
+
     # -- streams, timing, communicator -------------------------------------
 
     def synchronize(self):

@@ -74,6 +74,9 @@ SYMBOLS = [
     ("lbmi_lb_memcpy_h2d", _i, [_vp, _vp]),
     ("lbmi_lb_memcpy_d2h", _i, [_vp, _vp]),
     ("lbmi_lb_moments", _i, [_vp, _vp, _pd]),
+    ("lbmi_hydro_field_set", _i, [_vp, _vp, _i, _pd]),
+    ("lbmi_lb_records_pack", _i, [_vp, _vp]),
+    ("lbmi_lb_records_unpack", _i, [_vp, _vp]),
     ("lbmi_synchronize", _i, [_vp]),
     ("lbmi_stream", _i, [_vp, ctypes.POINTER(_vp)]),
     ("lbmi_timing", _i, [_vp, _i]),

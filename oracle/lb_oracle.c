@@ -634,3 +634,53 @@ int lbo_init_synthetic(const lbo_param_t * p, const int ntotal[3],
 
   return 0;
 }
+
+/*
+ * lbo_records_pack / lbo_records_unpack
+ *
+ * The binary record stream of the distribution files: lb_io_aggr_pack with
+ * lb_write_buf (model.c:1385-1402, 1479-1510) -- one record of nvel doubles
+ * in p order per INTERIOR site, sites in (ic, jc, kc) order, independent of
+ * the memory order -- and its inverse lb_io_aggr_unpack / lb_read_buf
+ * (model.c:1412-1430, 1520-1550). ndist = 1.
+ */
+
+int lbo_records_pack(const lbo_param_t * p, const double * f, double * rec) {
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+  ptrdiff_t ib = 0;
+  for (int ic = 1; ic <= p->nlocal[X]; ic++) {
+    for (int jc = 1; jc <= p->nlocal[Y]; jc++) {
+      for (int kc = 1; kc <= p->nlocal[Z]; kc++) {
+	ptrdiff_t index = str[X]*(p->nhalo + ic - 1)
+	  + str[Y]*(p->nhalo + jc - 1) + (p->nhalo + kc - 1);
+	for (int q = 0; q < p->nvel; q++) rec[ib*p->nvel + q] = f[nsite*q + index];
+	ib += 1;
+      }
+    }
+  }
+  return 0;
+}
+
+int lbo_records_unpack(const lbo_param_t * p, double * f, const double * rec) {
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+  ptrdiff_t ib = 0;
+  for (int ic = 1; ic <= p->nlocal[X]; ic++) {
+    for (int jc = 1; jc <= p->nlocal[Y]; jc++) {
+      for (int kc = 1; kc <= p->nlocal[Z]; kc++) {
+	ptrdiff_t index = str[X]*(p->nhalo + ic - 1)
+	  + str[Y]*(p->nhalo + jc - 1) + (p->nhalo + kc - 1);
+	for (int q = 0; q < p->nvel; q++) f[nsite*q + index] = rec[ib*p->nvel + q];
+	ib += 1;
+      }
+    }
+  }
+  return 0;
+}

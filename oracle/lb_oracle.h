@@ -60,6 +60,8 @@ int lbo_moments(const lbo_param_t * p, const double * f, const char * status,
 		double out[9]);
 int lbo_init_synthetic(const lbo_param_t * p, const int ntotal[3],
 		       const int noffset[3], double * f);
+int lbo_records_pack(const lbo_param_t * p, const double * f, double * rec);
+int lbo_records_unpack(const lbo_param_t * p, double * f, const double * rec);
 int lbo_equilibrium(const lbo_model_t * m, double rho, const double u[3],
 		    double * feq);
 

@@ -70,6 +70,8 @@ def lib():
         _lib.lbo_propagate.argtypes = [pp, dp, dp]
         _lib.lbo_moments.argtypes = [pp, dp, dp, dp]
         _lib.lbo_init_synthetic.argtypes = [pp, dp, dp, dp]
+        _lib.lbo_records_pack.argtypes = [pp, dp, dp]
+        _lib.lbo_records_unpack.argtypes = [pp, dp, dp]
     return _lib
 
 
@@ -153,6 +155,20 @@ def moments(p, f, status=None):
     rc = lib().lbo_moments(ctypes.byref(p), _ptr(f), _ptr(status), _ptr(out))
     assert rc == 0
     return out
+
+
+def records_pack(p, f):
+    """lb_io_aggr_pack (binary): (nx, ny, nz, nvel) record stream."""
+    rec = np.zeros(tuple(p.nlocal) + (p.nvel,))
+    rc = lib().lbo_records_pack(ctypes.byref(p), _ptr(f), _ptr(rec))
+    assert rc == 0
+    return rec
+
+
+def records_unpack(p, f, rec):
+    rec = np.ascontiguousarray(rec, dtype=np.float64)
+    rc = lib().lbo_records_unpack(ctypes.byref(p), _ptr(f), _ptr(rec))
+    assert rc == 0
 
 
 def init_synthetic(p, ntotal=None, noffset=(0, 0, 0)):

@@ -14,7 +14,8 @@ under /root/reference. Arrays are raw float64 in the reference's SoA order,
 shape (nvel, nall_x, nall_y, nall_z) (hydro fields: (3, ...) or (...)).
 
 Keys: meta (JSON string), f0, force, f_collide, rho, u, f_prop, f_final and,
-for some cases, f_halo.
+for some cases, f_halo and records (the binary per-site record stream of
+lb_io_aggr_pack / lb_write_buf for f_final, shape (nx, ny, nz, nvel)).
 """
 
 import json
@@ -72,6 +73,8 @@ def run_case(case, tmp):
     out["u"] = load("u", (3,))
     if keep_halo:
         out["f_halo"] = load("f_halo", (nvel,))
+        rec = np.fromfile("%s.records.f64" % prefix, dtype="<f8")
+        out["records"] = rec.reshape(tuple(meta["nlocal"]) + (nvel,))
     out["f_prop"] = load("f_prop", (nvel,))
     out["f_final"] = load("f_final", (nvel,))
     return out

@@ -278,6 +278,29 @@ int main(int argc, char ** argv) {
       }
       dump(prefix, "f_final", lb->f, nf);
       {
+	/* The on-disk record stream of lb_io_aggr_pack (model.c:1479-1510):
+	 * lb_write_buf for every interior site in (ic, jc, kc) order */
+	int nlocal[3];
+	size_t nrec;
+	size_t szrec = (size_t) lb->model.nvel*sizeof(double);
+	char * buf = NULL;
+	size_t ib = 0;
+	cs_nlocal(cs, nlocal);
+	nrec = (size_t) nlocal[X]*nlocal[Y]*nlocal[Z];
+	buf = (char *) malloc(nrec*szrec);
+	assert(buf);
+	for (int ic = 1; ic <= nlocal[X]; ic++) {
+	  for (int jc = 1; jc <= nlocal[Y]; jc++) {
+	    for (int kc = 1; kc <= nlocal[Z]; kc++) {
+	      lb_write_buf(lb, cs_index(cs, ic, jc, kc), buf + ib*szrec);
+	      ib += 1;
+	    }
+	  }
+	}
+	dump(prefix, "records", (const double *) buf, nrec*lb->model.nvel);
+	free(buf);
+      }
+      {
 	/* Header: everything a reader needs; consumed by make_golden.py */
 	char fn[1024];
 	FILE * fp = NULL;

@@ -120,3 +120,20 @@ def test_trt_d3q27_rejected():
     f = lbo.init_synthetic(p)
     with pytest.raises(ValueError):
         lbo.collide(p, f)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names()
+                                  if "records" in load_golden(n)])
+def test_record_stream(name):
+    # lb_io_aggr_pack / lb_write_buf, model.c:1385-1510
+    g = load_golden(name)
+    p = param_from_meta(g["meta"])
+    f = np.ascontiguousarray(np.nan_to_num(g["f_final"]))
+    rec = lbo.records_pack(p, f)
+    assert np.array_equal(rec, g["records"])
+    f2 = np.zeros_like(f)
+    lbo.records_unpack(p, f2, rec)
+    h = g["meta"]["nhalo"]
+    assert np.array_equal(interior(f2, h), interior(f, h))
+    # halo sites untouched
+    assert np.count_nonzero(f2) == np.count_nonzero(interior(f2, h))
