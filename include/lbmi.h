@@ -234,6 +234,28 @@ int lbmi_lb_moments(lbmi_t * lb, const char * status, double out[9]);
 int lbmi_hydro_field_set(lbmi_t * lb, double * field, int ncomp,
 			 const double * values);
 
+/* field_halo (field.c:field_halo -> halo_swap_packed) for an SoA field of
+ * nel components whose halo swap is nswap layers wide (phi with the
+ * symmetric free energy: 2). Single rank. */
+int lbmi_field_halo_n(lbmi_t * lb, int nel, int nswap, double * data);
+
+/* field_grad_compute with grad_3d_7pt_fluid_d2 (gradient_3d_7pt_fluid.c:
+ * 232-320): grad (3*nsite, SoA) and delsq (nsite) of the scalar phi for
+ * the interior and nhalo-1 layers around it. phi needs a valid halo. */
+int lbmi_field_grad_7pt(lbmi_t * lb, const double * phi, double * grad,
+			double * delsq);
+
+/* phi_force_calculation for the symmetric free energy with the stress-
+ * divergence method and no walls (phi_force.c:100-108 = pth_stress_compute
+ * + pth_force_fluid_driver; stress symmetric.c:371-420): F_a = -d_b P_ab is
+ * ADDED to force (hydro->force, 3*nsite) at the interior sites. With grad
+ * and delsq given they are used as the reference uses them; with both NULL
+ * the force is evaluated straight from phi (needs nhalo >= 2 and a valid
+ * 2-layer halo of phi) and no gradient arrays are needed at all. */
+int lbmi_symmetric_force(lbmi_t * lb, double a, double b, double kappa,
+			 const double * phi, const double * grad,
+			 const double * delsq, double * force);
+
 /* The on-disk record stream of the distribution files, lb_io_aggr_pack /
  * lb_io_aggr_unpack with lb_write_buf / lb_read_buf (model.c:1385-1430,
  * 1479-1550): nvel doubles in p order per interior site, sites in

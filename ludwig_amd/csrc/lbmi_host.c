@@ -667,10 +667,10 @@ static int lbmi_halo_generic(lbmi_t * lb, const lbmi_halo_sel_t sel[3],
     if (ifail) return ifail;
   }
   else {
-    KCHECK(lbmi_k_halo_copy(&lb->kp, X, &sel[X], data, st));
+    KCHECK(lbmi_k_halo_copy(&lb->kp, X, &sel[X], data, 1, st));
   }
-  KCHECK(lbmi_k_halo_copy(&lb->kp, Y, &sel[Y], data, st));
-  KCHECK(lbmi_k_halo_copy(&lb->kp, Z, &sel[Z], data, st));
+  KCHECK(lbmi_k_halo_copy(&lb->kp, Y, &sel[Y], data, 1, st));
+  KCHECK(lbmi_k_halo_copy(&lb->kp, Z, &sel[Z], data, 1, st));
   return 0;
 }
 
@@ -732,8 +732,8 @@ int lbmi_halo_yz(lbmi_t * lb, double * f, int scheme) {
   sel = lbmi_sel(lb, scheme);
   if (sel == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
   HIPCHECK(hipSetDevice(lb->device));
-  KCHECK(lbmi_k_halo_copy(&lb->kp, Y, &sel[Y], f, lb->stream));
-  KCHECK(lbmi_k_halo_copy(&lb->kp, Z, &sel[Z], f, lb->stream));
+  KCHECK(lbmi_k_halo_copy(&lb->kp, Y, &sel[Y], f, 1, lb->stream));
+  KCHECK(lbmi_k_halo_copy(&lb->kp, Z, &sel[Z], f, 1, lb->stream));
   return 0;
 }
 
@@ -1145,6 +1145,74 @@ int lbmi_hydro_field_set(lbmi_t * lb, double * field, int ncomp,
   }
   HIPCHECK(hipSetDevice(lb->device));
   KCHECK(lbmi_k_field_set(&lb->kp, ncomp, field, values, lb->stream));
+  return 0;
+}
+
+/* field_halo (field.c) for an SoA field of nel components with a halo swap
+ * of nswap layers (single rank; halo_swap_packed, halo_swap.c:709) */
+
+int lbmi_field_halo_n(lbmi_t * lb, int nel, int nswap, double * data) {
+  lbmi_halo_sel_t sel;
+  if (lb == NULL || data == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (nel < 1 || nel > LBMI_NVEL_MAX) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "nel = %d (1..%d)", nel, LBMI_NVEL_MAX);
+  }
+  if (nswap < 1 || nswap > lb->kp.nhalo) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "nswap = %d (1..nhalo = %d)", nswap,
+		     lb->kp.nhalo);
+  }
+  if (lb->opts.cartsz > 1) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "lbmi_field_halo_n: single rank "
+		     "only (use lbmi_field_halo for width 1 with slabs)");
+  }
+  for (int d = 0; d < 3; d++) {
+    if (nswap > lb->kp.nlocal[d]) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "nswap exceeds nlocal[%d]", d);
+    }
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  memset(&sel, 0, sizeof(sel));
+  for (int n = 0; n < nel; n++) {
+    sel.lo[sel.nlo++] = (int8_t) n;
+    sel.hi[sel.nhi++] = (int8_t) n;
+  }
+  KCHECK(lbmi_k_halo_copy(&lb->kp, X, &sel, data, nswap, lb->stream));
+  KCHECK(lbmi_k_halo_copy(&lb->kp, Y, &sel, data, nswap, lb->stream));
+  KCHECK(lbmi_k_halo_copy(&lb->kp, Z, &sel, data, nswap, lb->stream));
+  return 0;
+}
+
+/* field_grad_compute with grad_3d_7pt_fluid_d2 (gradient_3d_7pt_fluid.c) */
+
+int lbmi_field_grad_7pt(lbmi_t * lb, const double * phi, double * grad,
+			double * delsq) {
+  if (lb == NULL || !phi || !grad || !delsq) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->kp.nhalo < 2) {
+    /* the reference computes nextra = nhalo - 1 >= 0 layers beyond the
+     * interior and reads one further: it needs the halo to exist */
+    if (lb->kp.nhalo < 1) return lbmi_fail(LBMI_ERR_ARGUMENT, "nhalo < 1");
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_grad_7pt(&lb->kp, phi, grad, delsq, lb->stream));
+  return 0;
+}
+
+/* phi_force_calculation for the symmetric free energy and
+ * FE_FORCE_METHOD_STRESS_DIVERGENCE without walls (phi_force.c:100-108) */
+
+int lbmi_symmetric_force(lbmi_t * lb, double a, double b, double kappa,
+			 const double * phi, const double * grad,
+			 const double * delsq, double * force) {
+  if (lb == NULL || !phi || !force) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if ((grad == NULL) != (delsq == NULL)) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "grad and delsq: both or neither");
+  }
+  if (grad == NULL && lb->kp.nhalo < 2) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "force from phi needs nhalo >= 2");
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_symm_force(&lb->kp, a, b, kappa, phi, grad, delsq, force,
+			   lb->stream));
   return 0;
 }
 

@@ -87,7 +87,7 @@ int lbmi_k_unpropagate_wrap(const lbmi_kparam_t * kp, const double * f,
 /* In-place periodic halo copy for direction dir on an SoA field with
  * components of stride nsite. */
 int lbmi_k_halo_copy(const lbmi_kparam_t * kp, int dir,
-		     const lbmi_halo_sel_t * sel, double * data,
+		     const lbmi_halo_sel_t * sel, double * data, int nswap,
 		     void * stream);
 
 /* X direction through buffers (multi-GPU): pack the first interior plane
@@ -109,6 +109,14 @@ int lbmi_k_records(const lbmi_kparam_t * kp, double * f, double * rec,
 /* hydro_field_set: all nsite sites of ncomp (1..3) components := v[] */
 int lbmi_k_field_set(const lbmi_kparam_t * kp, int ncomp, double * field,
 		     const double * v, void * stream);
+
+/* Symmetric free energy (row f2): 7-point gradients; thermodynamic force by
+ * stress divergence, from grad/delsq arrays or (grad == NULL) from phi */
+int lbmi_k_grad_7pt(const lbmi_kparam_t * kp, const double * phi,
+		    double * grad, double * delsq, void * stream);
+int lbmi_k_symm_force(const lbmi_kparam_t * kp, double a, double b,
+		      double kappa, const double * phi, const double * grad,
+		      const double * delsq, double * force, void * stream);
 
 /* Moments: partial (nblk x 12 doubles workspace) then final (out_dev[9]) */
 int lbmi_k_moments_nblk(void);

@@ -906,17 +906,18 @@ void k_halo_copy(lbmi_kparam_t kp, int dir, lbmi_halo_sel_t sel,
   if (j >= plane_size(kp, dir)) return;
 
   int k = blockIdx.y;
+  const int w = blockIdx.z;                /* halo layer 0 .. nswap-1 */
   const int nh = kp.nhalo;
   int comp, src, dst;
   if (k < sel.nlo) {
     comp = sel.lo[k];                      /* low halo <- last interior */
-    src = nh + kp.nlocal[dir] - 1;
-    dst = nh - 1;
+    src = nh + kp.nlocal[dir] - 1 - w;
+    dst = nh - 1 - w;
   }
   else {
     comp = sel.hi[k - sel.nlo];            /* high halo <- first interior */
-    src = nh;
-    dst = nh + kp.nlocal[dir];
+    src = nh + w;
+    dst = nh + kp.nlocal[dir] + w;
   }
   double * d = data + (size_t) kp.nsite*comp;
   d[plane_site(kp, dir, j, dst)] = d[plane_site(kp, dir, j, src)];
@@ -1051,6 +1052,118 @@ void k_field_set(long long nsite, int ncomp, double * __restrict__ field,
   field[i] = v0;
   if (ncomp > 1) field[nsite + i] = v1;
   if (ncomp > 2) field[2*nsite + i] = v2;
+}
+
+/* ---- symmetric free energy: gradients and thermodynamic force (row f2) -----
+ *
+ * k_grad_7pt: grad_3d_7pt_fluid_d2 (gradient_3d_7pt_fluid.c:232-320):
+ *   grad_a = (phi(+e_a) - phi(-e_a))/2, delsq = 7-point Laplacian, for the
+ *   sites 1-nextra .. nlocal+nextra (nextra = nhalo - 1).
+ * k_symm_force<FROM_GRAD>: pth_stress_compute with fe_symm_str_v
+ *   (phi_force_stress.c:171-300, symmetric.c:371-420) followed by
+ *   pth_force_fluid_kernel_v (phi_force_colloid.c:324-480):
+ *     P_ab = p0 d_ab + kappa d_a phi d_b phi,
+ *     p0   = a phi^2/2 + 3 b phi^4/4 - kappa phi delsq - kappa |grad|^2/2,
+ *     F_a -= sum_b [ (P_ab(+e_b) + P_ab)/2 - (P_ab(-e_b) + P_ab)/2 ],
+ *   added to hydro->force at the interior sites.
+ *   FROM_GRAD = true reads the grad/delsq arrays (drop-in for the reference's
+ *   two stages without its 9-component stress array: 72 B/site never
+ *   written or re-read); FROM_GRAD = false is the MI355X-native form: the
+ *   force straight from phi (a 25-point stencil; phi is 137 MB at 256^3
+ *   and lives in L2/Infinity Cache, so HBM sees 8 B read + 48 B RMW per
+ *   site instead of ~270 B in the reference's three kernels).
+ */
+
+struct Symm { double a, b, kappa; };
+
+__device__ __forceinline__
+void symm_stress(const Symm & q, double phi, const double (&g)[3],
+		 double delsq, double (&s)[3][3]) {
+  double p0 = 0.5*q.a*phi*phi + 0.75*q.b*phi*phi*phi*phi - q.kappa*phi*delsq
+    - 0.5*q.kappa*(g[0]*g[0] + g[1]*g[1] + g[2]*g[2]);
+  for (int ia = 0; ia < 3; ia++) {
+    for (int ib = 0; ib < 3; ib++) {
+      s[ia][ib] = ((ia == ib) ? p0 : 0.0) + q.kappa*g[ia]*g[ib];
+    }
+  }
+}
+
+__device__ __forceinline__
+void grad7(const double * __restrict__ phi, size_t j, int strx, int stry,
+	   double (&g)[3], double & delsq) {
+  double xp = phi[j + strx], xm = phi[j - strx];
+  double yp = phi[j + stry], ym = phi[j - stry];
+  double zp = phi[j + 1], zm = phi[j - 1];
+  g[0] = 0.5*(xp - xm);
+  g[1] = 0.5*(yp - ym);
+  g[2] = 0.5*(zp - zm);
+  delsq = xp + xm + yp + ym + zp + zm - 6.0*phi[j];
+}
+
+__global__ __launch_bounds__(BLOCK)
+void k_grad_7pt(lbmi_kparam_t kp, const double * __restrict__ phi,
+		double * __restrict__ grad, double * __restrict__ delsq,
+		int i0, int i1) {
+  int i = i0 + (int) (blockIdx.x*BLOCK + threadIdx.x);
+  if (i >= i1) return;
+  Site s = decode(kp, i);
+  const int ne = kp.nhalo - 1;
+  const int nh = kp.nhalo;
+  if (s.y < nh - ne || s.y >= nh + kp.nlocal[1] + ne) return;
+  if (s.z < nh - ne || s.z >= nh + kp.nlocal[2] + ne) return;
+  const size_t ns = (size_t) kp.nsite;
+  double g[3], d2;
+  grad7(phi, (size_t) i, kp.strx, kp.stry, g, d2);
+  grad[i] = g[0];
+  grad[ns + i] = g[1];
+  grad[2*ns + i] = g[2];
+  delsq[i] = d2;
+}
+
+template <bool FROM_GRAD>
+__global__ __launch_bounds__(BLOCK)
+void k_symm_force(lbmi_kparam_t kp, Symm q, const double * __restrict__ phi,
+		  const double * __restrict__ grad,
+		  const double * __restrict__ delsq,
+		  double * __restrict__ force, int i0, int i1, unsigned nblk) {
+
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+  Site s = decode(kp, i);
+  if (!s.interior) return;
+
+  const size_t ns = (size_t) kp.nsite;
+  const int str[3] = {kp.strx, kp.stry, 1};
+
+  auto stress_at = [&](size_t j, double (&st)[3][3]) {
+    double g[3], d2;
+    if constexpr (FROM_GRAD) {
+      g[0] = grad[j]; g[1] = grad[ns + j]; g[2] = grad[2*ns + j];
+      d2 = delsq[j];
+    }
+    else {
+      grad7(phi, j, kp.strx, kp.stry, g, d2);
+    }
+    symm_stress(q, phi[j], g, d2, st);
+  };
+
+  double pth0[3][3], pth1[3][3];
+  double f[3] = {0.0, 0.0, 0.0};
+  stress_at((size_t) i, pth0);
+
+  static_for<0, 3>([&](auto D) {
+    constexpr int id = D;
+    stress_at((size_t) (i + str[id]), pth1);
+    for (int ia = 0; ia < 3; ia++) f[ia] -= 0.5*(pth1[ia][id] + pth0[ia][id]);
+    stress_at((size_t) (i - str[id]), pth1);
+    for (int ia = 0; ia < 3; ia++) f[ia] += 0.5*(pth1[ia][id] + pth0[ia][id]);
+  });
+
+  force[i] += f[0];
+  force[ns + i] += f[1];
+  force[2*ns + i] += f[2];
 }
 
 /* ---- moments ----------------------------------------------------------------
@@ -1519,13 +1632,16 @@ extern "C" int lbmi_k_unpropagate_wrap(const lbmi_kparam_t * kp,
 
 extern "C" int lbmi_k_halo_copy(const lbmi_kparam_t * kp, int dir,
 				const lbmi_halo_sel_t * sel, double * data,
-				void * stream) {
+				int nswap, void * stream) {
   hipStream_t st = (hipStream_t) stream;
   int psz = (dir == 0) ? kp->nall[1]*kp->nall[2]
     : ((dir == 1) ? kp->nall[0]*kp->nall[2] : kp->nall[0]*kp->nall[1]);
   int ncomp = sel->nlo + sel->nhi;
   if (ncomp == 0) return 0;
-  dim3 grid((psz + BLOCK - 1)/BLOCK, ncomp), block(BLOCK);
+  if (nswap < 1 || nswap > kp->nhalo || nswap > kp->nlocal[dir]) {
+    return (int) hipErrorInvalidValue;
+  }
+  dim3 grid((psz + BLOCK - 1)/BLOCK, ncomp, nswap), block(BLOCK);
   hipLaunchKernelGGL(k_halo_copy, grid, block, 0, st, *kp, dir, *sel, data);
   return (int) hipGetLastError();
 }
@@ -1583,6 +1699,37 @@ extern "C" int lbmi_k_field_set(const lbmi_kparam_t * kp, int ncomp,
   dim3 grid((unsigned) ((kp->nsite + BLOCK - 1)/BLOCK)), block(BLOCK);
   hipLaunchKernelGGL(k_field_set, grid, block, 0, st, kp->nsite, ncomp, field,
 		     v[0], (ncomp > 1) ? v[1] : 0.0, (ncomp > 2) ? v[2] : 0.0);
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_grad_7pt(const lbmi_kparam_t * kp, const double * phi,
+			       double * grad, double * delsq, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  int ne = kp->nhalo - 1;
+  int i0 = (kp->nhalo - ne)*kp->strx;
+  int i1 = (kp->nhalo + kp->nlocal[0] + ne)*kp->strx;
+  dim3 grid((unsigned) ((i1 - i0 + BLOCK - 1)/BLOCK)), block(BLOCK);
+  hipLaunchKernelGGL(k_grad_7pt, grid, block, 0, st, *kp, phi, grad, delsq,
+		     i0, i1);
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_symm_force(const lbmi_kparam_t * kp, double a, double b,
+				 double kappa, const double * phi,
+				 const double * grad, const double * delsq,
+				 double * force, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  Range1D r = interior_range(*kp);
+  dim3 grid(r.grid), block(BLOCK);
+  Symm q = {a, b, kappa};
+  if (grad && delsq) {
+    hipLaunchKernelGGL((k_symm_force<true>), grid, block, 0, st, *kp, q, phi,
+		       grad, delsq, force, r.i0, r.i1, r.nblk);
+  }
+  else {
+    hipLaunchKernelGGL((k_symm_force<false>), grid, block, 0, st, *kp, q, phi,
+		       grad, delsq, force, r.i0, r.i1, r.nblk);
+  }
   return (int) hipGetLastError();
 }
 

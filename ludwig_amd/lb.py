@@ -243,6 +243,22 @@ class LB:
         a = (ctypes.c_double * 3)(*([float(v) for v in values] + [0.0] * 3)[:3])
         _l.check(self._lib.lbmi_hydro_field_set(self._h, _ptr(field), ncomp, a))
 
+    def field_halo_n(self, data, nswap):
+        """field_halo with a swap of nswap layers (phi: 2)."""
+        nel = 1 if data.dim() == 3 else data.shape[0]
+        _l.check(self._lib.lbmi_field_halo_n(self._h, nel, nswap, _ptr(data)))
+
+    def field_grad_7pt(self, phi, grad, delsq):
+        """field_grad_compute (grad_3d_7pt_fluid)."""
+        _l.check(self._lib.lbmi_field_grad_7pt(self._h, _ptr(phi), _ptr(grad),
+                                               _ptr(delsq)))
+
+    def symmetric_force(self, a, b, kappa, phi, force, grad=None, delsq=None):
+        """phi_force_calculation (symmetric, stress divergence): force += F."""
+        _l.check(self._lib.lbmi_symmetric_force(
+            self._h, a, b, kappa, _ptr(phi), _ptr(grad), _ptr(delsq),
+            _ptr(force)))
+
     def lb_io_aggr_pack(self):
         """lb_io_aggr_pack (model.c:1479): the binary record stream as a
         host array (nx, ny, nz, nvel)."""

@@ -75,6 +75,9 @@ SYMBOLS = [
     ("lbmi_lb_memcpy_d2h", _i, [_vp, _vp]),
     ("lbmi_lb_moments", _i, [_vp, _vp, _pd]),
     ("lbmi_hydro_field_set", _i, [_vp, _vp, _i, _pd]),
+    ("lbmi_field_halo_n", _i, [_vp, _i, _i, _vp]),
+    ("lbmi_field_grad_7pt", _i, [_vp, _vp, _vp, _vp]),
+    ("lbmi_symmetric_force", _i, [_vp, _d, _d, _d, _vp, _vp, _vp, _vp]),
     ("lbmi_lb_records_pack", _i, [_vp, _vp]),
     ("lbmi_lb_records_unpack", _i, [_vp, _vp]),
     ("lbmi_synchronize", _i, [_vp]),

@@ -369,13 +369,22 @@ int lbo_collide(const lbo_param_t * p, double * f, const double * force,
  */
 
 int lbo_halo(const lbo_param_t * p, int nel, double * data) {
-  return lbo_halo_dirs(p, nel, data, 7);
+  return lbo_halo_width(p, nel, data, 7, 1);
+}
+
+int lbo_halo_dirs(const lbo_param_t * p, int nel, double * data, int dirmask) {
+  return lbo_halo_width(p, nel, data, dirmask, 1);
 }
 
 /* dirmask: bit d set = run the pass for direction d (X = 1, Y = 2, Z = 4);
  * a slab-decomposed test does X through its own exchange and Y, Z here. */
 
-int lbo_halo_dirs(const lbo_param_t * p, int nel, double * data, int dirmask) {
+/* nswap: number of halo layers exchanged (halo_swap_create's nhcomm:
+ * 1 for the distributions, model.c:431-440; the field's own halo width for
+ * field_halo, e.g. 2 for phi with the symmetric free energy). */
+
+int lbo_halo_width(const lbo_param_t * p, int nel, double * data, int dirmask,
+		   int nswap) {
 
   int nall[3];
   ptrdiff_t str[3];
@@ -390,10 +399,11 @@ int lbo_halo_dirs(const lbo_param_t * p, int nel, double * data, int dirmask) {
     int d1 = (id + 1) % 3;
     int d2 = (id + 2) % 3;
     /* plane coordinates (0-based, in nall): source lo/hi, destination */
-    int src_lo = nh;                      /* first interior plane */
-    int src_hi = nh + p->nlocal[id] - 1;  /* last interior plane */
-    int dst_lo = nh - 1;                  /* halo plane below */
-    int dst_hi = nh + p->nlocal[id];      /* halo plane above */
+    for (int w = 0; w < nswap; w++) {
+    int src_lo = nh + w;                      /* w-th interior plane */
+    int src_hi = nh + p->nlocal[id] - 1 - w;  /* w-th from the top */
+    int dst_lo = nh - 1 - w;                  /* halo plane below */
+    int dst_hi = nh + p->nlocal[id] + w;      /* halo plane above */
     {
     #pragma omp parallel for schedule(static)
     for (int n = 0; n < nel; n++) {
@@ -405,6 +415,7 @@ int lbo_halo_dirs(const lbo_param_t * p, int nel, double * data, int dirmask) {
 	  d[off + str[id]*dst_hi] = d[off + str[id]*src_lo];
 	}
       }
+    }
     }
     }
   }
@@ -682,5 +693,115 @@ int lbo_records_unpack(const lbo_param_t * p, double * f, const double * rec) {
       }
     }
   }
+  return 0;
+}
+
+/*
+ * lbo_grad_7pt
+ *
+ * grad_3d_7pt_fluid_d2 (gradient_3d_7pt_fluid.c:232-320, no Lees-Edwards
+ * planes): central differences grad_a = (phi(+e_a) - phi(-e_a))/2 and the
+ * 7-point Laplacian, for the sites 1-nextra .. nlocal+nextra in every
+ * direction (nextra = nhalo - 1). grad: 3*nsite (SoA, component slowest),
+ * delsq: nsite. Summation order of the Laplacian as the reference:
+ * +x -x +y -y +z -z then -6 phi.
+ */
+
+int lbo_grad_7pt(const lbo_param_t * p, const double * phi, double * grad,
+		 double * delsq) {
+
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+  int nextra = p->nhalo - 1;
+
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+
+  for (int ic = 1 - nextra; ic <= p->nlocal[X] + nextra; ic++) {
+    for (int jc = 1 - nextra; jc <= p->nlocal[Y] + nextra; jc++) {
+      for (int kc = 1 - nextra; kc <= p->nlocal[Z] + nextra; kc++) {
+	ptrdiff_t i = str[X]*(p->nhalo + ic - 1)
+	  + str[Y]*(p->nhalo + jc - 1) + (p->nhalo + kc - 1);
+	grad[0*nsite + i] = 0.5*(phi[i + str[X]] - phi[i - str[X]]);
+	grad[1*nsite + i] = 0.5*(phi[i + str[Y]] - phi[i - str[Y]]);
+	grad[2*nsite + i] = 0.5*(phi[i + 1] - phi[i - 1]);
+	delsq[i] = phi[i + str[X]] + phi[i - str[X]]
+	  + phi[i + str[Y]] + phi[i - str[Y]]
+	  + phi[i + 1] + phi[i - 1]
+	  - 6.0*phi[i];
+      }
+    }
+  }
+
+  return 0;
+}
+
+/*
+ * lbo_symm_force
+ *
+ * Thermodynamic force of the symmetric free energy by stress divergence:
+ * pth_stress_compute with fe_symm_str_v (phi_force_stress.c:171-300,
+ * symmetric.c:371-420) for the sites 0 .. nlocal+1, then
+ * pth_force_fluid_kernel_v (phi_force_colloid.c:324-480):
+ *   P_ab = p0 delta_ab + kappa d_a phi d_b phi,
+ *   p0 = a phi^2/2 + 3 b phi^4/4 - kappa phi delsq - kappa |grad phi|^2/2,
+ *   F_a = - sum_b [ (P_ab(+e_b) + P_ab)/2 - (P_ab(-e_b) + P_ab)/2 ],
+ * accumulated in the reference's order (+x, -x, +y, -y, +z, -z), and ADDED
+ * to force (3*nsite) at the interior sites.
+ */
+
+static void symm_stress(double a, double b, double kappa, double phi,
+			const double g[3], double delsq, double s[3][3]) {
+  double p0 = 0.5*a*phi*phi + 0.75*b*phi*phi*phi*phi - kappa*phi*delsq
+    - 0.5*kappa*(g[X]*g[X] + g[Y]*g[Y] + g[Z]*g[Z]);
+  for (int ia = 0; ia < 3; ia++) {
+    for (int ib = 0; ib < 3; ib++) {
+      s[ia][ib] = p0*(ia == ib) + kappa*g[ia]*g[ib];
+    }
+  }
+}
+
+int lbo_symm_force(const lbo_param_t * p, double a, double b, double kappa,
+		   const double * phi, const double * grad,
+		   const double * delsq, double * force) {
+
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+
+  for (int ic = 1; ic <= p->nlocal[X]; ic++) {
+    for (int jc = 1; jc <= p->nlocal[Y]; jc++) {
+      for (int kc = 1; kc <= p->nlocal[Z]; kc++) {
+	ptrdiff_t i = str[X]*(p->nhalo + ic - 1)
+	  + str[Y]*(p->nhalo + jc - 1) + (p->nhalo + kc - 1);
+	double pth0[3][3], pth1[3][3];
+	double f[3];
+	double g[3];
+
+	g[X] = grad[i]; g[Y] = grad[nsite + i]; g[Z] = grad[2*nsite + i];
+	symm_stress(a, b, kappa, phi[i], g, delsq[i], pth0);
+
+	for (int id = 0; id < 3; id++) {
+	  for (int sgn = +1; sgn >= -1; sgn -= 2) {
+	    ptrdiff_t j = i + sgn*str[id];
+	    g[X] = grad[j]; g[Y] = grad[nsite + j]; g[Z] = grad[2*nsite + j];
+	    symm_stress(a, b, kappa, phi[j], g, delsq[j], pth1);
+	    for (int ia = 0; ia < 3; ia++) {
+	      double face = 0.5*(pth1[ia][id] + pth0[ia][id]);
+	      if (id == 0 && sgn == +1) f[ia] = -face;
+	      else if (sgn == +1) f[ia] -= face;
+	      else f[ia] += face;
+	    }
+	  }
+	}
+	for (int ia = 0; ia < 3; ia++) force[nsite*ia + i] += f[ia];
+      }
+    }
+  }
+
   return 0;
 }

@@ -55,6 +55,13 @@ int lbo_collide(const lbo_param_t * p, double * f, const double * force,
 		const char * status, double * rho, double * u);
 int lbo_halo(const lbo_param_t * p, int nel, double * data);
 int lbo_halo_dirs(const lbo_param_t * p, int nel, double * data, int dirmask);
+int lbo_halo_width(const lbo_param_t * p, int nel, double * data, int dirmask,
+		   int nswap);
+int lbo_grad_7pt(const lbo_param_t * p, const double * phi, double * grad,
+		 double * delsq);
+int lbo_symm_force(const lbo_param_t * p, double a, double b, double kappa,
+		   const double * phi, const double * grad,
+		   const double * delsq, double * force);
 int lbo_propagate(const lbo_param_t * p, const double * f, double * fprime);
 int lbo_moments(const lbo_param_t * p, const double * f, const char * status,
 		double out[9]);

@@ -68,6 +68,11 @@ def lib():
         _lib.lbo_halo.argtypes = [pp, ctypes.c_int, dp]
         _lib.lbo_halo_dirs.argtypes = [pp, ctypes.c_int, dp, ctypes.c_int]
         _lib.lbo_propagate.argtypes = [pp, dp, dp]
+        _lib.lbo_halo_width.argtypes = [pp, ctypes.c_int, dp, ctypes.c_int,
+                                        ctypes.c_int]
+        _lib.lbo_grad_7pt.argtypes = [pp, dp, dp, dp]
+        _lib.lbo_symm_force.argtypes = [pp, ctypes.c_double, ctypes.c_double,
+                                        ctypes.c_double, dp, dp, dp, dp]
         _lib.lbo_moments.argtypes = [pp, dp, dp, dp]
         _lib.lbo_init_synthetic.argtypes = [pp, dp, dp, dp]
         _lib.lbo_records_pack.argtypes = [pp, dp, dp]
@@ -141,6 +146,28 @@ def halo_yz(p, data):
     """Only the local Y and Z passes (X comes from a neighbour rank)."""
     nel = data.shape[0]
     rc = lib().lbo_halo_dirs(ctypes.byref(p), nel, _ptr(data), 6)
+    assert rc == 0
+
+
+def field_halo(p, data, nswap):
+    """field_halo (field.c) = halo_swap_packed with nswap = the field's halo
+    width; data shape (nel, nall...) or (nall...)."""
+    nel = 1 if data.ndim == 3 else data.shape[0]
+    rc = lib().lbo_halo_width(ctypes.byref(p), nel, _ptr(data), 7, nswap)
+    assert rc == 0
+
+
+def grad_7pt(p, phi):
+    grad = np.zeros((3,) + phi.shape)
+    delsq = np.zeros(phi.shape)
+    rc = lib().lbo_grad_7pt(ctypes.byref(p), _ptr(phi), _ptr(grad), _ptr(delsq))
+    assert rc == 0
+    return grad, delsq
+
+
+def symm_force(p, a, b, kappa, phi, grad, delsq, force):
+    rc = lib().lbo_symm_force(ctypes.byref(p), a, b, kappa, _ptr(phi),
+                              _ptr(grad), _ptr(delsq), _ptr(force))
     assert rc == 0
 
 

@@ -80,11 +80,43 @@ def run_case(case, tmp):
     return out
 
 
+FE_CASES = [
+    ("fe_symm_a", (6, 5, 4), -0.0625, 0.0625, 0.04),
+    ("fe_symm_b", (5, 8, 7), -0.00625, 0.00625, 0.004),
+]
+
+
+def run_fe_case(case, tmp):
+    """Symmetric free-energy force chain (row f2): phi with its width-2 halo,
+    grad/delsq of grad_3d_7pt_fluid, force of pth_stress_compute +
+    pth_force_fluid_driver."""
+    name, n, a, b, kappa = case
+    exe = os.path.join(HERE, "_ref", "ref_driver_d3q19")
+    prefix = os.path.join(tmp, name)
+    subprocess.run([exe, "fe", prefix, *map(str, n), repr(a), repr(b),
+                    repr(kappa)], check=True)
+    meta = json.load(open(prefix + ".json"))
+    meta["name"] = name
+    nall = tuple(meta["nall"])
+
+    def load(key, lead):
+        return np.fromfile("%s.%s.f64" % (prefix, key), dtype="<f8").reshape(lead + nall)
+
+    return {"meta": np.array(json.dumps(meta)), "phi": load("phi", ()),
+            "grad": load("grad", (3,)), "delsq": load("delsq", ()),
+            "force": load("force", (3,))}
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
         for case in CASES:
             out = run_case(case, tmp)
+            fn = os.path.join(GOLD, case[0] + ".npz")
+            np.savez_compressed(fn, **out)
+            print("wrote", fn, os.path.getsize(fn))
+        for case in FE_CASES:
+            out = run_fe_case(case, tmp)
             fn = os.path.join(GOLD, case[0] + ".npz")
             np.savez_compressed(fn, **out)
             print("wrote", fn, os.path.getsize(fn))

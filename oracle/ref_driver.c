@@ -27,6 +27,9 @@
  *    ref_driver dump <prefix> nx ny nz nhalo scheme eta zeta fx fy fz \
  *               fieldforce solid nsteps
  *    ref_driver time nx ny nz scheme eta zeta nsteps
+ *    ref_driver fe <prefix> nx ny nz a b kappa     (symmetric free energy:
+ *               field_halo, field_grad_compute, pth_stress_compute,
+ *               pth_force_fluid_driver; nhalo = 2)
  *
  *  scheme: m10 | bgk | trt
  *
@@ -52,6 +55,13 @@
 #include "hydro.h"
 #include "map.h"
 #include "noise.h"
+#include "leesedwards.h"
+#include "field.h"
+#include "field_grad.h"
+#include "gradient_3d_7pt_fluid.h"
+#include "symmetric.h"
+#include "phi_force_stress.h"
+#include "phi_force_colloid.h"
 
 #define PI_ 3.14159265358979323846
 
@@ -171,6 +181,117 @@ static void init_map(cs_t * cs, map_t * map, const case_t * c) {
   }
 }
 
+/* Symmetric free-energy force chain of BASELINE config 4 (ludwig.c:563-717):
+ * field_halo(phi) -> field_grad_compute (3d_7pt_fluid) -> pth_stress_compute
+ * -> pth_force_fluid_driver (what phi_force_calculation runs for
+ * FE_FORCE_METHOD_STRESS_DIVERGENCE without walls, phi_force.c:100-108). */
+
+static int run_fe(int argc, char ** argv) {
+
+  const char * prefix = argv[2];
+  int ntotal[3] = {atoi(argv[3]), atoi(argv[4]), atoi(argv[5])};
+  fe_symm_param_t param = {0};
+  pe_t * pe = NULL;
+  cs_t * cs = NULL;
+  lees_edw_t * le = NULL;
+  field_t * phi = NULL;
+  field_grad_t * dphi = NULL;
+  fe_symm_t * fe = NULL;
+  pth_t * pth = NULL;
+  hydro_t * hydro = NULL;
+  physics_t * phys = NULL;
+  int nlocal[3];
+
+  param.a = atof(argv[6]);
+  param.b = atof(argv[7]);
+  param.kappa = atof(argv[8]);
+
+  MPI_Init(&argc, &argv);
+  pe_create(MPI_COMM_WORLD, PE_QUIET, &pe);
+  cs_create(pe, &cs);
+  cs_ntotal_set(cs, ntotal);
+  cs_nhalo_set(cs, 2);
+  cs_init(cs);
+  cs_nlocal(cs, nlocal);
+  physics_create(pe, &phys);
+
+  {
+    lees_edw_options_t opts = {0};
+    opts.nplanes = 0;
+    lees_edw_create(pe, cs, &opts, &le);
+  }
+  {
+    field_options_t opts = field_options_ndata_nhalo(1, 2);
+    field_create(pe, cs, le, "phi", &opts, &phi);
+  }
+  field_grad_create(pe, phi, 2, &dphi);
+  field_grad_set(dphi, grad_3d_7pt_fluid_d2, NULL);
+  fe_symm_create(pe, cs, phi, dphi, &fe);
+  fe_symm_param_set(fe, param);
+  pth_create(pe, cs, FE_FORCE_METHOD_STRESS_DIVERGENCE, &pth);
+  {
+    hydro_options_t hopts = hydro_options_nhalo(1);
+    hydro_create(pe, cs, le, &hopts, &hydro);
+  }
+
+  lcg_state = 12345u;
+  for (int ic = 1; ic <= nlocal[X]; ic++) {
+    for (int jc = 1; jc <= nlocal[Y]; jc++) {
+      for (int kc = 1; kc <= nlocal[Z]; kc++) {
+	double x = (ic - 1.0)/ntotal[X];
+	double y = (jc - 1.0)/ntotal[Y];
+	double z = (kc - 1.0)/ntotal[Z];
+	double r = lcg_uniform();
+	double v = 0.3*sin(2.0*PI_*x)*cos(2.0*PI_*y) + 0.2*sin(2.0*PI_*z + 1.0)
+	  + 0.05*(r - 0.5);
+	field_scalar_set(phi, cs_index(cs, ic, jc, kc), v);
+      }
+    }
+  }
+
+  field_halo(phi);
+  field_grad_compute(dphi);
+  {
+    double fzero[3] = {0.0, 0.0, 0.0};
+    hydro_f_zero(hydro, fzero);
+  }
+  pth_stress_compute(pth, (fe_t *) fe);
+  pth_force_fluid_driver(pth, hydro);
+
+  {
+    size_t ns = (size_t) phi->nsites;
+    int nall[3];
+    char fn[1024];
+    FILE * fp = NULL;
+    cs_nall(cs, nall);
+    dump(prefix, "phi", phi->data, ns);
+    dump(prefix, "grad", dphi->grad, 3*ns);
+    dump(prefix, "delsq", dphi->delsq, ns);
+    dump(prefix, "stress", pth->str, 9*ns);
+    dump(prefix, "force", hydro->force->data, 3*ns);
+    snprintf(fn, sizeof(fn), "%s.json", prefix);
+    fp = fopen(fn, "w");
+    fprintf(fp, "{\"nlocal\": [%d, %d, %d], \"nhalo\": 2, \"nall\": [%d, %d, %d],"
+	    " \"nsite\": %d, \"a\": %.17g, \"b\": %.17g, \"kappa\": %.17g,"
+	    " \"layout\": \"soa\"}\n", ntotal[X], ntotal[Y], ntotal[Z],
+	    nall[X], nall[Y], nall[Z], (int) ns, param.a, param.b, param.kappa);
+    fclose(fp);
+  }
+
+  hydro_free(hydro);
+  pth_free(pth);
+  fe_symm_free(fe);
+  field_grad_free(dphi);
+  field_free(phi);
+  lees_edw_free(le);
+  physics_free(phys);
+  cs_free(cs);
+  pe_free(pe);
+  MPI_Finalize();
+
+  return 0;
+}
+
 int main(int argc, char ** argv) {
 
   int timing = 0;
@@ -184,6 +305,8 @@ int main(int argc, char ** argv) {
   hydro_t * hydro = NULL;
   map_t * map = NULL;
   noise_t * noise = NULL;
+
+  if (argc == 9 && strcmp(argv[1], "fe") == 0) return run_fe(argc, argv);
 
   if (argc >= 2 && strcmp(argv[1], "dump") == 0 && argc == 16) {
     int a = 2;

@@ -16,8 +16,15 @@ RTOL_CONSERVED = 1.0e-12
 
 
 def golden_names():
+    """Fixtures of the LB step (q19_*, q27_*)."""
     return sorted(os.path.basename(f)[:-4]
-                  for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+                  for f in glob.glob(os.path.join(GOLDEN_DIR, "q*.npz")))
+
+
+def golden_fe_names():
+    """Fixtures of the symmetric free-energy force chain (fe_*)."""
+    return sorted(os.path.basename(f)[:-4]
+                  for f in glob.glob(os.path.join(GOLDEN_DIR, "fe_*.npz")))
 
 
 def load_golden(name):

@@ -1,0 +1,120 @@
+"""Row f2 on the device: width-2 field halo, 7-point gradients and the
+symmetric free-energy force, against the compiled-reference fixtures and the
+oracle. Needs an MI355X."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lb_oracle as lbo                        # noqa: E402
+from tests.common import golden_fe_names, interior, load_golden, relmax  # noqa: E402
+
+
+def _dev(lb, a):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(lb.device)
+    torch.cuda.synchronize(lb.device)
+    return t
+
+
+def _host(lb, t):
+    lb.synchronize()
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", golden_fe_names())
+def test_field_halo_width2_exact(name):
+    import ludwig_amd
+    g = load_golden(name)
+    meta = g["meta"]
+    h = meta["nhalo"]
+    lb = ludwig_amd.LB(19, tuple(meta["nlocal"]), h)
+    phi = np.zeros_like(g["phi"])
+    interior(phi, h)[...] = interior(g["phi"], h)
+    t = _dev(lb, phi)
+    lb.field_halo_n(t, 2)
+    assert np.array_equal(_host(lb, t), g["phi"])
+    lb.free()
+
+
+@pytest.mark.parametrize("name", golden_fe_names())
+def test_gradient_7pt_exact(name):
+    import ludwig_amd
+    import torch
+    g = load_golden(name)
+    meta = g["meta"]
+    lb = ludwig_amd.LB(19, tuple(meta["nlocal"]), meta["nhalo"])
+    phi = _dev(lb, g["phi"])
+    grad = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+    delsq = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    torch.cuda.synchronize()
+    lb.field_grad_7pt(phi, grad, delsq)
+    s = (slice(1, -1),) * 3
+    # differences of two doubles times 0.5, and a fixed-order 7-term sum:
+    # no contraction possible, so bit-exact
+    assert np.array_equal(_host(lb, grad)[(slice(None),) + s],
+                          g["grad"][(slice(None),) + s])
+    assert relmax(_host(lb, delsq)[s], g["delsq"][s]) < 1e-15
+    lb.free()
+
+
+@pytest.mark.parametrize("from_grad", [True, False], ids=["from_grad", "from_phi"])
+@pytest.mark.parametrize("name", golden_fe_names())
+def test_symmetric_force_vs_reference(name, from_grad):
+    import ludwig_amd
+    import torch
+    g = load_golden(name)
+    meta = g["meta"]
+    h = meta["nhalo"]
+    lb = ludwig_amd.LB(19, tuple(meta["nlocal"]), h)
+    phi = _dev(lb, g["phi"])
+    force = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+    torch.cuda.synchronize()
+    if from_grad:
+        lb.symmetric_force(meta["a"], meta["b"], meta["kappa"], phi, force,
+                           _dev(lb, g["grad"]), _dev(lb, g["delsq"]))
+    else:
+        lb.symmetric_force(meta["a"], meta["b"], meta["kappa"], phi, force)
+    f = _host(lb, force)
+    assert relmax(interior(f, h), interior(g["force"], h)) < 1e-12
+    # it ADDS to the force field: a second call doubles it
+    if from_grad:
+        lb.symmetric_force(meta["a"], meta["b"], meta["kappa"], phi, force,
+                           _dev(lb, g["grad"]), _dev(lb, g["delsq"]))
+        assert relmax(interior(_host(lb, force), h), 2 * interior(g["force"], h)) < 1e-12
+    lb.free()
+
+
+def test_force_chain_seeded_vs_oracle_and_feeds_collision():
+    """phi -> halo(2) -> force (from phi) -> lb_collide reads it: the
+    coupling of BASELINE config 4, against the oracle end to end."""
+    import ludwig_amd
+    import torch
+    nlocal, h = (24, 10, 18), 2
+    a, b, kappa = -0.00625, 0.00625, 0.004
+    p = lbo.make_param(19, nlocal, h, "m10", 0.1, 0.3)
+    rng = np.random.default_rng(5)
+    phi = np.zeros(lbo.nall(p))
+    interior(phi, h)[...] = 0.5 * rng.standard_normal(nlocal)
+    # oracle
+    phi_o = phi.copy()
+    lbo.field_halo(p, phi_o, 2)
+    grad, delsq = lbo.grad_7pt(p, phi_o)
+    force_o = np.zeros((3,) + phi.shape)
+    lbo.symm_force(p, a, b, kappa, phi_o, grad, delsq, force_o)
+    f0 = lbo.init_synthetic(p)
+    f_o = f0.copy()
+    lbo.collide(p, f_o, force_o)
+    # device
+    lb = ludwig_amd.LB(19, nlocal, h)
+    lb.relaxation_set("m10", 0.1, 0.3)
+    t = _dev(lb, phi)
+    lb.field_halo_n(t, 2)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, force=np.zeros((3,) + phi.shape))
+    lb.symmetric_force(a, b, kappa, t, hy.force)
+    assert relmax(interior(_host(lb, hy.force), h), interior(force_o, h)) < 1e-12
+    lb.lb_memcpy_h2d(f0)
+    lb.lb_collide(hy)
+    assert relmax(interior(lb.lb_memcpy_d2h(), h), interior(f_o, h)) < 1e-12
+    lb.free()

@@ -1,0 +1,54 @@
+"""Pin the oracle's symmetric free-energy force chain (row f2) against the
+compiled reference: field_halo (width 2), grad_3d_7pt_fluid, and
+pth_stress_compute + pth_force_fluid_driver. CPU only."""
+
+import numpy as np
+import pytest
+
+from oracle import lb_oracle as lbo
+from tests.common import golden_fe_names, interior, load_golden, relmax
+
+
+def fe_param(meta):
+    return lbo.make_param(19, meta["nlocal"], meta["nhalo"])
+
+
+@pytest.mark.parametrize("name", golden_fe_names())
+def test_field_halo_width2_exact(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    p = fe_param(meta)
+    h = meta["nhalo"]
+    phi = np.zeros_like(g["phi"])
+    interior(phi, h)[...] = interior(g["phi"], h)
+    lbo.field_halo(p, phi, 2)
+    assert np.array_equal(phi, g["phi"])        # both halo layers, bit for bit
+
+
+@pytest.mark.parametrize("name", golden_fe_names())
+def test_gradient_7pt(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    p = fe_param(meta)
+    grad, delsq = lbo.grad_7pt(p, np.ascontiguousarray(g["phi"]))
+    # computed region: interior + nextra = nhalo - 1 = 1 layer
+    s = (slice(1, -1),) * 3
+    assert np.array_equal(grad[(slice(None),) + s], g["grad"][(slice(None),) + s])
+    assert np.array_equal(delsq[s], g["delsq"][s])
+
+
+@pytest.mark.parametrize("name", golden_fe_names())
+def test_symmetric_force(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    p = fe_param(meta)
+    h = meta["nhalo"]
+    force = np.zeros_like(g["force"])
+    lbo.symm_force(p, meta["a"], meta["b"], meta["kappa"],
+                   np.ascontiguousarray(g["phi"]),
+                   np.ascontiguousarray(g["grad"]),
+                   np.ascontiguousarray(g["delsq"]), force)
+    assert relmax(interior(force, h), interior(g["force"], h)) < 1e-13
+    # a stress divergence sums to zero over a periodic box
+    total = interior(force, h).reshape(3, -1).sum(axis=1)
+    assert np.max(np.abs(total)) < 1e-15
