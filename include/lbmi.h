@@ -256,6 +256,18 @@ int lbmi_symmetric_force(lbmi_t * lb, double a, double b, double kappa,
 			 const double * phi, const double * grad,
 			 const double * delsq, double * force);
 
+/* phi_cahn_hilliard (phi_cahn_hilliard.c:195-284) for the symmetric free
+ * energy without noise, walls or Lees-Edwards planes: first-order upwind
+ * advection in u (advection.c:542-640), diffusive flux -M grad mu,
+ * forward step. phi (valid halo: 1 layer with delsq given, 2 layers with
+ * delsq == NULL), u = hydro->u with a valid 1-layer halo (hydro_u_halo);
+ * the new interior goes to phi_out (!= phi). The reference updates phi in
+ * place through four flux arrays; the caller here swaps the two arrays. */
+int lbmi_cahn_hilliard(lbmi_t * lb, double a, double b, double kappa,
+		       double mobility, const double * phi,
+		       const double * delsq, const double * u,
+		       double * phi_out);
+
 /* The on-disk record stream of the distribution files, lb_io_aggr_pack /
  * lb_io_aggr_unpack with lb_write_buf / lb_read_buf (model.c:1385-1430,
  * 1479-1550): nvel doubles in p order per interior site, sites in

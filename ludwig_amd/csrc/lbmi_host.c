@@ -1216,6 +1216,27 @@ int lbmi_symmetric_force(lbmi_t * lb, double a, double b, double kappa,
   return 0;
 }
 
+/* phi_cahn_hilliard (phi_cahn_hilliard.c:195-284) for the symmetric free
+ * energy: no noise, no walls, no Lees-Edwards planes, first-order advection */
+
+int lbmi_cahn_hilliard(lbmi_t * lb, double a, double b, double kappa,
+		       double mobility, const double * phi,
+		       const double * delsq, const double * u,
+		       double * phi_out) {
+  if (lb == NULL || !phi || !u || !phi_out) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (phi_out == phi) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_cahn_hilliard: phi_out must "
+		     "not alias phi (every site reads its neighbours)");
+  }
+  if (delsq == NULL && lb->kp.nhalo < 2) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "mu from phi needs nhalo >= 2");
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_cahn_hilliard(&lb->kp, a, b, kappa, mobility, phi, delsq, u,
+			      phi_out, lb->stream));
+  return 0;
+}
+
 int lbmi_lb_records_pack(lbmi_t * lb, double * records) {
   int ifail;
   if (lb == NULL || records == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");

@@ -118,6 +118,11 @@ int lbmi_k_symm_force(const lbmi_kparam_t * kp, double a, double b,
 		      double kappa, const double * phi, const double * grad,
 		      const double * delsq, double * force, void * stream);
 
+int lbmi_k_cahn_hilliard(const lbmi_kparam_t * kp, double a, double b,
+			 double kappa, double mobility, const double * phi,
+			 const double * delsq, const double * u,
+			 double * phi_out, void * stream);
+
 /* Moments: partial (nblk x 12 doubles workspace) then final (out_dev[9]) */
 int lbmi_k_moments_nblk(void);
 int lbmi_k_moments(const lbmi_kparam_t * kp, const double * f,

@@ -1166,6 +1166,85 @@ void k_symm_force(lbmi_kparam_t kp, Symm q, const double * __restrict__ phi,
   force[2*ns + i] += f[2];
 }
 
+/* k_cahn_hilliard<FROM_DELSQ>: one Cahn-Hilliard step of the symmetric
+ * binary fluid as phi_cahn_hilliard runs it without noise, walls or LE planes
+ * (phi_cahn_hilliard.c:195-284): first-order upwind advective fluxes
+ * (advection.c:542-640), diffusive fluxes -M (mu_1 - mu_0) with
+ * mu = a phi + b phi^3 - kappa delsq (phi_cahn_hilliard.c:349-402,
+ * symmetric.c:303-316) and the forward step (:1026-1060). The reference
+ * stores four flux arrays (fw, fe, fy, fz: 32 B/site written and re-read)
+ * and updates phi in place; here each site evaluates its six face fluxes
+ * in registers and writes phi_out (phi_out != phi), 8 B + 24 B (u) read and
+ * 8 B written per site. FROM_DELSQ = false takes delsq from phi itself. */
+
+template <bool FROM_DELSQ>
+__global__ __launch_bounds__(BLOCK)
+void k_cahn_hilliard(lbmi_kparam_t kp, Symm q, double mobility,
+		     const double * __restrict__ phi,
+		     const double * __restrict__ delsq,
+		     const double * __restrict__ u,
+		     double * __restrict__ phi_out, int i0, int i1,
+		     unsigned nblk) {
+
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+  Site s = decode(kp, i);
+  if (!s.interior) return;
+
+  const size_t ns = (size_t) kp.nsite;
+  const int str[3] = {kp.strx, kp.stry, 1};
+
+  auto mu_at = [&](size_t j) {
+    double d2;
+    if constexpr (FROM_DELSQ) {
+      d2 = delsq[j];
+    }
+    else {
+      double g[3];
+      grad7(phi, j, kp.strx, kp.stry, g, d2);
+    }
+    double ph = phi[j];
+    return q.a*ph + q.b*ph*ph*ph - q.kappa*d2;
+  };
+
+  const double phi0 = phi[i];
+  const double mu0 = mu_at((size_t) i);
+  double fhi[3], flo[3];               /* fluxes through the +d and -d faces */
+
+  static_for<0, 3>([&](auto D) {
+    constexpr int id = D;
+    const double ud0 = u[ns*id + i];
+    {
+      size_t j = (size_t) (i + str[id]);       /* face (i, i + e_d) */
+      double uf = 0.5*(ud0 + u[ns*id + j]);
+      double f = uf*((uf < 0.0) ? phi[j] : phi0);
+      f -= mobility*(mu_at(j) - mu0);
+      fhi[id] = f;
+    }
+    {
+      size_t j = (size_t) (i - str[id]);       /* face (i - e_d, i) */
+      double uf = 0.5*(ud0 + u[ns*id + j]);
+      double f;
+      if constexpr (id == 0) {
+	/* "west" flux of this site (advection.c:570-584) */
+	f = uf*((uf > 0.0) ? phi[j] : phi0);
+      }
+      else {
+	/* the +d flux of the site below (advection.c:602-636 at i - e_d) */
+	f = uf*((uf < 0.0) ? phi0 : phi[j]);
+      }
+      f -= mobility*(mu0 - mu_at(j));
+      flo[id] = f;
+    }
+  });
+
+  const double wz = (kp.nlocal[2] == 1) ? 0.0 : 1.0;
+  phi_out[i] = phi0 - (+ fhi[0] - flo[0] + fhi[1] - flo[1]
+		       + wz*fhi[2] - wz*flo[2]);
+}
+
 /* ---- moments ----------------------------------------------------------------
  *
  * Per interior fluid site: rho = sum_p f_p in p order (lb_0th_moment,
@@ -1729,6 +1808,26 @@ extern "C" int lbmi_k_symm_force(const lbmi_kparam_t * kp, double a, double b,
   else {
     hipLaunchKernelGGL((k_symm_force<false>), grid, block, 0, st, *kp, q, phi,
 		       grad, delsq, force, r.i0, r.i1, r.nblk);
+  }
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_cahn_hilliard(const lbmi_kparam_t * kp, double a,
+				    double b, double kappa, double mobility,
+				    const double * phi, const double * delsq,
+				    const double * u, double * phi_out,
+				    void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  Range1D r = interior_range(*kp);
+  dim3 grid(r.grid), block(BLOCK);
+  Symm q = {a, b, kappa};
+  if (delsq) {
+    hipLaunchKernelGGL((k_cahn_hilliard<true>), grid, block, 0, st, *kp, q,
+		       mobility, phi, delsq, u, phi_out, r.i0, r.i1, r.nblk);
+  }
+  else {
+    hipLaunchKernelGGL((k_cahn_hilliard<false>), grid, block, 0, st, *kp, q,
+		       mobility, phi, delsq, u, phi_out, r.i0, r.i1, r.nblk);
   }
   return (int) hipGetLastError();
 }

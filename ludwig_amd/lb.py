@@ -259,6 +259,12 @@ class LB:
             self._h, a, b, kappa, _ptr(phi), _ptr(grad), _ptr(delsq),
             _ptr(force)))
 
+    def cahn_hilliard(self, a, b, kappa, mobility, phi, u, phi_out, delsq=None):
+        """phi_cahn_hilliard (symmetric; order-1 advection): phi_out <- step(phi)."""
+        _l.check(self._lib.lbmi_cahn_hilliard(
+            self._h, a, b, kappa, mobility, _ptr(phi), _ptr(delsq), _ptr(u),
+            _ptr(phi_out)))
+
     def lb_io_aggr_pack(self):
         """lb_io_aggr_pack (model.c:1479): the binary record stream as a
         host array (nx, ny, nz, nvel)."""

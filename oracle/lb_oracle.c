@@ -805,3 +805,84 @@ int lbo_symm_force(const lbo_param_t * p, double a, double b, double kappa,
 
   return 0;
 }
+
+/*
+ * lbo_cahn_hilliard
+ *
+ * One Cahn-Hilliard step of the symmetric binary fluid as phi_cahn_hilliard
+ * runs it without noise, walls or Lees-Edwards planes
+ * (phi_cahn_hilliard.c:195-284):
+ *   advective fluxes, first-order upwind (advection_le_1st_kernel,
+ *   advection.c:542-640): at the face between i and its neighbour the
+ *   velocity is the mean of the two site velocities, phi is taken upwind;
+ *   diffusive fluxes -M (mu_1 - mu_0) with mu = a phi + b phi^3 - kappa
+ *   delsq (phi_ch_flux_mu1_kernel :349-402, fe_symm_mu symmetric.c:303-316);
+ *   forward step phi -= fe - fw + fy - fy(-y) + fz - fz(-z)
+ *   (phi_ch_ufs_kernel :1026-1060).
+ * u must carry a valid width-1 halo (hydro_u_halo), phi and delsq the
+ * width-1 layer around the interior. phi is updated in place at the
+ * interior sites; work: 4*nsite doubles (the flux arrays fw, fe, fy, fz).
+ */
+
+int lbo_cahn_hilliard(const lbo_param_t * p, double a, double b, double kappa,
+		      double mobility, double * phi, const double * delsq,
+		      const double * u, double * work) {
+
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+  double * fw, * fe, * fy, * fz;
+
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+  fw = work; fe = work + nsite; fy = work + 2*nsite; fz = work + 3*nsite;
+
+#define MU(j) (a*phi[j] + b*phi[j]*phi[j]*phi[j] - kappa*delsq[j])
+
+  /* fluxes for ic = 1..nlocal, jc, kc = 0..nlocal (advection.c:508-510) */
+  for (int ic = 1; ic <= p->nlocal[X]; ic++) {
+    for (int jc = 0; jc <= p->nlocal[Y]; jc++) {
+      for (int kc = 0; kc <= p->nlocal[Z]; kc++) {
+	ptrdiff_t i = str[X]*(p->nhalo + ic - 1)
+	  + str[Y]*(p->nhalo + jc - 1) + (p->nhalo + kc - 1);
+	ptrdiff_t j;
+	double uf, mu0 = MU(i);
+
+	j = i - str[X];                              /* west face */
+	uf = 0.5*(u[i] + u[j]);
+	fw[i] = uf*phi[(uf > 0.0) ? j : i];
+	fw[i] -= mobility*(mu0 - MU(j));
+
+	j = i + str[X];                              /* east face */
+	uf = 0.5*(u[i] + u[j]);
+	fe[i] = uf*phi[(uf < 0.0) ? j : i];
+	fe[i] -= mobility*(MU(j) - mu0);
+
+	j = i + str[Y];
+	uf = 0.5*(u[nsite + i] + u[nsite + j]);
+	fy[i] = uf*phi[(uf < 0.0) ? j : i];
+	fy[i] -= mobility*(MU(j) - mu0);
+
+	j = i + 1;
+	uf = 0.5*(u[2*nsite + i] + u[2*nsite + j]);
+	fz[i] = uf*phi[(uf < 0.0) ? j : i];
+	fz[i] -= mobility*(MU(j) - mu0);
+      }
+    }
+  }
+#undef MU
+
+  for (int ic = 1; ic <= p->nlocal[X]; ic++) {
+    for (int jc = 1; jc <= p->nlocal[Y]; jc++) {
+      for (int kc = 1; kc <= p->nlocal[Z]; kc++) {
+	ptrdiff_t i = str[X]*(p->nhalo + ic - 1)
+	  + str[Y]*(p->nhalo + jc - 1) + (p->nhalo + kc - 1);
+	double wz = (p->nlocal[Z] == 1) ? 0.0 : 1.0;
+	phi[i] -= (+ fe[i] - fw[i] + fy[i] - fy[i - str[Y]]
+		   + wz*fz[i] - wz*fz[i - 1]);
+      }
+    }
+  }
+
+  return 0;
+}

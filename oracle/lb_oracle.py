@@ -71,6 +71,9 @@ def lib():
         _lib.lbo_halo_width.argtypes = [pp, ctypes.c_int, dp, ctypes.c_int,
                                         ctypes.c_int]
         _lib.lbo_grad_7pt.argtypes = [pp, dp, dp, dp]
+        _lib.lbo_cahn_hilliard.argtypes = [pp, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_double, ctypes.c_double,
+                                           dp, dp, dp, dp]
         _lib.lbo_symm_force.argtypes = [pp, ctypes.c_double, ctypes.c_double,
                                         ctypes.c_double, dp, dp, dp, dp]
         _lib.lbo_moments.argtypes = [pp, dp, dp, dp]
@@ -168,6 +171,14 @@ def grad_7pt(p, phi):
 def symm_force(p, a, b, kappa, phi, grad, delsq, force):
     rc = lib().lbo_symm_force(ctypes.byref(p), a, b, kappa, _ptr(phi),
                               _ptr(grad), _ptr(delsq), _ptr(force))
+    assert rc == 0
+
+
+def cahn_hilliard(p, a, b, kappa, mobility, phi, delsq, u):
+    """phi_cahn_hilliard (no noise/walls/LE): phi updated in place."""
+    work = np.zeros((4,) + phi.shape)
+    rc = lib().lbo_cahn_hilliard(ctypes.byref(p), a, b, kappa, mobility,
+                                 _ptr(phi), _ptr(delsq), _ptr(u), _ptr(work))
     assert rc == 0
 
 

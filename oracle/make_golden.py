@@ -81,20 +81,21 @@ def run_case(case, tmp):
 
 
 FE_CASES = [
-    ("fe_symm_a", (6, 5, 4), -0.0625, 0.0625, 0.04),
-    ("fe_symm_b", (5, 8, 7), -0.00625, 0.00625, 0.004),
+    ("fe_symm_a", (6, 5, 4), -0.0625, 0.0625, 0.04, 0.15),
+    ("fe_symm_b", (5, 8, 7), -0.00625, 0.00625, 0.004, 1.25),
 ]
 
 
 def run_fe_case(case, tmp):
     """Symmetric free-energy force chain (row f2): phi with its width-2 halo,
     grad/delsq of grad_3d_7pt_fluid, force of pth_stress_compute +
-    pth_force_fluid_driver."""
-    name, n, a, b, kappa = case
+    pth_force_fluid_driver; u (with its halo) and phi_new of
+    phi_cahn_hilliard (first-order advection)."""
+    name, n, a, b, kappa, mobility = case
     exe = os.path.join(HERE, "_ref", "ref_driver_d3q19")
     prefix = os.path.join(tmp, name)
     subprocess.run([exe, "fe", prefix, *map(str, n), repr(a), repr(b),
-                    repr(kappa)], check=True)
+                    repr(kappa), repr(mobility)], check=True)
     meta = json.load(open(prefix + ".json"))
     meta["name"] = name
     nall = tuple(meta["nall"])
@@ -104,7 +105,8 @@ def run_fe_case(case, tmp):
 
     return {"meta": np.array(json.dumps(meta)), "phi": load("phi", ()),
             "grad": load("grad", (3,)), "delsq": load("delsq", ()),
-            "force": load("force", (3,))}
+            "force": load("force", (3,)), "u": load("u", (3,)),
+            "phi_new": load("phi_new", ())}
 
 
 def main():

@@ -29,7 +29,8 @@
  *    ref_driver time nx ny nz scheme eta zeta nsteps
  *    ref_driver fe <prefix> nx ny nz a b kappa     (symmetric free energy:
  *               field_halo, field_grad_compute, pth_stress_compute,
- *               pth_force_fluid_driver; nhalo = 2)
+ *               pth_force_fluid_driver, then phi_cahn_hilliard with first-
+ *               order advection in a prescribed velocity field; nhalo = 2)
  *
  *  scheme: m10 | bgk | trt
  *
@@ -62,6 +63,8 @@
 #include "symmetric.h"
 #include "phi_force_stress.h"
 #include "phi_force_colloid.h"
+#include "phi_cahn_hilliard.h"
+#include "advection.h"
 
 #define PI_ 3.14159265358979323846
 
@@ -202,6 +205,9 @@ static int run_fe(int argc, char ** argv) {
   physics_t * phys = NULL;
   int nlocal[3];
 
+  double mobility = atof(argv[9]);
+  phi_ch_t * pch = NULL;
+
   param.a = atof(argv[6]);
   param.b = atof(argv[7]);
   param.kappa = atof(argv[8]);
@@ -214,6 +220,7 @@ static int run_fe(int argc, char ** argv) {
   cs_init(cs);
   cs_nlocal(cs, nlocal);
   physics_create(pe, &phys);
+  physics_mobility_set(phys, mobility);
 
   {
     lees_edw_options_t opts = {0};
@@ -269,12 +276,42 @@ static int run_fe(int argc, char ** argv) {
     dump(prefix, "delsq", dphi->delsq, ns);
     dump(prefix, "stress", pth->str, 9*ns);
     dump(prefix, "force", hydro->force->data, 3*ns);
+
+    /* Cahn-Hilliard update (ludwig.c:759): prescribed velocity field,
+     * upwind advection (advection.c:542-640), diffusive flux of mu
+     * (phi_cahn_hilliard.c:349-402), forward step (:981-1060) */
+    {
+      phi_ch_info_t options = {0};
+      phi_ch_create(pe, cs, le, &options, &pch);
+      advection_order_set(1);
+      for (int ic = 1; ic <= nlocal[X]; ic++) {
+	for (int jc = 1; jc <= nlocal[Y]; jc++) {
+	  for (int kc = 1; kc <= nlocal[Z]; kc++) {
+	    int index = cs_index(cs, ic, jc, kc);
+	    double x = (ic - 1.0)/ntotal[X];
+	    double y = (jc - 1.0)/ntotal[Y];
+	    double z = (kc - 1.0)/ntotal[Z];
+	    double u[3];
+	    u[X] = 0.05*sin(2.0*PI_*y) + 0.01*(lcg_uniform() - 0.5);
+	    u[Y] = 0.05*sin(2.0*PI_*z) + 0.01*(lcg_uniform() - 0.5);
+	    u[Z] = 0.05*sin(2.0*PI_*x) + 0.01*(lcg_uniform() - 0.5);
+	    hydro_u_set(hydro, index, u);
+	  }
+	}
+      }
+      phi_cahn_hilliard(pch, (fe_t *) fe, phi, hydro, NULL, NULL);
+      dump(prefix, "u", hydro->u->data, 3*ns);       /* after hydro_u_halo */
+      dump(prefix, "phi_new", phi->data, ns);
+      phi_ch_free(pch);
+    }
     snprintf(fn, sizeof(fn), "%s.json", prefix);
     fp = fopen(fn, "w");
     fprintf(fp, "{\"nlocal\": [%d, %d, %d], \"nhalo\": 2, \"nall\": [%d, %d, %d],"
 	    " \"nsite\": %d, \"a\": %.17g, \"b\": %.17g, \"kappa\": %.17g,"
-	    " \"layout\": \"soa\"}\n", ntotal[X], ntotal[Y], ntotal[Z],
-	    nall[X], nall[Y], nall[Z], (int) ns, param.a, param.b, param.kappa);
+	    " \"mobility\": %.17g, \"layout\": \"soa\"}\n",
+	    ntotal[X], ntotal[Y], ntotal[Z],
+	    nall[X], nall[Y], nall[Z], (int) ns, param.a, param.b, param.kappa,
+	    mobility);
     fclose(fp);
   }
 
@@ -306,7 +343,7 @@ int main(int argc, char ** argv) {
   map_t * map = NULL;
   noise_t * noise = NULL;
 
-  if (argc == 9 && strcmp(argv[1], "fe") == 0) return run_fe(argc, argv);
+  if (argc == 10 && strcmp(argv[1], "fe") == 0) return run_fe(argc, argv);
 
   if (argc >= 2 && strcmp(argv[1], "dump") == 0 && argc == 16) {
     int a = 2;

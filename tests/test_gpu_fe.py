@@ -118,3 +118,91 @@ def test_force_chain_seeded_vs_oracle_and_feeds_collision():
     lb.lb_collide(hy)
     assert relmax(interior(lb.lb_memcpy_d2h(), h), interior(f_o, h)) < 1e-12
     lb.free()
+
+
+@pytest.mark.parametrize("from_delsq", [True, False], ids=["from_delsq", "from_phi"])
+@pytest.mark.parametrize("name", golden_fe_names())
+def test_cahn_hilliard_vs_reference(name, from_delsq):
+    import ludwig_amd
+    import torch
+    g = load_golden(name)
+    meta = g["meta"]
+    h = meta["nhalo"]
+    lb = ludwig_amd.LB(19, tuple(meta["nlocal"]), h)
+    phi = _dev(lb, g["phi"])
+    # u: interior from the fixture, halo by our own width-1 field halo
+    u0 = np.zeros_like(g["u"])
+    interior(u0, h)[...] = interior(g["u"], h)
+    u = _dev(lb, u0)
+    lb.field_halo_n(u, 1)
+    out = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    torch.cuda.synchronize()
+    lb.cahn_hilliard(meta["a"], meta["b"], meta["kappa"], meta["mobility"],
+                     phi, u, out, _dev(lb, g["delsq"]) if from_delsq else None)
+    res = _host(lb, out)
+    assert relmax(interior(res, h), interior(g["phi_new"], h)) < 1e-12
+    assert abs(interior(res, h).sum() - interior(g["phi"], h).sum()) < 1e-12
+    lb.free()
+
+
+def test_cahn_hilliard_rejects_aliasing():
+    import ludwig_amd
+    import torch
+    lb = ludwig_amd.LB(19, (4, 4, 4), 2)
+    phi = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    u = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.cahn_hilliard(-1.0, 1.0, 1.0, 0.1, phi, u, phi)
+    lb.free()
+
+
+def test_binary_fluid_steps_vs_oracle():
+    """A few complete steps of BASELINE config 4 on a small box, the order
+    of ludwig.c:537-860: f_zero, phi halo, force, Cahn-Hilliard (with the u
+    of the previous collision), u_zero, collide, halo, propagate -- device
+    (fused-from-phi kernels, FUSED LB step) against the oracle."""
+    import ludwig_amd
+    import torch
+    nlocal, h, nsteps = (12, 10, 8), 2, 4
+    a, b, kappa, mob = -0.00625, 0.00625, 0.004, 1.25
+    p = lbo.make_param(19, nlocal, h, "m10", 0.1, 0.3)
+    rng = np.random.default_rng(9)
+    phi0 = np.zeros(lbo.nall(p))
+    interior(phi0, h)[...] = 0.1 * rng.standard_normal(nlocal)
+    f0 = lbo.init_synthetic(p)
+
+    # oracle
+    phi = phi0.copy()
+    f = f0.copy()
+    fp = np.zeros_like(f)
+    u = np.zeros((3,) + phi.shape)
+    rho = np.zeros(phi.shape)
+    for _ in range(nsteps):
+        force = np.zeros((3,) + phi.shape)
+        lbo.field_halo(p, phi, 2)
+        grad, delsq = lbo.grad_7pt(p, phi)
+        lbo.symm_force(p, a, b, kappa, phi, grad, delsq, force)
+        lbo.field_halo(p, u, 1)
+        lbo.cahn_hilliard(p, a, b, kappa, mob, phi, delsq, u)
+        u[...] = 0.0
+        f, fp = lbo.step(p, f, fp, force, None, rho, u)
+
+    # device
+    lb = ludwig_amd.LB(19, nlocal, h, mode=ludwig_amd.FUSED)
+    lb.relaxation_set("m10", 0.1, 0.3)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, force=np.zeros((3,) + phi.shape))
+    pa = _dev(lb, phi0)
+    pb = torch.zeros_like(pa)
+    lb.lb_memcpy_h2d(f0)
+    for _ in range(nsteps):
+        lb.hydro_field_set(hy.force, (0, 0, 0))
+        lb.field_halo_n(pa, 2)
+        lb.symmetric_force(a, b, kappa, pa, hy.force)
+        lb.field_halo_n(hy.u, 1)
+        lb.cahn_hilliard(a, b, kappa, mob, pa, hy.u, pb)
+        pa, pb = pb, pa
+        lb.hydro_field_set(hy.u, (0, 0, 0))
+        lb.step(hy)
+    assert relmax(interior(_host(lb, pa), h), interior(phi, h)) < 1e-12
+    assert relmax(interior(lb.lb_memcpy_d2h(), h), interior(f, h)) < 1e-12
+    lb.free()

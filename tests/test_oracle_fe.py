@@ -52,3 +52,23 @@ def test_symmetric_force(name):
     # a stress divergence sums to zero over a periodic box
     total = interior(force, h).reshape(3, -1).sum(axis=1)
     assert np.max(np.abs(total)) < 1e-15
+
+
+@pytest.mark.parametrize("name", golden_fe_names())
+def test_u_halo_and_cahn_hilliard(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    p = fe_param(meta)
+    h = meta["nhalo"]
+    # hydro_u_halo: width-1 swap of the 3-component field (hydro.c:190)
+    u = np.zeros_like(g["u"])
+    interior(u, h)[...] = interior(g["u"], h)
+    lbo.field_halo(p, u, 1)
+    s1 = (slice(None), slice(1, -1), slice(1, -1), slice(1, -1))
+    assert np.array_equal(u[s1], g["u"][s1])
+    phi = np.ascontiguousarray(g["phi"]).copy()
+    lbo.cahn_hilliard(p, meta["a"], meta["b"], meta["kappa"], meta["mobility"],
+                      phi, np.ascontiguousarray(g["delsq"]), u)
+    assert relmax(interior(phi, h), interior(g["phi_new"], h)) < 1e-14
+    # conservative: sum phi unchanged to rounding
+    assert abs(interior(phi, h).sum() - interior(g["phi"], h).sum()) < 1e-13

@@ -60,6 +60,25 @@ def main():
     print("k_propagate       %.3f ms  %6.0f GB/s" % (t, gbs(304 * sites, t)))
     lb.free()
 
+    # row f2: symmetric free-energy force chain (nhalo = 2)
+    for n in (128, 256):
+        lb = ludwig_amd.LB(19, (n, n, n), 2)
+        phi = 0.3 * torch.randn(lb.nall, dtype=torch.float64, device=lb.device)
+        grad = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+        delsq = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+        force = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+        torch.cuda.synchronize()
+        s3 = n ** 3
+        t = timed(lb, lambda: lb.field_halo_n(phi, 2))
+        print("%d^3 field_halo(2)        %.4f ms" % (n, t))
+        t = timed(lb, lambda: lb.field_grad_7pt(phi, grad, delsq))
+        print("%d^3 grad_7pt             %.4f ms  %6.0f GB/s (40 B/site)" % (n, t, gbs(40 * s3, t)))
+        t = timed(lb, lambda: lb.symmetric_force(-0.00625, 0.00625, 0.004, phi, force, grad, delsq))
+        print("%d^3 force from grad      %.4f ms  %6.0f GB/s (88 B/site)" % (n, t, gbs(88 * s3, t)))
+        t = timed(lb, lambda: lb.symmetric_force(-0.00625, 0.00625, 0.004, phi, force))
+        print("%d^3 force from phi       %.4f ms  %6.0f GB/s (56 B/site)" % (n, t, gbs(56 * s3, t)))
+        lb.free()
+
 
 if __name__ == "__main__":
     main()
