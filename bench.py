@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--nhalo", type=int, default=1)
     ap.add_argument("--force-field", type=int, default=0,
                     help="1: per-site force F = 1e-5 cos(2 pi x/L) (BASELINE config 4)")
+    ap.add_argument("--fe", default="none", choices=["none", "symmetric"],
+                    help="symmetric: the full binary-fluid step of BASELINE "
+                    "config 4 (phi halo, thermodynamic force, Cahn-Hilliard, "
+                    "LB step); 1 GPU, forces --nhalo 2")
     ap.add_argument("--selfring", type=int, default=0,
                     help="1 GPU only: route the X halo through a 1-rank RCCL "
                     "ring (exercises the N>1 step path: pack, send/recv, "
@@ -187,6 +191,39 @@ def main():
                 hydro.force[a][h:-h, h:-h, h:-h] = c.reshape(shape)
         torch.cuda.synchronize()
 
+    fe = None
+    if args.fe == "symmetric":
+        if world > 1 or args.nhalo < 2:
+            raise SystemExit("--fe symmetric: 1 GPU and --nhalo 2")
+        if hydro is None:
+            raise SystemExit("--fe symmetric needs --hydro 1")
+        g = torch.Generator(device=lb.device)
+        g.manual_seed(1234)
+        fe = {"a": -0.00625, "b": 0.00625, "kappa": 0.004, "mobility": 1.25,
+              "phi": torch.zeros(lb.nall, dtype=torch.float64, device=lb.device),
+              "phi2": torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)}
+        h = args.nhalo
+        fe["phi"][h:-h, h:-h, h:-h] = 0.05 * (torch.rand(
+            lb.nlocal, dtype=torch.float64, device=lb.device, generator=g) - 0.5)
+        torch.cuda.synchronize()
+
+    def fe_step():
+        # ludwig.c:537-791 for free_energy symmetric (finite difference)
+        lb.hydro_field_set(hydro.force, (0.0, 0.0, 0.0))       # hydro_f_zero
+        lb.field_halo_n(fe["phi"], 2)                           # field_halo
+        lb.symmetric_force(fe["a"], fe["b"], fe["kappa"], fe["phi"],
+                           hydro.force)                         # phi_force_calculation
+        lb.field_halo_n(hydro.u, 1)                             # hydro_u_halo
+        lb.cahn_hilliard(fe["a"], fe["b"], fe["kappa"], fe["mobility"],
+                         fe["phi"], hydro.u, fe["phi2"])        # phi_cahn_hilliard
+        fe["phi"], fe["phi2"] = fe["phi2"], fe["phi"]
+        lb.hydro_field_set(hydro.u, (0.0, 0.0, 0.0))            # hydro_u_zero
+
+    def one_step():
+        if fe is not None:
+            fe_step()
+        lb.step(hydro)
+
     def allsum(v):
         if world == 1:
             return v
@@ -197,7 +234,7 @@ def main():
     mom0 = allsum(lb.moments()[[1, 5, 6, 7]])
 
     for _ in range(args.warmup):
-        lb.step(hydro)
+        one_step()
     lb.synchronize()
     lb.timing(True)
 
@@ -206,7 +243,7 @@ def main():
     lb.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        lb.step(hydro)
+        one_step()
     lb.synchronize()
     torch.cuda.synchronize()
     barrier()
@@ -270,6 +307,7 @@ def main():
                             % (args.nvel, args.scheme.upper(), *ntotal),
                 "mode": args.mode,
                 "hydro_io": bool(args.hydro),
+                "free_energy": args.fe,
                 "decomposition": "x-slab %d_1_1" % world
                                  + (" (1-rank RCCL ring)" if args.selfring else ""),
                 "halo": "index wrap (1 GPU); reduced X planes over RCCL (N>1)",
