@@ -211,11 +211,10 @@ def main():
         # ludwig.c:537-791 for free_energy symmetric (finite difference)
         lb.hydro_field_set(hydro.force, (0.0, 0.0, 0.0))       # hydro_f_zero
         lb.field_halo_n(fe["phi"], 2)                           # field_halo
-        lb.symmetric_force(fe["a"], fe["b"], fe["kappa"], fe["phi"],
-                           hydro.force)                         # phi_force_calculation
         lb.field_halo_n(hydro.u, 1)                             # hydro_u_halo
-        lb.cahn_hilliard(fe["a"], fe["b"], fe["kappa"], fe["mobility"],
-                         fe["phi"], hydro.u, fe["phi2"])        # phi_cahn_hilliard
+        # phi_force_calculation + phi_cahn_hilliard, one pass over phi
+        lb.symmetric_step(fe["a"], fe["b"], fe["kappa"], fe["mobility"],
+                          fe["phi"], hydro.u, hydro.force, fe["phi2"])
         fe["phi"], fe["phi2"] = fe["phi2"], fe["phi"]
         lb.hydro_field_set(hydro.u, (0.0, 0.0, 0.0))            # hydro_u_zero
 

@@ -268,6 +268,13 @@ int lbmi_cahn_hilliard(lbmi_t * lb, double a, double b, double kappa,
 		       const double * delsq, const double * u,
 		       double * phi_out);
 
+/* lbmi_symmetric_force (from phi) and lbmi_cahn_hilliard (from phi) in ONE
+ * pass: they share the seven (grad, delsq) evaluations around every site.
+ * Results identical to the two separate calls. Needs nhalo >= 2. */
+int lbmi_symmetric_step(lbmi_t * lb, double a, double b, double kappa,
+			double mobility, const double * phi, const double * u,
+			double * force, double * phi_out);
+
 /* The on-disk record stream of the distribution files, lb_io_aggr_pack /
  * lb_io_aggr_unpack with lb_write_buf / lb_read_buf (model.c:1385-1430,
  * 1479-1550): nvel doubles in p order per interior site, sites in

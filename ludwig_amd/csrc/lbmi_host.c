@@ -1237,6 +1237,22 @@ int lbmi_cahn_hilliard(lbmi_t * lb, double a, double b, double kappa,
   return 0;
 }
 
+/* phi_force_calculation + phi_cahn_hilliard in one pass over phi */
+
+int lbmi_symmetric_step(lbmi_t * lb, double a, double b, double kappa,
+			double mobility, const double * phi, const double * u,
+			double * force, double * phi_out) {
+  if (lb == NULL || !phi || !u || !force || !phi_out) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  }
+  if (phi_out == phi) return lbmi_fail(LBMI_ERR_ARGUMENT, "phi_out aliases phi");
+  if (lb->kp.nhalo < 2) return lbmi_fail(LBMI_ERR_ARGUMENT, "needs nhalo >= 2");
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_symm_fe_step(&lb->kp, a, b, kappa, mobility, phi, u, force,
+			     phi_out, lb->stream));
+  return 0;
+}
+
 int lbmi_lb_records_pack(lbmi_t * lb, double * records) {
   int ifail;
   if (lb == NULL || records == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");

@@ -123,6 +123,11 @@ int lbmi_k_cahn_hilliard(const lbmi_kparam_t * kp, double a, double b,
 			 const double * delsq, const double * u,
 			 double * phi_out, void * stream);
 
+int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, double a, double b,
+			double kappa, double mobility, const double * phi,
+			const double * u, double * force, double * phi_out,
+			void * stream);
+
 /* Moments: partial (nblk x 12 doubles workspace) then final (out_dev[9]) */
 int lbmi_k_moments_nblk(void);
 int lbmi_k_moments(const lbmi_kparam_t * kp, const double * f,

@@ -1245,6 +1245,81 @@ void k_cahn_hilliard(lbmi_kparam_t kp, Symm q, double mobility,
 		       + wz*fhi[2] - wz*flo[2]);
 }
 
+/* k_symm_fe_step: thermodynamic force AND Cahn-Hilliard step of the symmetric
+ * binary fluid in one pass over phi (k_symm_force<false> + k_cahn_hilliard
+ * <false> share the seven (grad, delsq) evaluations around a site): reads
+ * phi (25-point, cache resident) and u, adds F to force, writes phi_out.
+ * u is the velocity of the previous collision with a valid halo; the force
+ * does not depend on u and the update of phi does not depend on the force,
+ * so the two results are exactly those of the separate kernels. */
+
+__global__ __launch_bounds__(BLOCK)
+void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility,
+		    const double * __restrict__ phi,
+		    const double * __restrict__ u,
+		    double * __restrict__ force,
+		    double * __restrict__ phi_out, int i0, int i1,
+		    unsigned nblk) {
+
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+  Site s = decode(kp, i);
+  if (!s.interior) return;
+
+  const size_t ns = (size_t) kp.nsite;
+  const int str[3] = {kp.strx, kp.stry, 1};
+
+  /* stress and chemical potential at a site, from phi alone */
+  auto at = [&](size_t j, double (&st)[3][3], double & mu, double & ph) {
+    double g[3], d2;
+    grad7(phi, j, kp.strx, kp.stry, g, d2);
+    ph = phi[j];
+    symm_stress(q, ph, g, d2, st);
+    mu = q.a*ph + q.b*ph*ph*ph - q.kappa*d2;
+  };
+
+  double pth0[3][3], pth1[3][3];
+  double mu0, mu1, phi0, phi1;
+  double f[3] = {0.0, 0.0, 0.0};
+  double fhi[3], flo[3];
+  at((size_t) i, pth0, mu0, phi0);
+
+  static_for<0, 3>([&](auto D) {
+    constexpr int id = D;
+    const double ud0 = u[ns*id + i];
+    {
+      size_t j = (size_t) (i + str[id]);
+      at(j, pth1, mu1, phi1);
+      for (int ia = 0; ia < 3; ia++) f[ia] -= 0.5*(pth1[ia][id] + pth0[ia][id]);
+      double uf = 0.5*(ud0 + u[ns*id + j]);
+      double fl = uf*((uf < 0.0) ? phi1 : phi0);
+      fl -= mobility*(mu1 - mu0);
+      fhi[id] = fl;
+    }
+    {
+      size_t j = (size_t) (i - str[id]);
+      at(j, pth1, mu1, phi1);
+      for (int ia = 0; ia < 3; ia++) f[ia] += 0.5*(pth1[ia][id] + pth0[ia][id]);
+      double uf = 0.5*(ud0 + u[ns*id + j]);
+      double fl;
+      if constexpr (id == 0) fl = uf*((uf > 0.0) ? phi1 : phi0);
+      else fl = uf*((uf < 0.0) ? phi0 : phi1);
+      fl -= mobility*(mu0 - mu1);
+      flo[id] = fl;
+    }
+  });
+
+  force[i] += f[0];
+  force[ns + i] += f[1];
+  force[2*ns + i] += f[2];
+
+  const double wz = (kp.nlocal[2] == 1) ? 0.0 : 1.0;
+  phi_out[i] = phi0 - (+ fhi[0] - flo[0] + fhi[1] - flo[1]
+		       + wz*fhi[2] - wz*flo[2]);
+}
+
 /* ---- moments ----------------------------------------------------------------
  *
  * Per interior fluid site: rho = sum_p f_p in p order (lb_0th_moment,
@@ -1829,6 +1904,20 @@ extern "C" int lbmi_k_cahn_hilliard(const lbmi_kparam_t * kp, double a,
     hipLaunchKernelGGL((k_cahn_hilliard<false>), grid, block, 0, st, *kp, q,
 		       mobility, phi, delsq, u, phi_out, r.i0, r.i1, r.nblk);
   }
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, double a,
+				   double b, double kappa, double mobility,
+				   const double * phi, const double * u,
+				   double * force, double * phi_out,
+				   void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  Range1D r = interior_range(*kp);
+  dim3 grid(r.grid), block(BLOCK);
+  Symm q = {a, b, kappa};
+  hipLaunchKernelGGL(k_symm_fe_step, grid, block, 0, st, *kp, q, mobility,
+		     phi, u, force, phi_out, r.i0, r.i1, r.nblk);
   return (int) hipGetLastError();
 }
 

@@ -206,3 +206,32 @@ def test_binary_fluid_steps_vs_oracle():
     assert relmax(interior(_host(lb, pa), h), interior(phi, h)) < 1e-12
     assert relmax(interior(lb.lb_memcpy_d2h(), h), interior(f, h)) < 1e-12
     lb.free()
+
+
+@pytest.mark.parametrize("name", golden_fe_names())
+def test_symmetric_step_equals_separate_kernels(name):
+    import ludwig_amd
+    import torch
+    g = load_golden(name)
+    meta = g["meta"]
+    h = meta["nhalo"]
+    lb = ludwig_amd.LB(19, tuple(meta["nlocal"]), h)
+    phi = _dev(lb, g["phi"])
+    u0 = np.zeros_like(g["u"])
+    interior(u0, h)[...] = interior(g["u"], h)
+    u = _dev(lb, u0)
+    lb.field_halo_n(u, 1)
+    args = (meta["a"], meta["b"], meta["kappa"])
+    f1 = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+    f2 = torch.zeros_like(f1)
+    o1 = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    o2 = torch.zeros_like(o1)
+    torch.cuda.synchronize()
+    lb.symmetric_force(*args, phi, f1)
+    lb.cahn_hilliard(*args, meta["mobility"], phi, u, o1)
+    lb.symmetric_step(*args, meta["mobility"], phi, u, f2, o2)
+    assert relmax(interior(_host(lb, f2), h), interior(g["force"], h)) < 1e-12
+    assert relmax(interior(_host(lb, o2), h), interior(g["phi_new"], h)) < 1e-12
+    assert relmax(_host(lb, f2), _host(lb, f1)) < 1e-14
+    assert relmax(_host(lb, o2), _host(lb, o1)) < 1e-14
+    lb.free()

@@ -77,6 +77,13 @@ def main():
         print("%d^3 force from grad      %.4f ms  %6.0f GB/s (88 B/site)" % (n, t, gbs(88 * s3, t)))
         t = timed(lb, lambda: lb.symmetric_force(-0.00625, 0.00625, 0.004, phi, force))
         print("%d^3 force from phi       %.4f ms  %6.0f GB/s (56 B/site)" % (n, t, gbs(56 * s3, t)))
+        u = 0.01 * torch.randn((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+        out = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+        torch.cuda.synchronize()
+        t = timed(lb, lambda: lb.cahn_hilliard(-0.00625, 0.00625, 0.004, 1.25, phi, u, out))
+        print("%d^3 cahn_hilliard (phi)  %.4f ms  %6.0f GB/s (40 B/site)" % (n, t, gbs(40 * s3, t)))
+        t = timed(lb, lambda: lb.symmetric_step(-0.00625, 0.00625, 0.004, 1.25, phi, u, force, out))
+        print("%d^3 force + CH, one pass %.4f ms  %6.0f GB/s (88 B/site)" % (n, t, gbs(88 * s3, t)))
         lb.free()
 
 
