@@ -288,6 +288,12 @@ int lbmi_lb_records_unpack(lbmi_t * lb, const double * records);
 int lbmi_synchronize(lbmi_t * lb);
 /* hipStream_t of the compute stream, as void* */
 int lbmi_stream(lbmi_t * lb, void ** stream);
+/* Run all further work of this handle on the caller's hipStream_t (NULL =
+ * the default stream) instead of the handle's own non-blocking stream, so
+ * that it is ordered with the caller's other work on that stream (e.g.
+ * Ludwig's default-stream kernels, or a torch stream). The handle does not
+ * own the stream. Pending work on the previous stream is drained first. */
+int lbmi_set_stream(lbmi_t * lb, void * stream);
 /* Average device time (ms) of the fused kernel launches since the last
  * call, measured with hipEvents on the compute stream (bench.py roofline);
  * enable with lbmi_timing(lb, 1). */

@@ -148,6 +148,10 @@ static lbmi_t * shim_handle(lb_t * lb) {
     if (mode && mode[0] == 'f') opts.mode = LBMI_MODE_FUSED;
 
     SHIM_CHECK(lb, lbmi_create(&opts, &shim_.h));
+    /* Ludwig launches all its kernels on the default stream
+     * (tdpLaunchKernel(..., 0, 0, ...)): run ours there too, so that the
+     * kernels on either side of each call are ordered without extra syncs */
+    SHIM_CHECK(lb, lbmi_set_stream(shim_.h, NULL));
     shim_.lb = lb;
     shim_.fused = (opts.mode == LBMI_MODE_FUSED);
 

@@ -37,7 +37,8 @@ struct lbmi_s {
   lbmi_halo_sel_t sel_full[3];       /* all populations, both sides */
   lbmi_halo_sel_t sel_reduced[3];    /* c_d = +1 low side, c_d = -1 high */
 
-  hipStream_t stream;                /* compute */
+  hipStream_t stream;                /* compute (own_stream, or the caller's) */
+  hipStream_t own_stream;
   hipStream_t comm_stream;           /* halo exchange (multi-GPU overlap) */
   hipEvent_t ev_ready;               /* boundary planes of f written */
   hipEvent_t ev_halo;                /* x halo planes of f filled */
@@ -295,13 +296,14 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   /* Defaults of the reference: rho0 = 1, eta = zeta = 1/6 (physics.c:33-56) */
   lbmi_set_relaxation(lb, LBMI_RELAXATION_M10, 1.0, 1.0/6.0, 1.0/6.0);
 
-  if (hipStreamCreateWithFlags(&lb->stream, hipStreamNonBlocking) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&lb->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&lb->comm_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&lb->ev_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&lb->ev_halo, hipEventDisableTiming) != hipSuccess) {
     free(lb);
     return lbmi_fail(LBMI_ERR_HIP, "stream/event creation failed");
   }
+  lb->stream = lb->own_stream;
 
   if (hipMalloc((void **) &lb->mom_work,
 		sizeof(double)*12*(size_t) lbmi_k_moments_nblk()) != hipSuccess ||
@@ -346,7 +348,7 @@ int lbmi_free(lbmi_t * lb) {
   hipEventDestroy(lb->ev_ready);
   hipEventDestroy(lb->ev_halo);
   hipStreamDestroy(lb->comm_stream);
-  hipStreamDestroy(lb->stream);
+  hipStreamDestroy(lb->own_stream);
   free(lb);
 
   return 0;
@@ -1283,6 +1285,16 @@ int lbmi_synchronize(lbmi_t * lb) {
   HIPCHECK(hipSetDevice(lb->device));
   HIPCHECK(hipStreamSynchronize(lb->comm_stream));
   HIPCHECK(hipStreamSynchronize(lb->stream));
+  return 0;
+}
+
+int lbmi_set_stream(lbmi_t * lb, void * stream) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  HIPCHECK(hipSetDevice(lb->device));
+  HIPCHECK(hipStreamSynchronize(lb->comm_stream));
+  HIPCHECK(hipStreamSynchronize(lb->stream));
+  lb->stream = (hipStream_t) stream;
+  lb->nev = 0;                       /* timing events belong to a stream */
   return 0;
 }
 

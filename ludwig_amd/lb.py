@@ -76,7 +76,14 @@ class LB:
     """lb_t: the distributions of one rank and the operators of a time step."""
 
     def __init__(self, nvel=19, nlocal=(64, 64, 64), nhalo=1, mode=EAGER,
-                 halo_scheme=HALO_FULL, device=0, cartsz=1, cartrank=0):
+                 halo_scheme=HALO_FULL, device=0, cartsz=1, cartrank=0,
+                 own_stream=False):
+        """own_stream=False (default): the library works on torch's current
+        stream of `device`, so its kernels are ordered with torch operations
+        on the same tensors. own_stream=True keeps the handle's private
+        non-blocking stream: then the caller must synchronise explicitly
+        (lb.synchronize() / torch.cuda.synchronize()) between torch
+        operations and library calls that touch the same memory."""
         torch = _torch()
         self._lib = _l.library()
         self._h = ctypes.c_void_p()
@@ -104,6 +111,9 @@ class LB:
                               device=self.device)
         self._b = torch.zeros_like(self._a)
         torch.cuda.synchronize(self.device)
+        if not own_stream:
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _l.check(self._lib.lbmi_set_stream(self._h, ctypes.c_void_p(st)))
         _l.check(self._lib.lbmi_lb_bind(self._h, _ptr(self._a), _ptr(self._b)))
 
     # -- life cycle ---------------------------------------------------------

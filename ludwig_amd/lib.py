@@ -84,6 +84,7 @@ SYMBOLS = [
     ("lbmi_lb_records_unpack", _i, [_vp, _vp]),
     ("lbmi_synchronize", _i, [_vp]),
     ("lbmi_stream", _i, [_vp, ctypes.POINTER(_vp)]),
+    ("lbmi_set_stream", _i, [_vp, _vp]),
     ("lbmi_timing", _i, [_vp, _i]),
     ("lbmi_timing_read", _i, [_vp, _pd, ctypes.POINTER(_i)]),
     ("lbmi_tune", _i, [_vp, ctypes.c_char_p, _i]),
