@@ -283,9 +283,25 @@ def main():
                 "launches": nlaunch,
                 "achieved_populations_only": round(
                     1e-9 * pop_bytes * local_sites / t_launch, 1),
-                "note": "traffic (PMC FETCH_SIZE/WRITE_SIZE) is collected in "
-                        "separate rocprofv3 passes: see profiles/",
             }
+            # HBM bytes per launch from the PMC counters cannot be collected
+            # inside this process (they need their own rocprofv3 --pmc
+            # passes): quote the committed measurement of the same kernel
+            # on the same workload, if this run is that workload
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+            same = (args.nvel == 19 and tuple(args.size) == (256, 256, 256)
+                    and args.hydro and world == 1 and args.mode == "fused"
+                    and args.scheme == "m10" and args.fe == "none")
+            if same and os.path.exists(pmc):
+                with open(pmc) as fp:
+                    t = json.load(fp)["summary"]
+                roofline["traffic"] = int(t["traffic_bytes"])
+                roofline["traffic_unit"] = "bytes per launch"
+                roofline["traffic_source"] = (
+                    "profiles/r01_pmc_hbm_traffic.json: separate rocprofv3 "
+                    "--pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                    "FETCH_SIZE x2 (gfx950); algorithmic = %d"
+                    % t["algorithmic_bytes_360_per_lup"])
         out = {
             "metric": "MLUPS (million lattice updates/sec) D3Q%d %dx%dx%d"
                       % (args.nvel, *ntotal),
