@@ -208,15 +208,17 @@ def main():
         torch.cuda.synchronize()
 
     def fe_step():
-        # ludwig.c:537-791 for free_energy symmetric (finite difference)
-        lb.hydro_field_set(hydro.force, (0.0, 0.0, 0.0))       # hydro_f_zero
+        # ludwig.c:537-791 for free_energy symmetric (finite difference).
+        # hydro_f_zero is absorbed (the force kernel overwrites: no other
+        # contribution exists in this configuration) and hydro_u_zero is
+        # redundant on an all-fluid lattice (lb_collide writes u everywhere).
         lb.field_halo_n(fe["phi"], 2)                           # field_halo
         lb.field_halo_n(hydro.u, 1)                             # hydro_u_halo
         # phi_force_calculation + phi_cahn_hilliard, one pass over phi
         lb.symmetric_step(fe["a"], fe["b"], fe["kappa"], fe["mobility"],
-                          fe["phi"], hydro.u, hydro.force, fe["phi2"])
+                          fe["phi"], hydro.u, hydro.force, fe["phi2"],
+                          accumulate=False)
         fe["phi"], fe["phi2"] = fe["phi2"], fe["phi"]
-        lb.hydro_field_set(hydro.u, (0.0, 0.0, 0.0))            # hydro_u_zero
 
     def one_step():
         if fe is not None:

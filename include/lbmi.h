@@ -270,10 +270,13 @@ int lbmi_cahn_hilliard(lbmi_t * lb, double a, double b, double kappa,
 
 /* lbmi_symmetric_force (from phi) and lbmi_cahn_hilliard (from phi) in ONE
  * pass: they share the seven (grad, delsq) evaluations around every site.
- * Results identical to the two separate calls. Needs nhalo >= 2. */
+ * Results identical to the two separate calls. Needs nhalo >= 2.
+ * accumulate != 0: force += F (the reference's behaviour after
+ * hydro_f_zero); accumulate == 0: force = F at the interior sites, which
+ * absorbs hydro_f_zero when nothing else contributes to the force field. */
 int lbmi_symmetric_step(lbmi_t * lb, double a, double b, double kappa,
 			double mobility, const double * phi, const double * u,
-			double * force, double * phi_out);
+			double * force, double * phi_out, int accumulate);
 
 /* The on-disk record stream of the distribution files, lb_io_aggr_pack /
  * lb_io_aggr_unpack with lb_write_buf / lb_read_buf (model.c:1385-1430,

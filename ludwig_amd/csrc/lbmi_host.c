@@ -1243,7 +1243,7 @@ int lbmi_cahn_hilliard(lbmi_t * lb, double a, double b, double kappa,
 
 int lbmi_symmetric_step(lbmi_t * lb, double a, double b, double kappa,
 			double mobility, const double * phi, const double * u,
-			double * force, double * phi_out) {
+			double * force, double * phi_out, int accumulate) {
   if (lb == NULL || !phi || !u || !force || !phi_out) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   }
@@ -1251,7 +1251,7 @@ int lbmi_symmetric_step(lbmi_t * lb, double a, double b, double kappa,
   if (lb->kp.nhalo < 2) return lbmi_fail(LBMI_ERR_ARGUMENT, "needs nhalo >= 2");
   HIPCHECK(hipSetDevice(lb->device));
   KCHECK(lbmi_k_symm_fe_step(&lb->kp, a, b, kappa, mobility, phi, u, force,
-			     phi_out, lb->stream));
+			     phi_out, accumulate, lb->stream));
   return 0;
 }
 

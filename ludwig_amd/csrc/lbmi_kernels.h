@@ -126,7 +126,7 @@ int lbmi_k_cahn_hilliard(const lbmi_kparam_t * kp, double a, double b,
 int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, double a, double b,
 			double kappa, double mobility, const double * phi,
 			const double * u, double * force, double * phi_out,
-			void * stream);
+			int accumulate, void * stream);
 
 /* Moments: partial (nblk x 12 doubles workspace) then final (out_dev[9]) */
 int lbmi_k_moments_nblk(void);

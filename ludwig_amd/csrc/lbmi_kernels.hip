@@ -1253,6 +1253,7 @@ void k_cahn_hilliard(lbmi_kparam_t kp, Symm q, double mobility,
  * does not depend on u and the update of phi does not depend on the force,
  * so the two results are exactly those of the separate kernels. */
 
+template <bool ACCUMULATE>
 __global__ __launch_bounds__(BLOCK)
 void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility,
 		    const double * __restrict__ phi,
@@ -1311,9 +1312,18 @@ void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility,
     }
   });
 
-  force[i] += f[0];
-  force[ns + i] += f[1];
-  force[2*ns + i] += f[2];
+  if constexpr (ACCUMULATE) {
+    force[i] += f[0];
+    force[ns + i] += f[1];
+    force[2*ns + i] += f[2];
+  }
+  else {
+    /* hydro_f_zero + add in one store: the caller asserts that nothing
+     * else has contributed to the force field this step */
+    force[i] = f[0];
+    force[ns + i] = f[1];
+    force[2*ns + i] = f[2];
+  }
 
   const double wz = (kp.nlocal[2] == 1) ? 0.0 : 1.0;
   phi_out[i] = phi0 - (+ fhi[0] - flo[0] + fhi[1] - flo[1]
@@ -1911,13 +1921,19 @@ extern "C" int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, double a,
 				   double b, double kappa, double mobility,
 				   const double * phi, const double * u,
 				   double * force, double * phi_out,
-				   void * stream) {
+				   int accumulate, void * stream) {
   hipStream_t st = (hipStream_t) stream;
   Range1D r = interior_range(*kp);
   dim3 grid(r.grid), block(BLOCK);
   Symm q = {a, b, kappa};
-  hipLaunchKernelGGL(k_symm_fe_step, grid, block, 0, st, *kp, q, mobility,
-		     phi, u, force, phi_out, r.i0, r.i1, r.nblk);
+  if (accumulate) {
+    hipLaunchKernelGGL((k_symm_fe_step<true>), grid, block, 0, st, *kp, q,
+		       mobility, phi, u, force, phi_out, r.i0, r.i1, r.nblk);
+  }
+  else {
+    hipLaunchKernelGGL((k_symm_fe_step<false>), grid, block, 0, st, *kp, q,
+		       mobility, phi, u, force, phi_out, r.i0, r.i1, r.nblk);
+  }
   return (int) hipGetLastError();
 }
 

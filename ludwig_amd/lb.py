@@ -275,11 +275,13 @@ class LB:
             self._h, a, b, kappa, mobility, _ptr(phi), _ptr(delsq), _ptr(u),
             _ptr(phi_out)))
 
-    def symmetric_step(self, a, b, kappa, mobility, phi, u, force, phi_out):
-        """symmetric_force + cahn_hilliard (both from phi) in one kernel."""
+    def symmetric_step(self, a, b, kappa, mobility, phi, u, force, phi_out,
+                       accumulate=True):
+        """symmetric_force + cahn_hilliard (both from phi) in one kernel;
+        accumulate=False overwrites the force (absorbs hydro_f_zero)."""
         _l.check(self._lib.lbmi_symmetric_step(
             self._h, a, b, kappa, mobility, _ptr(phi), _ptr(u), _ptr(force),
-            _ptr(phi_out)))
+            _ptr(phi_out), 1 if accumulate else 0))
 
     def lb_io_aggr_pack(self):
         """lb_io_aggr_pack (model.c:1479): the binary record stream as a

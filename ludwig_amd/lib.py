@@ -79,7 +79,7 @@ SYMBOLS = [
     ("lbmi_field_grad_7pt", _i, [_vp, _vp, _vp, _vp]),
     ("lbmi_symmetric_force", _i, [_vp, _d, _d, _d, _vp, _vp, _vp, _vp]),
     ("lbmi_cahn_hilliard", _i, [_vp, _d, _d, _d, _d, _vp, _vp, _vp, _vp]),
-    ("lbmi_symmetric_step", _i, [_vp, _d, _d, _d, _d, _vp, _vp, _vp, _vp]),
+    ("lbmi_symmetric_step", _i, [_vp, _d, _d, _d, _d, _vp, _vp, _vp, _vp, _i]),
     ("lbmi_lb_records_pack", _i, [_vp, _vp]),
     ("lbmi_lb_records_unpack", _i, [_vp, _vp]),
     ("lbmi_synchronize", _i, [_vp]),

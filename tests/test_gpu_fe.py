@@ -234,4 +234,9 @@ def test_symmetric_step_equals_separate_kernels(name):
     assert relmax(interior(_host(lb, o2), h), interior(g["phi_new"], h)) < 1e-12
     assert relmax(_host(lb, f2), _host(lb, f1)) < 1e-14
     assert relmax(_host(lb, o2), _host(lb, o1)) < 1e-14
+    # overwrite mode: same force regardless of what was there
+    f3 = torch.full_like(f1, 123.0)
+    torch.cuda.synchronize()
+    lb.symmetric_step(*args, meta["mobility"], phi, u, f3, o2, accumulate=False)
+    assert np.array_equal(interior(_host(lb, f3), h), interior(_host(lb, f2), h))
     lb.free()
