@@ -296,11 +296,12 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   /* Defaults of the reference: rho0 = 1, eta = zeta = 1/6 (physics.c:33-56) */
   lbmi_set_relaxation(lb, LBMI_RELAXATION_M10, 1.0, 1.0/6.0, 1.0/6.0);
 
+  /* lbmi_free() releases whatever exists so far (members start as NULL) */
   if (hipStreamCreateWithFlags(&lb->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&lb->comm_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&lb->ev_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&lb->ev_halo, hipEventDisableTiming) != hipSuccess) {
-    free(lb);
+    lbmi_free(lb);
     return lbmi_fail(LBMI_ERR_HIP, "stream/event creation failed");
   }
   lb->stream = lb->own_stream;
@@ -308,7 +309,7 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   if (hipMalloc((void **) &lb->mom_work,
 		sizeof(double)*12*(size_t) lbmi_k_moments_nblk()) != hipSuccess ||
       hipMalloc((void **) &lb->mom_out, sizeof(double)*16) != hipSuccess) {
-    free(lb);
+    lbmi_free(lb);
     return lbmi_fail(LBMI_ERR_HIP, "hipMalloc (moments workspace) failed");
   }
 
@@ -328,8 +329,8 @@ int lbmi_free(lbmi_t * lb) {
   if (lb == NULL) return 0;
 
   hipSetDevice(lb->device);
-  hipStreamSynchronize(lb->stream);
-  hipStreamSynchronize(lb->comm_stream);
+  if (lb->own_stream) hipStreamSynchronize(lb->stream);
+  if (lb->comm_stream) hipStreamSynchronize(lb->comm_stream);
 
   lbmi_comm_free(lb);
 
@@ -337,18 +338,18 @@ int lbmi_free(lbmi_t * lb) {
     hipFree(lb->f);
     hipFree(lb->fprime);
   }
-  hipFree(lb->mom_work);
-  hipFree(lb->mom_out);
+  if (lb->mom_work) hipFree(lb->mom_work);
+  if (lb->mom_out) hipFree(lb->mom_out);
   if (lb->ev_created) {
     for (int n = 0; n < LBMI_NEVENT; n++) {
-      hipEventDestroy(lb->ev0[n]);
-      hipEventDestroy(lb->ev1[n]);
+      if (lb->ev0[n]) hipEventDestroy(lb->ev0[n]);
+      if (lb->ev1[n]) hipEventDestroy(lb->ev1[n]);
     }
   }
-  hipEventDestroy(lb->ev_ready);
-  hipEventDestroy(lb->ev_halo);
-  hipStreamDestroy(lb->comm_stream);
-  hipStreamDestroy(lb->own_stream);
+  if (lb->ev_ready) hipEventDestroy(lb->ev_ready);
+  if (lb->ev_halo) hipEventDestroy(lb->ev_halo);
+  if (lb->comm_stream) hipStreamDestroy(lb->comm_stream);
+  if (lb->own_stream) hipStreamDestroy(lb->own_stream);
   free(lb);
 
   return 0;
@@ -463,11 +464,11 @@ static lbmi_hydro_dev_t lbmi_hydro_dev(const lbmi_hydro_t * hydro) {
 static int lbmi_time_begin(lbmi_t * lb) {
   if (!lb->timing) return 0;
   if (!lb->ev_created) {
+    lb->ev_created = 1;               /* lbmi_free destroys the non-NULL ones */
     for (int n = 0; n < LBMI_NEVENT; n++) {
       HIPCHECK(hipEventCreate(&lb->ev0[n]));
       HIPCHECK(hipEventCreate(&lb->ev1[n]));
     }
-    lb->ev_created = 1;
   }
   if (lb->nev == LBMI_NEVENT) {
     double ms; int n;
@@ -1343,10 +1344,13 @@ int lbmi_comm_init(lbmi_t * lb, const void * id) {
    * or a generic field of up to LBMI_NVEL_MAX components) */
   lb->xbuf_doubles = (size_t) lb->kp.strx*LBMI_NVEL_MAX;
   bytes = sizeof(double)*lb->xbuf_doubles;
-  HIPCHECK(hipMalloc((void **) &lb->sendlo, bytes));
-  HIPCHECK(hipMalloc((void **) &lb->sendhi, bytes));
-  HIPCHECK(hipMalloc((void **) &lb->recvlo, bytes));
-  HIPCHECK(hipMalloc((void **) &lb->recvhi, bytes));
+  if (hipMalloc((void **) &lb->sendlo, bytes) != hipSuccess ||
+      hipMalloc((void **) &lb->sendhi, bytes) != hipSuccess ||
+      hipMalloc((void **) &lb->recvlo, bytes) != hipSuccess ||
+      hipMalloc((void **) &lb->recvhi, bytes) != hipSuccess) {
+    lbmi_comm_free(lb);
+    return lbmi_fail(LBMI_ERR_HIP, "hipMalloc (halo staging buffers) failed");
+  }
 
   return 0;
 }
@@ -1354,8 +1358,10 @@ int lbmi_comm_init(lbmi_t * lb, const void * id) {
 int lbmi_comm_free(lbmi_t * lb) {
   if (lb == NULL) return 0;
   if (lb->have_comm) {
-    hipFree(lb->sendlo); hipFree(lb->sendhi);
-    hipFree(lb->recvlo); hipFree(lb->recvhi);
+    if (lb->sendlo) hipFree(lb->sendlo);
+    if (lb->sendhi) hipFree(lb->sendhi);
+    if (lb->recvlo) hipFree(lb->recvlo);
+    if (lb->recvhi) hipFree(lb->recvhi);
     lb->sendlo = lb->sendhi = lb->recvlo = lb->recvhi = NULL;
     ncclCommDestroy(lb->comm);
     lb->have_comm = 0;
