@@ -61,7 +61,7 @@ def parse():
                     "unpack, interior/boundary split)")
     ap.add_argument("--tune", default="", help="key=value,... (lbmi_tune)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
-    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
 
 
@@ -76,21 +76,33 @@ def cpu_baseline(args):
     sample = "%dx%dx%d %s, %d steps after 1 warm-up" % (*size, args.scheme,
                                                          args.cpu_steps)
     if os.path.exists(exe):
-        env = dict(os.environ, OMP_NUM_THREADS=str(cores))
-        try:
-            out = subprocess.run(
-                [exe, "time", *map(str, size), args.scheme, "0.1", repr(zeta),
-                 str(args.cpu_steps)], env=env, check=True,
-                capture_output=True, text=True, timeout=900).stdout
-            r = json.loads(out.strip().splitlines()[-1])
+        # The GPU box gives a process a CPU share of ~16 cores although it
+        # sees all 256 hardware threads; the reference's OpenMP kernels
+        # collapse when oversubscribed (8 MLUPS at 256 threads against 53-56
+        # at 16-32, profiles/r01_cpu_baseline_threads.txt). Time it at 16 and
+        # at 32 threads and report the better one.
+        best = None
+        for nthr in sorted({min(16, cores), min(32, cores)}):
+            env = dict(os.environ, OMP_NUM_THREADS=str(nthr))
+            try:
+                out = subprocess.run(
+                    [exe, "time", *map(str, size), args.scheme, "0.1",
+                     repr(zeta), str(args.cpu_steps)], env=env, check=True,
+                    capture_output=True, text=True, timeout=900).stdout
+                r = json.loads(out.strip().splitlines()[-1])
+                if best is None or r["mlups"] > best["mlups"]:
+                    best = r
+            except Exception as e:      # fall through to the port
+                sys.stderr.write("cpu_baseline: reference run failed: %r\n" % e)
+        if best is not None:
+            r = best
             return {"value": round(r["mlups"], 3), "unit": "MLUPS",
-                    "cores": cores, "kind": "reference",
-                    "sample": sample + " (reference built -O2 -DNDEBUG "
-                    "-fopenmp, AoS, lb_collide+lb_halo+lb_propagation; "
-                    "t_collide/halo/prop = %.3f/%.3f/%.3f s)"
+                    "cores": r["threads"], "kind": "reference",
+                    "sample": sample + " (the reference itself, oracle/_ref: "
+                    "gcc -O2 -DNDEBUG -fopenmp, its default AoS order, "
+                    "lb_collide+lb_halo+lb_propagation; best of 16/32 OpenMP "
+                    "threads; t_collide/halo/prop = %.3f/%.3f/%.3f s)"
                     % (r["t_collide"], r["t_halo"], r["t_propagation"])}
-        except Exception as e:      # fall through to the port
-            sys.stderr.write("cpu_baseline: reference run failed: %r\n" % e)
     import numpy as np
     from oracle import lb_oracle as lbo
     os.environ["OMP_NUM_THREADS"] = str(cores)
