@@ -239,11 +239,26 @@ int lbmi_hydro_field_set(lbmi_t * lb, double * field, int ncomp,
  * symmetric free energy: 2). Single rank. */
 int lbmi_field_halo_n(lbmi_t * lb, int nel, int nswap, double * data);
 
+/* The finite-difference choices of the free-energy sector, as the input
+ * keys fd_gradient_calculation (3d_7pt_fluid | 3d_27pt_fluid; gradient_rt.c)
+ * and fd_advection_scheme_order (advection_order_set, advection.c:93-97;
+ * orders 1..4 of advection_x, advection.c:433-482) select them. Defaults 7
+ * and 1, the reference's. They apply to every lbmi_* free-energy call below
+ * that evaluates gradients or fluxes itself. Orders 3 and 4 need nhalo >= 2
+ * and a 2-layer halo of phi. */
+int lbmi_fe_scheme_set(lbmi_t * lb, int grad_npt, int advection_order);
+
 /* field_grad_compute with grad_3d_7pt_fluid_d2 (gradient_3d_7pt_fluid.c:
- * 232-320): grad (3*nsite, SoA) and delsq (nsite) of the scalar phi for
- * the interior and nhalo-1 layers around it. phi needs a valid halo. */
+ * 232-320) / grad_3d_27pt_fluid_d2 (gradient_3d_27pt_fluid.c:85-364): grad
+ * (3*nsite, SoA) and delsq (nsite) of the scalar phi for the interior and
+ * nhalo-1 layers around it. phi needs a valid halo. lbmi_field_grad uses
+ * the stencil of lbmi_fe_scheme_set. */
 int lbmi_field_grad_7pt(lbmi_t * lb, const double * phi, double * grad,
 			double * delsq);
+int lbmi_field_grad_27pt(lbmi_t * lb, const double * phi, double * grad,
+			 double * delsq);
+int lbmi_field_grad(lbmi_t * lb, const double * phi, double * grad,
+		    double * delsq);
 
 /* phi_force_calculation for the symmetric free energy with the stress-
  * divergence method and no walls (phi_force.c:100-108 = pth_stress_compute
@@ -257,9 +272,9 @@ int lbmi_symmetric_force(lbmi_t * lb, double a, double b, double kappa,
 			 const double * delsq, double * force);
 
 /* phi_cahn_hilliard (phi_cahn_hilliard.c:195-284) for the symmetric free
- * energy without noise, walls or Lees-Edwards planes: first-order upwind
- * advection in u (advection.c:542-640), diffusive flux -M grad mu,
- * forward step. phi (valid halo: 1 layer with delsq given, 2 layers with
+ * energy without noise, walls or Lees-Edwards planes: advection in u at the
+ * order of lbmi_fe_scheme_set (advection.c:433-482), diffusive flux -M grad
+ * mu, forward step. phi (valid halo: 1 layer with delsq given, 2 layers with
  * delsq == NULL), u = hydro->u with a valid 1-layer halo (hydro_u_halo);
  * the new interior goes to phi_out (!= phi). The reference updates phi in
  * place through four flux arrays; the caller here swaps the two arrays. */
@@ -277,6 +292,16 @@ int lbmi_cahn_hilliard(lbmi_t * lb, double a, double b, double kappa,
 int lbmi_symmetric_step(lbmi_t * lb, double a, double b, double kappa,
 			double mobility, const double * phi, const double * u,
 			double * force, double * phi_out, int accumulate);
+
+/* The same single pass, with the gradients taken from the arrays grad and
+ * delsq of lbmi_field_grad (valid on the interior and one layer around it)
+ * instead of re-evaluated from phi: the cheaper route for the 27-point
+ * stencil, where one evaluation costs 27 loads. */
+int lbmi_symmetric_step_grad(lbmi_t * lb, double a, double b, double kappa,
+			     double mobility, const double * phi,
+			     const double * grad, const double * delsq,
+			     const double * u, double * force,
+			     double * phi_out, int accumulate);
 
 /* The on-disk record stream of the distribution files, lb_io_aggr_pack /
  * lb_io_aggr_unpack with lb_write_buf / lb_read_buf (model.c:1385-1430,

@@ -64,6 +64,10 @@ struct lbmi_s {
   size_t xbuf_doubles;
   int x_packed;                      /* 1: pack/unpack through buffers */
 
+  /* free-energy sector: gradient stencil (7 | 27), advection order (1..4) */
+  int grad_npt;
+  int adv_order;
+
   /* kernel timing */
   int timing;
   int nev;
@@ -292,6 +296,8 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   lb->kp.xcd_group = 16;
   lb->kp.lds_cap = 65536;
   lb->x_packed = 1;
+  lb->grad_npt = 7;
+  lb->adv_order = 1;
 
   /* Defaults of the reference: rho0 = 1, eta = zeta = 1/6 (physics.c:33-56) */
   lbmi_set_relaxation(lb, LBMI_RELAXATION_M10, 1.0, 1.0/6.0, 1.0/6.0);
@@ -1187,17 +1193,49 @@ int lbmi_field_halo_n(lbmi_t * lb, int nel, int nswap, double * data) {
 
 /* field_grad_compute with grad_3d_7pt_fluid_d2 (gradient_3d_7pt_fluid.c) */
 
+int lbmi_fe_scheme_set(lbmi_t * lb, int grad_npt, int advection_order) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (grad_npt != 7 && grad_npt != 27) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "gradient stencil: 7 or 27 points");
+  }
+  if (advection_order < 1 || advection_order > 4) {
+    /* the reference aborts likewise ("Unexpected advection scheme order",
+     * advection.c:477); its order 5 needs a 3-layer halo and stays out */
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "advection scheme order: 1..4");
+  }
+  if (advection_order > 2 && lb->kp.nhalo < 2) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "advection order 3, 4 needs nhalo >= 2");
+  }
+  lb->grad_npt = grad_npt;
+  lb->adv_order = advection_order;
+  return 0;
+}
+
+static int lbmi_field_grad_npt(lbmi_t * lb, int npt, const double * phi,
+			       double * grad, double * delsq) {
+  if (lb == NULL || !phi || !grad || !delsq) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  /* the reference computes nextra = nhalo - 1 >= 0 layers beyond the
+   * interior and reads one further: it needs the halo to exist */
+  if (lb->kp.nhalo < 1) return lbmi_fail(LBMI_ERR_ARGUMENT, "nhalo < 1");
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_grad(&lb->kp, npt, phi, grad, delsq, lb->stream));
+  return 0;
+}
+
 int lbmi_field_grad_7pt(lbmi_t * lb, const double * phi, double * grad,
 			double * delsq) {
-  if (lb == NULL || !phi || !grad || !delsq) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
-  if (lb->kp.nhalo < 2) {
-    /* the reference computes nextra = nhalo - 1 >= 0 layers beyond the
-     * interior and reads one further: it needs the halo to exist */
-    if (lb->kp.nhalo < 1) return lbmi_fail(LBMI_ERR_ARGUMENT, "nhalo < 1");
-  }
-  HIPCHECK(hipSetDevice(lb->device));
-  KCHECK(lbmi_k_grad_7pt(&lb->kp, phi, grad, delsq, lb->stream));
-  return 0;
+  return lbmi_field_grad_npt(lb, 7, phi, grad, delsq);
+}
+
+int lbmi_field_grad_27pt(lbmi_t * lb, const double * phi, double * grad,
+			 double * delsq) {
+  return lbmi_field_grad_npt(lb, 27, phi, grad, delsq);
+}
+
+int lbmi_field_grad(lbmi_t * lb, const double * phi, double * grad,
+		    double * delsq) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  return lbmi_field_grad_npt(lb, lb->grad_npt, phi, grad, delsq);
 }
 
 /* phi_force_calculation for the symmetric free energy and
@@ -1214,13 +1252,13 @@ int lbmi_symmetric_force(lbmi_t * lb, double a, double b, double kappa,
     return lbmi_fail(LBMI_ERR_ARGUMENT, "force from phi needs nhalo >= 2");
   }
   HIPCHECK(hipSetDevice(lb->device));
-  KCHECK(lbmi_k_symm_force(&lb->kp, a, b, kappa, phi, grad, delsq, force,
-			   lb->stream));
+  KCHECK(lbmi_k_symm_force(&lb->kp, lb->grad_npt, a, b, kappa, phi, grad,
+			   delsq, force, lb->stream));
   return 0;
 }
 
 /* phi_cahn_hilliard (phi_cahn_hilliard.c:195-284) for the symmetric free
- * energy: no noise, no walls, no Lees-Edwards planes, first-order advection */
+ * energy: no noise, no walls, no Lees-Edwards planes */
 
 int lbmi_cahn_hilliard(lbmi_t * lb, double a, double b, double kappa,
 		       double mobility, const double * phi,
@@ -1235,8 +1273,9 @@ int lbmi_cahn_hilliard(lbmi_t * lb, double a, double b, double kappa,
     return lbmi_fail(LBMI_ERR_ARGUMENT, "mu from phi needs nhalo >= 2");
   }
   HIPCHECK(hipSetDevice(lb->device));
-  KCHECK(lbmi_k_cahn_hilliard(&lb->kp, a, b, kappa, mobility, phi, delsq, u,
-			      phi_out, lb->stream));
+  KCHECK(lbmi_k_cahn_hilliard(&lb->kp, lb->grad_npt, lb->adv_order, a, b,
+			      kappa, mobility, phi, delsq, u, phi_out,
+			      lb->stream));
   return 0;
 }
 
@@ -1251,8 +1290,26 @@ int lbmi_symmetric_step(lbmi_t * lb, double a, double b, double kappa,
   if (phi_out == phi) return lbmi_fail(LBMI_ERR_ARGUMENT, "phi_out aliases phi");
   if (lb->kp.nhalo < 2) return lbmi_fail(LBMI_ERR_ARGUMENT, "needs nhalo >= 2");
   HIPCHECK(hipSetDevice(lb->device));
-  KCHECK(lbmi_k_symm_fe_step(&lb->kp, a, b, kappa, mobility, phi, u, force,
+  KCHECK(lbmi_k_symm_fe_step(&lb->kp, lb->grad_npt, lb->adv_order, a, b,
+			     kappa, mobility, phi, NULL, NULL, u, force,
 			     phi_out, accumulate, lb->stream));
+  return 0;
+}
+
+int lbmi_symmetric_step_grad(lbmi_t * lb, double a, double b, double kappa,
+			     double mobility, const double * phi,
+			     const double * grad, const double * delsq,
+			     const double * u, double * force,
+			     double * phi_out, int accumulate) {
+  if (lb == NULL || !phi || !grad || !delsq || !u || !force || !phi_out) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  }
+  if (phi_out == phi) return lbmi_fail(LBMI_ERR_ARGUMENT, "phi_out aliases phi");
+  if (lb->kp.nhalo < 2) return lbmi_fail(LBMI_ERR_ARGUMENT, "needs nhalo >= 2");
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_symm_fe_step(&lb->kp, 0, lb->adv_order, a, b, kappa, mobility,
+			     phi, grad, delsq, u, force, phi_out, accumulate,
+			     lb->stream));
   return 0;
 }
 

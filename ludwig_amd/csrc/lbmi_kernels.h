@@ -112,21 +112,24 @@ int lbmi_k_field_set(const lbmi_kparam_t * kp, int ncomp, double * field,
 
 /* Symmetric free energy (row f2): 7-point gradients; thermodynamic force by
  * stress divergence, from grad/delsq arrays or (grad == NULL) from phi */
-int lbmi_k_grad_7pt(const lbmi_kparam_t * kp, const double * phi,
-		    double * grad, double * delsq, void * stream);
-int lbmi_k_symm_force(const lbmi_kparam_t * kp, double a, double b,
+/* npt: 7 | 27 point gradient stencil (0 in lbmi_k_symm_fe_step: use the
+ * arrays grad, delsq); order: advection scheme order 1..4 */
+int lbmi_k_grad(const lbmi_kparam_t * kp, int npt, const double * phi,
+		double * grad, double * delsq, void * stream);
+int lbmi_k_symm_force(const lbmi_kparam_t * kp, int npt, double a, double b,
 		      double kappa, const double * phi, const double * grad,
 		      const double * delsq, double * force, void * stream);
 
-int lbmi_k_cahn_hilliard(const lbmi_kparam_t * kp, double a, double b,
-			 double kappa, double mobility, const double * phi,
-			 const double * delsq, const double * u,
-			 double * phi_out, void * stream);
+int lbmi_k_cahn_hilliard(const lbmi_kparam_t * kp, int npt, int order,
+			 double a, double b, double kappa, double mobility,
+			 const double * phi, const double * delsq,
+			 const double * u, double * phi_out, void * stream);
 
-int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, double a, double b,
-			double kappa, double mobility, const double * phi,
-			const double * u, double * force, double * phi_out,
-			int accumulate, void * stream);
+int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, int npt, int order,
+			double a, double b, double kappa, double mobility,
+			const double * phi, const double * grad,
+			const double * delsq, const double * u, double * force,
+			double * phi_out, int accumulate, void * stream);
 
 /* Moments: partial (nblk x 12 doubles workspace) then final (out_dev[9]) */
 int lbmi_k_moments_nblk(void);

@@ -1100,10 +1100,83 @@ void grad7(const double * __restrict__ phi, size_t j, int strx, int stry,
   delsq = xp + xm + yp + ym + zp + zm - 6.0*phi[j];
 }
 
+/* grad_3d_27pt_kernel, GRAD_DEL2 (gradient_3d_27pt_fluid.c:216-364):
+ * grad_a = (1/18) sum of the nine differences across the 3x3 plane normal to
+ * a, delsq = (1/9)(sum of the 26 neighbours - 26 phi); summation orders of
+ * the reference (z fastest), so the result is the reference's bit for bit
+ * when the compiler does not contract (it has nothing to contract here). */
+
+__device__ __forceinline__
+void grad27(const double * __restrict__ phi, size_t j, int strx, int stry,
+	    double (&g)[3], double & delsq) {
+  double v[3][3][3];
+  static_for<0, 27>([&](auto N) {
+    constexpr int n = N;
+    constexpr int a = n/9, b = (n/3) % 3, c = n % 3;
+    v[a][b][c] = phi[(ptrdiff_t) j + (a - 1)*strx + (b - 1)*stry + (c - 1)];
+  });
+  const double r9 = (1.0/9.0);
+  double sx = 0.0, sy = 0.0, sz = 0.0, d2 = 0.0;
+  static_for<0, 9>([&](auto N) {
+    constexpr int n = N;
+    constexpr int b = n/3, c = n % 3;
+    sx += v[2][b][c]; sx -= v[0][b][c];
+    sy += v[b][2][c]; sy -= v[b][0][c];
+    sz += v[b][c][2]; sz -= v[b][c][0];
+  });
+  static_for<0, 27>([&](auto N) {
+    constexpr int n = N;
+    if constexpr (n != 13) d2 += v[n/9][(n/3) % 3][n % 3];
+  });
+  d2 -= 26.0*v[1][1][1];
+  g[0] = 0.5*r9*sx;
+  g[1] = 0.5*r9*sy;
+  g[2] = 0.5*r9*sz;
+  delsq = r9*d2;
+}
+
+template <int NPT>
+__device__ __forceinline__
+void grad_at(const double * __restrict__ phi, size_t j, int strx, int stry,
+	     double (&g)[3], double & delsq) {
+  if constexpr (NPT == 27) grad27(phi, j, strx, stry, g, delsq);
+  else grad7(phi, j, strx, stry, g, delsq);
+}
+
+/* Advective flux through the face between the sites l and r = l + s, face
+ * velocity uf (advection_x, advection.c:433-482): order 1 upwind (:542-640),
+ * 2 mean (:790-916), 3 three-point upwind-biased (:977-1176), 4 four-point
+ * centred (:1188-1296). west selects the form the reference uses for the
+ * "west" face of a site (it differs only in the side a zero velocity takes).
+ * The order is uniform over the launch. */
+
+__device__ __forceinline__
+double adv_flux(int order, bool west, double uf,
+		const double * __restrict__ phi, size_t l, int s) {
+  const size_t r = l + s;
+  if (order == 1) {
+    if (west) return uf*((uf > 0.0) ? phi[l] : phi[r]);
+    return uf*((uf < 0.0) ? phi[r] : phi[l]);
+  }
+  if (order == 2) return uf*0.5*(phi[l] + phi[r]);
+  if (order == 3) {
+    const double a1 = -0.213933;
+    const double a2 =  0.927865;
+    const double a3 =  0.286067;
+    const bool down = west ? !(uf > 0.0) : (uf < 0.0);
+    if (down) return uf*(a1*phi[r + s] + a2*phi[r] + a3*phi[l]);
+    return uf*(a1*phi[l - s] + a2*phi[l] + a3*phi[r]);
+  }
+  const double a1 = (1.0/16.0);
+  const double a2 = (9.0/16.0);
+  return uf*(- a1*phi[l - s] + a2*phi[l] + a2*phi[r] - a1*phi[r + s]);
+}
+
+template <int NPT>
 __global__ __launch_bounds__(BLOCK)
-void k_grad_7pt(lbmi_kparam_t kp, const double * __restrict__ phi,
-		double * __restrict__ grad, double * __restrict__ delsq,
-		int i0, int i1) {
+void k_grad(lbmi_kparam_t kp, const double * __restrict__ phi,
+	    double * __restrict__ grad, double * __restrict__ delsq,
+	    int i0, int i1) {
   int i = i0 + (int) (blockIdx.x*BLOCK + threadIdx.x);
   if (i >= i1) return;
   Site s = decode(kp, i);
@@ -1113,14 +1186,14 @@ void k_grad_7pt(lbmi_kparam_t kp, const double * __restrict__ phi,
   if (s.z < nh - ne || s.z >= nh + kp.nlocal[2] + ne) return;
   const size_t ns = (size_t) kp.nsite;
   double g[3], d2;
-  grad7(phi, (size_t) i, kp.strx, kp.stry, g, d2);
+  grad_at<NPT>(phi, (size_t) i, kp.strx, kp.stry, g, d2);
   grad[i] = g[0];
   grad[ns + i] = g[1];
   grad[2*ns + i] = g[2];
   delsq[i] = d2;
 }
 
-template <bool FROM_GRAD>
+template <bool FROM_GRAD, int NPT>
 __global__ __launch_bounds__(BLOCK)
 void k_symm_force(lbmi_kparam_t kp, Symm q, const double * __restrict__ phi,
 		  const double * __restrict__ grad,
@@ -1144,7 +1217,7 @@ void k_symm_force(lbmi_kparam_t kp, Symm q, const double * __restrict__ phi,
       d2 = delsq[j];
     }
     else {
-      grad7(phi, j, kp.strx, kp.stry, g, d2);
+      grad_at<NPT>(phi, j, kp.strx, kp.stry, g, d2);
     }
     symm_stress(q, phi[j], g, d2, st);
   };
@@ -1177,9 +1250,9 @@ void k_symm_force(lbmi_kparam_t kp, Symm q, const double * __restrict__ phi,
  * in registers and writes phi_out (phi_out != phi), 8 B + 24 B (u) read and
  * 8 B written per site. FROM_DELSQ = false takes delsq from phi itself. */
 
-template <bool FROM_DELSQ>
+template <bool FROM_DELSQ, int NPT>
 __global__ __launch_bounds__(BLOCK)
-void k_cahn_hilliard(lbmi_kparam_t kp, Symm q, double mobility,
+void k_cahn_hilliard(lbmi_kparam_t kp, Symm q, double mobility, int order,
 		     const double * __restrict__ phi,
 		     const double * __restrict__ delsq,
 		     const double * __restrict__ u,
@@ -1203,7 +1276,7 @@ void k_cahn_hilliard(lbmi_kparam_t kp, Symm q, double mobility,
     }
     else {
       double g[3];
-      grad7(phi, j, kp.strx, kp.stry, g, d2);
+      grad_at<NPT>(phi, j, kp.strx, kp.stry, g, d2);
     }
     double ph = phi[j];
     return q.a*ph + q.b*ph*ph*ph - q.kappa*d2;
@@ -1219,22 +1292,16 @@ void k_cahn_hilliard(lbmi_kparam_t kp, Symm q, double mobility,
     {
       size_t j = (size_t) (i + str[id]);       /* face (i, i + e_d) */
       double uf = 0.5*(ud0 + u[ns*id + j]);
-      double f = uf*((uf < 0.0) ? phi[j] : phi0);
+      double f = adv_flux(order, false, uf, phi, (size_t) i, str[id]);
       f -= mobility*(mu_at(j) - mu0);
       fhi[id] = f;
     }
     {
+      /* x: the "west" flux of this site; y, z: the +d flux of the site
+       * below, as the reference's update reads them */
       size_t j = (size_t) (i - str[id]);       /* face (i - e_d, i) */
       double uf = 0.5*(ud0 + u[ns*id + j]);
-      double f;
-      if constexpr (id == 0) {
-	/* "west" flux of this site (advection.c:570-584) */
-	f = uf*((uf > 0.0) ? phi[j] : phi0);
-      }
-      else {
-	/* the +d flux of the site below (advection.c:602-636 at i - e_d) */
-	f = uf*((uf < 0.0) ? phi0 : phi[j]);
-      }
+      double f = adv_flux(order, id == 0, uf, phi, j, str[id]);
       f -= mobility*(mu0 - mu_at(j));
       flo[id] = f;
     }
@@ -1253,10 +1320,12 @@ void k_cahn_hilliard(lbmi_kparam_t kp, Symm q, double mobility,
  * does not depend on u and the update of phi does not depend on the force,
  * so the two results are exactly those of the separate kernels. */
 
-template <bool ACCUMULATE>
+template <bool ACCUMULATE, int NPT>
 __global__ __launch_bounds__(BLOCK)
-void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility,
+void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility, int order,
 		    const double * __restrict__ phi,
+		    const double * __restrict__ grad,
+		    const double * __restrict__ delsq,
 		    const double * __restrict__ u,
 		    double * __restrict__ force,
 		    double * __restrict__ phi_out, int i0, int i1,
@@ -1272,10 +1341,17 @@ void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility,
   const size_t ns = (size_t) kp.nsite;
   const int str[3] = {kp.strx, kp.stry, 1};
 
-  /* stress and chemical potential at a site, from phi alone */
+  /* stress and chemical potential at a site: from phi alone (NPT = 7, 27)
+   * or from the gradient arrays (NPT = 0) */
   auto at = [&](size_t j, double (&st)[3][3], double & mu, double & ph) {
     double g[3], d2;
-    grad7(phi, j, kp.strx, kp.stry, g, d2);
+    if constexpr (NPT == 0) {
+      g[0] = grad[j]; g[1] = grad[ns + j]; g[2] = grad[2*ns + j];
+      d2 = delsq[j];
+    }
+    else {
+      grad_at<NPT>(phi, j, kp.strx, kp.stry, g, d2);
+    }
     ph = phi[j];
     symm_stress(q, ph, g, d2, st);
     mu = q.a*ph + q.b*ph*ph*ph - q.kappa*d2;
@@ -1295,7 +1371,7 @@ void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility,
       at(j, pth1, mu1, phi1);
       for (int ia = 0; ia < 3; ia++) f[ia] -= 0.5*(pth1[ia][id] + pth0[ia][id]);
       double uf = 0.5*(ud0 + u[ns*id + j]);
-      double fl = uf*((uf < 0.0) ? phi1 : phi0);
+      double fl = adv_flux(order, false, uf, phi, (size_t) i, str[id]);
       fl -= mobility*(mu1 - mu0);
       fhi[id] = fl;
     }
@@ -1304,9 +1380,7 @@ void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility,
       at(j, pth1, mu1, phi1);
       for (int ia = 0; ia < 3; ia++) f[ia] += 0.5*(pth1[ia][id] + pth0[ia][id]);
       double uf = 0.5*(ud0 + u[ns*id + j]);
-      double fl;
-      if constexpr (id == 0) fl = uf*((uf > 0.0) ? phi1 : phi0);
-      else fl = uf*((uf < 0.0) ? phi0 : phi1);
+      double fl = adv_flux(order, id == 0, uf, phi, j, str[id]);
       fl -= mobility*(mu0 - mu1);
       flo[id] = fl;
     }
@@ -1866,20 +1940,27 @@ extern "C" int lbmi_k_field_set(const lbmi_kparam_t * kp, int ncomp,
   return (int) hipGetLastError();
 }
 
-extern "C" int lbmi_k_grad_7pt(const lbmi_kparam_t * kp, const double * phi,
-			       double * grad, double * delsq, void * stream) {
+extern "C" int lbmi_k_grad(const lbmi_kparam_t * kp, int npt,
+			   const double * phi, double * grad, double * delsq,
+			   void * stream) {
   hipStream_t st = (hipStream_t) stream;
   int ne = kp->nhalo - 1;
   int i0 = (kp->nhalo - ne)*kp->strx;
   int i1 = (kp->nhalo + kp->nlocal[0] + ne)*kp->strx;
   dim3 grid((unsigned) ((i1 - i0 + BLOCK - 1)/BLOCK)), block(BLOCK);
-  hipLaunchKernelGGL(k_grad_7pt, grid, block, 0, st, *kp, phi, grad, delsq,
-		     i0, i1);
+  if (npt == 27) {
+    hipLaunchKernelGGL((k_grad<27>), grid, block, 0, st, *kp, phi, grad,
+		       delsq, i0, i1);
+  }
+  else {
+    hipLaunchKernelGGL((k_grad<7>), grid, block, 0, st, *kp, phi, grad, delsq,
+		       i0, i1);
+  }
   return (int) hipGetLastError();
 }
 
-extern "C" int lbmi_k_symm_force(const lbmi_kparam_t * kp, double a, double b,
-				 double kappa, const double * phi,
+extern "C" int lbmi_k_symm_force(const lbmi_kparam_t * kp, int npt, double a,
+				 double b, double kappa, const double * phi,
 				 const double * grad, const double * delsq,
 				 double * force, void * stream) {
   hipStream_t st = (hipStream_t) stream;
@@ -1887,18 +1968,23 @@ extern "C" int lbmi_k_symm_force(const lbmi_kparam_t * kp, double a, double b,
   dim3 grid(r.grid), block(BLOCK);
   Symm q = {a, b, kappa};
   if (grad && delsq) {
-    hipLaunchKernelGGL((k_symm_force<true>), grid, block, 0, st, *kp, q, phi,
-		       grad, delsq, force, r.i0, r.i1, r.nblk);
+    hipLaunchKernelGGL((k_symm_force<true, 7>), grid, block, 0, st, *kp, q,
+		       phi, grad, delsq, force, r.i0, r.i1, r.nblk);
+  }
+  else if (npt == 27) {
+    hipLaunchKernelGGL((k_symm_force<false, 27>), grid, block, 0, st, *kp, q,
+		       phi, grad, delsq, force, r.i0, r.i1, r.nblk);
   }
   else {
-    hipLaunchKernelGGL((k_symm_force<false>), grid, block, 0, st, *kp, q, phi,
-		       grad, delsq, force, r.i0, r.i1, r.nblk);
+    hipLaunchKernelGGL((k_symm_force<false, 7>), grid, block, 0, st, *kp, q,
+		       phi, grad, delsq, force, r.i0, r.i1, r.nblk);
   }
   return (int) hipGetLastError();
 }
 
-extern "C" int lbmi_k_cahn_hilliard(const lbmi_kparam_t * kp, double a,
-				    double b, double kappa, double mobility,
+extern "C" int lbmi_k_cahn_hilliard(const lbmi_kparam_t * kp, int npt,
+				    int order, double a, double b,
+				    double kappa, double mobility,
 				    const double * phi, const double * delsq,
 				    const double * u, double * phi_out,
 				    void * stream) {
@@ -1907,32 +1993,66 @@ extern "C" int lbmi_k_cahn_hilliard(const lbmi_kparam_t * kp, double a,
   dim3 grid(r.grid), block(BLOCK);
   Symm q = {a, b, kappa};
   if (delsq) {
-    hipLaunchKernelGGL((k_cahn_hilliard<true>), grid, block, 0, st, *kp, q,
-		       mobility, phi, delsq, u, phi_out, r.i0, r.i1, r.nblk);
+    hipLaunchKernelGGL((k_cahn_hilliard<true, 7>), grid, block, 0, st, *kp, q,
+		       mobility, order, phi, delsq, u, phi_out, r.i0, r.i1,
+		       r.nblk);
+  }
+  else if (npt == 27) {
+    hipLaunchKernelGGL((k_cahn_hilliard<false, 27>), grid, block, 0, st, *kp,
+		       q, mobility, order, phi, delsq, u, phi_out, r.i0, r.i1,
+		       r.nblk);
   }
   else {
-    hipLaunchKernelGGL((k_cahn_hilliard<false>), grid, block, 0, st, *kp, q,
-		       mobility, phi, delsq, u, phi_out, r.i0, r.i1, r.nblk);
+    hipLaunchKernelGGL((k_cahn_hilliard<false, 7>), grid, block, 0, st, *kp,
+		       q, mobility, order, phi, delsq, u, phi_out, r.i0, r.i1,
+		       r.nblk);
   }
   return (int) hipGetLastError();
 }
 
-extern "C" int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, double a,
-				   double b, double kappa, double mobility,
-				   const double * phi, const double * u,
+/* npt = 7 or 27: everything from phi; npt = 0: from the arrays grad, delsq */
+
+template <bool ACCUMULATE>
+static void launch_fe_step(const lbmi_kparam_t * kp, int npt, int order,
+			   Symm q, double mobility, const double * phi,
+			   const double * grad, const double * delsq,
+			   const double * u, double * force, double * phi_out,
+			   hipStream_t st) {
+  Range1D r = interior_range(*kp);
+  dim3 grid(r.grid), block(BLOCK);
+  if (npt == 0) {
+    hipLaunchKernelGGL((k_symm_fe_step<ACCUMULATE, 0>), grid, block, 0, st,
+		       *kp, q, mobility, order, phi, grad, delsq, u, force,
+		       phi_out, r.i0, r.i1, r.nblk);
+  }
+  else if (npt == 27) {
+    hipLaunchKernelGGL((k_symm_fe_step<ACCUMULATE, 27>), grid, block, 0, st,
+		       *kp, q, mobility, order, phi, grad, delsq, u, force,
+		       phi_out, r.i0, r.i1, r.nblk);
+  }
+  else {
+    hipLaunchKernelGGL((k_symm_fe_step<ACCUMULATE, 7>), grid, block, 0, st,
+		       *kp, q, mobility, order, phi, grad, delsq, u, force,
+		       phi_out, r.i0, r.i1, r.nblk);
+  }
+}
+
+extern "C" int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, int npt,
+				   int order, double a, double b,
+				   double kappa, double mobility,
+				   const double * phi, const double * grad,
+				   const double * delsq, const double * u,
 				   double * force, double * phi_out,
 				   int accumulate, void * stream) {
   hipStream_t st = (hipStream_t) stream;
-  Range1D r = interior_range(*kp);
-  dim3 grid(r.grid), block(BLOCK);
   Symm q = {a, b, kappa};
   if (accumulate) {
-    hipLaunchKernelGGL((k_symm_fe_step<true>), grid, block, 0, st, *kp, q,
-		       mobility, phi, u, force, phi_out, r.i0, r.i1, r.nblk);
+    launch_fe_step<true>(kp, npt, order, q, mobility, phi, grad, delsq, u,
+			 force, phi_out, st);
   }
   else {
-    hipLaunchKernelGGL((k_symm_fe_step<false>), grid, block, 0, st, *kp, q,
-		       mobility, phi, u, force, phi_out, r.i0, r.i1, r.nblk);
+    launch_fe_step<false>(kp, npt, order, q, mobility, phi, grad, delsq, u,
+			  force, phi_out, st);
   }
   return (int) hipGetLastError();
 }

@@ -258,10 +258,26 @@ class LB:
         nel = 1 if data.dim() == 3 else data.shape[0]
         _l.check(self._lib.lbmi_field_halo_n(self._h, nel, nswap, _ptr(data)))
 
+    def fe_scheme_set(self, grad_npt=7, advection_order=1):
+        """fd_gradient_calculation 3d_7pt_fluid | 3d_27pt_fluid and
+        fd_advection_scheme_order 1..4 (advection_order_set)."""
+        _l.check(self._lib.lbmi_fe_scheme_set(self._h, int(grad_npt),
+                                              int(advection_order)))
+
     def field_grad_7pt(self, phi, grad, delsq):
         """field_grad_compute (grad_3d_7pt_fluid)."""
         _l.check(self._lib.lbmi_field_grad_7pt(self._h, _ptr(phi), _ptr(grad),
                                                _ptr(delsq)))
+
+    def field_grad_27pt(self, phi, grad, delsq):
+        """field_grad_compute (grad_3d_27pt_fluid)."""
+        _l.check(self._lib.lbmi_field_grad_27pt(self._h, _ptr(phi), _ptr(grad),
+                                                _ptr(delsq)))
+
+    def field_grad(self, phi, grad, delsq):
+        """field_grad_compute with the stencil of fe_scheme_set."""
+        _l.check(self._lib.lbmi_field_grad(self._h, _ptr(phi), _ptr(grad),
+                                           _ptr(delsq)))
 
     def symmetric_force(self, a, b, kappa, phi, force, grad=None, delsq=None):
         """phi_force_calculation (symmetric, stress divergence): force += F."""
@@ -270,7 +286,7 @@ class LB:
             _ptr(force)))
 
     def cahn_hilliard(self, a, b, kappa, mobility, phi, u, phi_out, delsq=None):
-        """phi_cahn_hilliard (symmetric; order-1 advection): phi_out <- step(phi)."""
+        """phi_cahn_hilliard (symmetric): phi_out <- step(phi)."""
         _l.check(self._lib.lbmi_cahn_hilliard(
             self._h, a, b, kappa, mobility, _ptr(phi), _ptr(delsq), _ptr(u),
             _ptr(phi_out)))
@@ -282,6 +298,14 @@ class LB:
         _l.check(self._lib.lbmi_symmetric_step(
             self._h, a, b, kappa, mobility, _ptr(phi), _ptr(u), _ptr(force),
             _ptr(phi_out), 1 if accumulate else 0))
+
+    def symmetric_step_grad(self, a, b, kappa, mobility, phi, grad, delsq, u,
+                            force, phi_out, accumulate=True):
+        """symmetric_step with the gradients read from the arrays of
+        field_grad instead of re-evaluated from phi."""
+        _l.check(self._lib.lbmi_symmetric_step_grad(
+            self._h, a, b, kappa, mobility, _ptr(phi), _ptr(grad), _ptr(delsq),
+            _ptr(u), _ptr(force), _ptr(phi_out), 1 if accumulate else 0))
 
     def lb_io_aggr_pack(self):
         """lb_io_aggr_pack (model.c:1479): the binary record stream as a

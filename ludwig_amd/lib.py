@@ -76,10 +76,15 @@ SYMBOLS = [
     ("lbmi_lb_moments", _i, [_vp, _vp, _pd]),
     ("lbmi_hydro_field_set", _i, [_vp, _vp, _i, _pd]),
     ("lbmi_field_halo_n", _i, [_vp, _i, _i, _vp]),
+    ("lbmi_fe_scheme_set", _i, [_vp, _i, _i]),
     ("lbmi_field_grad_7pt", _i, [_vp, _vp, _vp, _vp]),
+    ("lbmi_field_grad_27pt", _i, [_vp, _vp, _vp, _vp]),
+    ("lbmi_field_grad", _i, [_vp, _vp, _vp, _vp]),
     ("lbmi_symmetric_force", _i, [_vp, _d, _d, _d, _vp, _vp, _vp, _vp]),
     ("lbmi_cahn_hilliard", _i, [_vp, _d, _d, _d, _d, _vp, _vp, _vp, _vp]),
     ("lbmi_symmetric_step", _i, [_vp, _d, _d, _d, _d, _vp, _vp, _vp, _vp, _i]),
+    ("lbmi_symmetric_step_grad", _i, [_vp, _d, _d, _d, _d, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _i]),
     ("lbmi_lb_records_pack", _i, [_vp, _vp]),
     ("lbmi_lb_records_unpack", _i, [_vp, _vp]),
     ("lbmi_synchronize", _i, [_vp]),

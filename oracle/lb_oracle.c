@@ -738,6 +738,72 @@ int lbo_grad_7pt(const lbo_param_t * p, const double * phi, double * grad,
 }
 
 /*
+ * lbo_grad_27pt
+ *
+ * grad_3d_27pt_kernel, GRAD_DEL2 (gradient_3d_27pt_fluid.c:216-364, no
+ * Lees-Edwards planes): grad_a = (1/18) sum over the nine pairs of the 3x3
+ * plane normal to a of (phi(+e_a) - phi(-e_a)); delsq = (1/9) (sum of the 26
+ * neighbours - 26 phi). Same extent as lbo_grad_7pt. Summation orders are
+ * the reference's: for grad_x the pairs run over (dy, dz) with dz fastest;
+ * for grad_y over (dx, dz); for grad_z over (dx, dy); the Laplacian runs
+ * over (dx, dy, dz), dz fastest, and subtracts the centre last.
+ */
+
+int lbo_grad_27pt(const lbo_param_t * p, const double * phi, double * grad,
+		  double * delsq) {
+
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+  int nextra = p->nhalo - 1;
+  const double r9 = (1.0/9.0);
+
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+
+  for (int ic = 1 - nextra; ic <= p->nlocal[X] + nextra; ic++) {
+    for (int jc = 1 - nextra; jc <= p->nlocal[Y] + nextra; jc++) {
+      for (int kc = 1 - nextra; kc <= p->nlocal[Z] + nextra; kc++) {
+	ptrdiff_t i = str[X]*(p->nhalo + ic - 1)
+	  + str[Y]*(p->nhalo + jc - 1) + (p->nhalo + kc - 1);
+	double v[3][3][3];
+	double sx = 0.0, sy = 0.0, sz = 0.0, d2 = 0.0;
+
+	for (int a = 0; a < 3; a++) {
+	  for (int b = 0; b < 3; b++) {
+	    for (int c = 0; c < 3; c++) {
+	      v[a][b][c] = phi[i + (a - 1)*str[X] + (b - 1)*str[Y] + (c - 1)];
+	    }
+	  }
+	}
+	for (int b = 0; b < 3; b++) {
+	  for (int c = 0; c < 3; c++) {
+	    sx += v[2][b][c]; sx -= v[0][b][c];
+	    sy += v[b][2][c]; sy -= v[b][0][c];
+	    sz += v[b][c][2]; sz -= v[b][c][0];
+	  }
+	}
+	for (int a = 0; a < 3; a++) {
+	  for (int b = 0; b < 3; b++) {
+	    for (int c = 0; c < 3; c++) {
+	      if (a == 1 && b == 1 && c == 1) continue;
+	      d2 += v[a][b][c];
+	    }
+	  }
+	}
+	d2 -= 26.0*v[1][1][1];
+	grad[0*nsite + i] = 0.5*r9*sx;
+	grad[1*nsite + i] = 0.5*r9*sy;
+	grad[2*nsite + i] = 0.5*r9*sz;
+	delsq[i] = r9*d2;
+      }
+    }
+  }
+
+  return 0;
+}
+
+/*
  * lbo_symm_force
  *
  * Thermodynamic force of the symmetric free energy by stress divergence:
@@ -812,21 +878,59 @@ int lbo_symm_force(const lbo_param_t * p, double a, double b, double kappa,
  * One Cahn-Hilliard step of the symmetric binary fluid as phi_cahn_hilliard
  * runs it without noise, walls or Lees-Edwards planes
  * (phi_cahn_hilliard.c:195-284):
- *   advective fluxes, first-order upwind (advection_le_1st_kernel,
- *   advection.c:542-640): at the face between i and its neighbour the
- *   velocity is the mean of the two site velocities, phi is taken upwind;
+ *   advective fluxes of order 1..4 (advection_x, advection.c:433-482): at
+ *   the face between i and its neighbour the velocity is the mean of the
+ *   two site velocities; phi at the face is upwind (1), the mean (2), a
+ *   three-point upwind-biased (3) or a four-point centred (4) interpolation;
  *   diffusive fluxes -M (mu_1 - mu_0) with mu = a phi + b phi^3 - kappa
  *   delsq (phi_ch_flux_mu1_kernel :349-402, fe_symm_mu symmetric.c:303-316);
  *   forward step phi -= fe - fw + fy - fy(-y) + fz - fz(-z)
  *   (phi_ch_ufs_kernel :1026-1060).
- * u must carry a valid width-1 halo (hydro_u_halo), phi and delsq the
- * width-1 layer around the interior. phi is updated in place at the
+ * u must carry a valid width-1 halo (hydro_u_halo), delsq the width-1 layer
+ * around the interior and phi its width-2 halo (orders 3 and 4 reach two
+ * sites). phi is updated in place at the
  * interior sites; work: 4*nsite doubles (the flux arrays fw, fe, fy, fz).
  */
 
+/* Advective flux through the face between the sites l and l + s (s = the
+ * stride of the face normal), face velocity uf = (u_l + u_{l+s})/2. west = 1
+ * selects the "west" form of the first-order kernel (it differs from the
+ * other only in which side a zero velocity takes). */
+
+static double advective_flux(int order, int west, double uf,
+			     const double * phi, ptrdiff_t l, ptrdiff_t s) {
+  const ptrdiff_t r = l + s;
+  switch (order) {
+  case 1:
+    /* advection_le_1st_kernel (advection.c:542-640) */
+    if (west) return uf*phi[(uf > 0.0) ? l : r];
+    return uf*phi[(uf < 0.0) ? r : l];
+  case 2:
+    /* advection_2nd_kernel_v (advection.c:790-916) */
+    return uf*0.5*(phi[l] + phi[r]);
+  case 3:
+    /* advection_le_3rd_kernel_v (advection.c:977-1176) */
+    {
+      const double a1 = -0.213933;
+      const double a2 =  0.927865;
+      const double a3 =  0.286067;
+      int down = west ? !(uf > 0.0) : (uf < 0.0);
+      if (down) return uf*(a1*phi[r + s] + a2*phi[r] + a3*phi[l]);
+      return uf*(a1*phi[l - s] + a2*phi[l] + a3*phi[r]);
+    }
+  default:
+    /* advection_le_4th (advection.c:1188-1296) */
+    {
+      const double a1 = (1.0/16.0);
+      const double a2 = (9.0/16.0);
+      return uf*(- a1*phi[l - s] + a2*phi[l] + a2*phi[r] - a1*phi[r + s]);
+    }
+  }
+}
+
 int lbo_cahn_hilliard(const lbo_param_t * p, double a, double b, double kappa,
-		      double mobility, double * phi, const double * delsq,
-		      const double * u, double * work) {
+		      double mobility, int order, double * phi,
+		      const double * delsq, const double * u, double * work) {
 
   int nall[3];
   ptrdiff_t str[3];
@@ -850,22 +954,22 @@ int lbo_cahn_hilliard(const lbo_param_t * p, double a, double b, double kappa,
 
 	j = i - str[X];                              /* west face */
 	uf = 0.5*(u[i] + u[j]);
-	fw[i] = uf*phi[(uf > 0.0) ? j : i];
+	fw[i] = advective_flux(order, 1, uf, phi, j, str[X]);
 	fw[i] -= mobility*(mu0 - MU(j));
 
 	j = i + str[X];                              /* east face */
 	uf = 0.5*(u[i] + u[j]);
-	fe[i] = uf*phi[(uf < 0.0) ? j : i];
+	fe[i] = advective_flux(order, 0, uf, phi, i, str[X]);
 	fe[i] -= mobility*(MU(j) - mu0);
 
 	j = i + str[Y];
 	uf = 0.5*(u[nsite + i] + u[nsite + j]);
-	fy[i] = uf*phi[(uf < 0.0) ? j : i];
+	fy[i] = advective_flux(order, 0, uf, phi, i, str[Y]);
 	fy[i] -= mobility*(MU(j) - mu0);
 
 	j = i + 1;
 	uf = 0.5*(u[2*nsite + i] + u[2*nsite + j]);
-	fz[i] = uf*phi[(uf < 0.0) ? j : i];
+	fz[i] = advective_flux(order, 0, uf, phi, i, 1);
 	fz[i] -= mobility*(MU(j) - mu0);
       }
     }

@@ -59,12 +59,14 @@ int lbo_halo_width(const lbo_param_t * p, int nel, double * data, int dirmask,
 		   int nswap);
 int lbo_grad_7pt(const lbo_param_t * p, const double * phi, double * grad,
 		 double * delsq);
+int lbo_grad_27pt(const lbo_param_t * p, const double * phi, double * grad,
+		  double * delsq);
 int lbo_symm_force(const lbo_param_t * p, double a, double b, double kappa,
 		   const double * phi, const double * grad,
 		   const double * delsq, double * force);
 int lbo_cahn_hilliard(const lbo_param_t * p, double a, double b, double kappa,
-		      double mobility, double * phi, const double * delsq,
-		      const double * u, double * work);
+		      double mobility, int order, double * phi,
+		      const double * delsq, const double * u, double * work);
 int lbo_propagate(const lbo_param_t * p, const double * f, double * fprime);
 int lbo_moments(const lbo_param_t * p, const double * f, const char * status,
 		double out[9]);

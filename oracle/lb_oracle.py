@@ -71,9 +71,10 @@ def lib():
         _lib.lbo_halo_width.argtypes = [pp, ctypes.c_int, dp, ctypes.c_int,
                                         ctypes.c_int]
         _lib.lbo_grad_7pt.argtypes = [pp, dp, dp, dp]
+        _lib.lbo_grad_27pt.argtypes = [pp, dp, dp, dp]
         _lib.lbo_cahn_hilliard.argtypes = [pp, ctypes.c_double, ctypes.c_double,
                                            ctypes.c_double, ctypes.c_double,
-                                           dp, dp, dp, dp]
+                                           ctypes.c_int, dp, dp, dp, dp]
         _lib.lbo_symm_force.argtypes = [pp, ctypes.c_double, ctypes.c_double,
                                         ctypes.c_double, dp, dp, dp, dp]
         _lib.lbo_moments.argtypes = [pp, dp, dp, dp]
@@ -168,17 +169,29 @@ def grad_7pt(p, phi):
     return grad, delsq
 
 
+def grad_27pt(p, phi):
+    grad = np.zeros((3,) + phi.shape)
+    delsq = np.zeros(phi.shape)
+    rc = lib().lbo_grad_27pt(ctypes.byref(p), _ptr(phi), _ptr(grad), _ptr(delsq))
+    assert rc == 0
+    return grad, delsq
+
+
+def grad(p, phi, npt=7):
+    return grad_27pt(p, phi) if npt == 27 else grad_7pt(p, phi)
+
+
 def symm_force(p, a, b, kappa, phi, grad, delsq, force):
     rc = lib().lbo_symm_force(ctypes.byref(p), a, b, kappa, _ptr(phi),
                               _ptr(grad), _ptr(delsq), _ptr(force))
     assert rc == 0
 
 
-def cahn_hilliard(p, a, b, kappa, mobility, phi, delsq, u):
+def cahn_hilliard(p, a, b, kappa, mobility, phi, delsq, u, order=1):
     """phi_cahn_hilliard (no noise/walls/LE): phi updated in place."""
     work = np.zeros((4,) + phi.shape)
     rc = lib().lbo_cahn_hilliard(ctypes.byref(p), a, b, kappa, mobility,
-                                 _ptr(phi), _ptr(delsq), _ptr(u), _ptr(work))
+                                 int(order), _ptr(phi), _ptr(delsq), _ptr(u), _ptr(work))
     assert rc == 0
 
 

@@ -80,22 +80,27 @@ def run_case(case, tmp):
     return out
 
 
+# name, (nx, ny, nz), a, b, kappa, mobility, gradient stencil, advection order
 FE_CASES = [
-    ("fe_symm_a", (6, 5, 4), -0.0625, 0.0625, 0.04, 0.15),
-    ("fe_symm_b", (5, 8, 7), -0.00625, 0.00625, 0.004, 1.25),
+    ("fe_symm_a", (6, 5, 4), -0.0625, 0.0625, 0.04, 0.15, 7, 1),
+    ("fe_symm_b", (5, 8, 7), -0.00625, 0.00625, 0.004, 1.25, 7, 1),
+    ("fe_symm_c", (6, 5, 4), -0.0625, 0.0625, 0.04, 0.15, 27, 2),
+    ("fe_symm_d", (5, 8, 7), -0.00625, 0.00625, 0.004, 1.25, 27, 3),
+    ("fe_symm_e", (7, 6, 5), -0.0625, 0.0625, 0.04, 0.15, 7, 4),
 ]
 
 
 def run_fe_case(case, tmp):
     """Symmetric free-energy force chain (row f2): phi with its width-2 halo,
-    grad/delsq of grad_3d_7pt_fluid, force of pth_stress_compute +
-    pth_force_fluid_driver; u (with its halo) and phi_new of
-    phi_cahn_hilliard (first-order advection)."""
-    name, n, a, b, kappa, mobility = case
+    grad/delsq of grad_3d_7pt_fluid or grad_3d_27pt_fluid, force of
+    pth_stress_compute + pth_force_fluid_driver; u (with its halo) and
+    phi_new of phi_cahn_hilliard (advection of order 1..4)."""
+    name, n, a, b, kappa, mobility, gradnpt, advorder = case
     exe = os.path.join(HERE, "_ref", "ref_driver_d3q19")
     prefix = os.path.join(tmp, name)
     subprocess.run([exe, "fe", prefix, *map(str, n), repr(a), repr(b),
-                    repr(kappa), repr(mobility)], check=True)
+                    repr(kappa), repr(mobility), str(gradnpt), str(advorder)],
+                   check=True)
     meta = json.load(open(prefix + ".json"))
     meta["name"] = name
     nall = tuple(meta["nall"])

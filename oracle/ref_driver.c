@@ -27,10 +27,11 @@
  *    ref_driver dump <prefix> nx ny nz nhalo scheme eta zeta fx fy fz \
  *               fieldforce solid nsteps
  *    ref_driver time nx ny nz scheme eta zeta nsteps
- *    ref_driver fe <prefix> nx ny nz a b kappa     (symmetric free energy:
- *               field_halo, field_grad_compute, pth_stress_compute,
- *               pth_force_fluid_driver, then phi_cahn_hilliard with first-
- *               order advection in a prescribed velocity field; nhalo = 2)
+ *    ref_driver fe <prefix> nx ny nz a b kappa mobility [gradnpt advorder]
+ *               (symmetric free energy: field_halo, field_grad_compute with
+ *               the 7- or 27-point stencil, pth_stress_compute,
+ *               pth_force_fluid_driver, then phi_cahn_hilliard with advection
+ *               of order 1..4 in a prescribed velocity field; nhalo = 2)
  *
  *  scheme: m10 | bgk | trt
  *
@@ -60,6 +61,7 @@
 #include "field.h"
 #include "field_grad.h"
 #include "gradient_3d_7pt_fluid.h"
+#include "gradient_3d_27pt_fluid.h"
 #include "symmetric.h"
 #include "phi_force_stress.h"
 #include "phi_force_colloid.h"
@@ -206,6 +208,8 @@ static int run_fe(int argc, char ** argv) {
   int nlocal[3];
 
   double mobility = atof(argv[9]);
+  int gradnpt = (argc == 12) ? atoi(argv[10]) : 7;     /* 7 | 27 */
+  int advorder = (argc == 12) ? atoi(argv[11]) : 1;    /* 1 .. 4 */
   phi_ch_t * pch = NULL;
 
   param.a = atof(argv[6]);
@@ -232,7 +236,8 @@ static int run_fe(int argc, char ** argv) {
     field_create(pe, cs, le, "phi", &opts, &phi);
   }
   field_grad_create(pe, phi, 2, &dphi);
-  field_grad_set(dphi, grad_3d_7pt_fluid_d2, NULL);
+  if (gradnpt == 27) field_grad_set(dphi, grad_3d_27pt_fluid_d2, NULL);
+  else field_grad_set(dphi, grad_3d_7pt_fluid_d2, NULL);
   fe_symm_create(pe, cs, phi, dphi, &fe);
   fe_symm_param_set(fe, param);
   pth_create(pe, cs, FE_FORCE_METHOD_STRESS_DIVERGENCE, &pth);
@@ -283,7 +288,7 @@ static int run_fe(int argc, char ** argv) {
     {
       phi_ch_info_t options = {0};
       phi_ch_create(pe, cs, le, &options, &pch);
-      advection_order_set(1);
+      advection_order_set(advorder);
       for (int ic = 1; ic <= nlocal[X]; ic++) {
 	for (int jc = 1; jc <= nlocal[Y]; jc++) {
 	  for (int kc = 1; kc <= nlocal[Z]; kc++) {
@@ -308,10 +313,11 @@ static int run_fe(int argc, char ** argv) {
     fp = fopen(fn, "w");
     fprintf(fp, "{\"nlocal\": [%d, %d, %d], \"nhalo\": 2, \"nall\": [%d, %d, %d],"
 	    " \"nsite\": %d, \"a\": %.17g, \"b\": %.17g, \"kappa\": %.17g,"
-	    " \"mobility\": %.17g, \"layout\": \"soa\"}\n",
+	    " \"mobility\": %.17g, \"grad_npt\": %d, \"advection_order\": %d,"
+	    " \"layout\": \"soa\"}\n",
 	    ntotal[X], ntotal[Y], ntotal[Z],
 	    nall[X], nall[Y], nall[Z], (int) ns, param.a, param.b, param.kappa,
-	    mobility);
+	    mobility, gradnpt, advorder);
     fclose(fp);
   }
 
@@ -343,7 +349,9 @@ int main(int argc, char ** argv) {
   map_t * map = NULL;
   noise_t * noise = NULL;
 
-  if (argc == 10 && strcmp(argv[1], "fe") == 0) return run_fe(argc, argv);
+  if ((argc == 10 || argc == 12) && strcmp(argv[1], "fe") == 0) {
+    return run_fe(argc, argv);
+  }
 
   if (argc >= 2 && strcmp(argv[1], "dump") == 0 && argc == 16) {
     int a = 2;

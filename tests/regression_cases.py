@@ -72,3 +72,82 @@ def close_as_printed(x, ref, digits_after_point=None, sig=None):
     else:
         tol = 0.5 * 10.0 ** (-digits_after_point)
     return abs(x - ref) <= tol + 1e-12
+
+
+# ---- symmetric free energy: the drop regressions (row f2) -------------------
+
+
+def load_expected_drop():
+    with open(os.path.join(HERE, "golden", "regression_symmetric_drop.json")) as fp:
+        return json.load(fp)
+
+
+def drop_phi(case, nhalo=2):
+    """field_phi_init_drop (field_phi_init.c:38-82), serial, not centred:
+    phi = tanh((r - radius)/xi), r from (L/2, L/2, L/2), xi the interfacial
+    width sqrt(-2 kappa / a) (symmetric.c: fe_symm_interfacial_width)."""
+    n = case["size"]
+    xi = np.sqrt(-2.0 * case["kappa"] / case["a"])
+    ax = [np.arange(1, n[a] + 1, dtype=np.float64) - 0.5 * n[a] for a in range(3)]
+    x, y, z = np.meshgrid(*ax, indexing="ij")
+    r = np.sqrt(x * x + y * y + z * z)
+    phi = np.zeros(tuple(m + 2 * nhalo for m in n))
+    h = nhalo
+    phi[h:-h, h:-h, h:-h] = 1.0 * np.tanh((1.0 / xi) * (r - case["radius"]))
+    return phi
+
+
+def rest_f(model, nall, nhalo):
+    """rho = 1, u = 0: f_p = w_p at the interior sites."""
+    f = np.zeros((model["nvel"],) + tuple(nall))
+    h = nhalo
+    for p in range(model["nvel"]):
+        f[p, h:-h, h:-h, h:-h] = model["wv"][p]
+    return f
+
+
+def drop_report(case, phi, grad, mom, u, nhalo=2):
+    """The quantities ludwig_report_statistics prints for this set-up
+    (stats_distribution.c:55-117, cahn_hilliard_stats.c:96-110,
+    stats_free_energy.c:115-122 with fe_symm_fed symmetric.c:285-299,
+    stats_velocity.c): interior sites only."""
+    h = nhalo
+    s = (slice(h, -h),) * 3
+    ph = phi[s]
+    vol = float(ph.size)
+    g2 = sum(grad[a][s] ** 2 for a in range(3))
+    fed = (0.5 * case["a"] + 0.25 * case["b"] * ph * ph) * ph * ph \
+        + 0.5 * case["kappa"] * g2
+    out = {"phi_total": ph.sum(), "phi_mean": ph.sum() / vol,
+           "phi_var": (ph * ph).sum() / vol - (ph.sum() / vol) ** 2,
+           "phi_min": ph.min(), "phi_max": ph.max(), "fed": fed.sum() / vol}
+    if mom is not None:
+        # stats_distribution_print: rho = sum_p f_p of the propagated
+        # distributions (mom = the moments vector: volume, sum rho,
+        # sum rho^2, min, max, momentum)
+        mean = mom[1] / mom[0]
+        out.update({"rho_total": mom[1], "rho_mean": mean,
+                    "rho_var": mom[2] / mom[0] - mean * mean,
+                    "rho_min": mom[3], "rho_max": mom[4],
+                    "u_min": [u[a][s].min() for a in range(3)],
+                    "u_max": [u[a][s].max() for a in range(3)]})
+    return out
+
+
+def check_drop_report(rep, exp):
+    """Each printed number to its printed precision."""
+    digits = {"rho_total": ("dp", 2), "rho_mean": ("dp", 11),
+              "rho_min": ("dp", 11), "rho_max": ("dp", 11),
+              "rho_var": ("sig", 8), "phi_total": ("sig", 8),
+              "phi_mean": ("sig", 8), "phi_var": ("sig", 8),
+              "phi_min": ("sig", 8), "phi_max": ("sig", 8),
+              "fed": ("sig", 11)}
+    for key, ref in exp.items():
+        if key in ("u_min", "u_max"):
+            for a in range(3):
+                assert close_as_printed(rep[key][a], ref[a], sig=8), (key, a, rep[key][a], ref[a])
+            continue
+        kind, nd = digits[key]
+        ok = (close_as_printed(rep[key], ref, nd) if kind == "dp"
+              else close_as_printed(rep[key], ref, sig=nd))
+        assert ok, (key, rep[key], ref)

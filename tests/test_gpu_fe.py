@@ -1,5 +1,6 @@
-"""Row f2 on the device: width-2 field halo, 7-point gradients and the
-symmetric free-energy force, against the compiled-reference fixtures and the
+"""Row f2 on the device: width-2 field halo, 7- and 27-point gradients, the
+symmetric free-energy force and the Cahn-Hilliard step (advection orders
+1..4), against the compiled-reference fixtures and the
 oracle. Needs an MI355X."""
 
 import numpy as np
@@ -23,6 +24,11 @@ def _host(lb, t):
     return t.cpu().numpy()
 
 
+def _scheme(lb, meta):
+    """The fixture's fd_gradient_calculation / fd_advection_scheme_order."""
+    lb.fe_scheme_set(meta.get("grad_npt", 7), meta.get("advection_order", 1))
+
+
 @pytest.mark.parametrize("name", golden_fe_names())
 def test_field_halo_width2_exact(name):
     import ludwig_amd
@@ -39,22 +45,26 @@ def test_field_halo_width2_exact(name):
 
 
 @pytest.mark.parametrize("name", golden_fe_names())
-def test_gradient_7pt_exact(name):
+def test_gradient_exact(name):
     import ludwig_amd
     import torch
     g = load_golden(name)
     meta = g["meta"]
     lb = ludwig_amd.LB(19, tuple(meta["nlocal"]), meta["nhalo"])
+    _scheme(lb, meta)
     phi = _dev(lb, g["phi"])
     grad = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
     delsq = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
     torch.cuda.synchronize()
-    lb.field_grad_7pt(phi, grad, delsq)
+    lb.field_grad(phi, grad, delsq)
     s = (slice(1, -1),) * 3
-    # differences of two doubles times 0.5, and a fixed-order 7-term sum:
-    # no contraction possible, so bit-exact
-    assert np.array_equal(_host(lb, grad)[(slice(None),) + s],
-                          g["grad"][(slice(None),) + s])
+    # 7-point: differences of two doubles times 0.5, no contraction possible,
+    # so bit-exact; the Laplacians end in "- n*phi" which may contract
+    if meta.get("grad_npt", 7) == 7:
+        assert np.array_equal(_host(lb, grad)[(slice(None),) + s],
+                              g["grad"][(slice(None),) + s])
+    assert relmax(_host(lb, grad)[(slice(None),) + s],
+                  g["grad"][(slice(None),) + s]) < 1e-15
     assert relmax(_host(lb, delsq)[s], g["delsq"][s]) < 1e-15
     lb.free()
 
@@ -68,6 +78,7 @@ def test_symmetric_force_vs_reference(name, from_grad):
     meta = g["meta"]
     h = meta["nhalo"]
     lb = ludwig_amd.LB(19, tuple(meta["nlocal"]), h)
+    _scheme(lb, meta)
     phi = _dev(lb, g["phi"])
     force = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
     torch.cuda.synchronize()
@@ -129,6 +140,7 @@ def test_cahn_hilliard_vs_reference(name, from_delsq):
     meta = g["meta"]
     h = meta["nhalo"]
     lb = ludwig_amd.LB(19, tuple(meta["nlocal"]), h)
+    _scheme(lb, meta)
     phi = _dev(lb, g["phi"])
     # u: interior from the fixture, halo by our own width-1 field halo
     u0 = np.zeros_like(g["u"])
@@ -156,7 +168,8 @@ def test_cahn_hilliard_rejects_aliasing():
     lb.free()
 
 
-def test_binary_fluid_steps_vs_oracle():
+@pytest.mark.parametrize("npt,order", [(7, 1), (27, 2), (27, 3), (7, 4)])
+def test_binary_fluid_steps_vs_oracle(npt, order):
     """A few complete steps of BASELINE config 4 on a small box, the order
     of ludwig.c:537-860: f_zero, phi halo, force, Cahn-Hilliard (with the u
     of the previous collision), u_zero, collide, halo, propagate -- device
@@ -180,16 +193,17 @@ def test_binary_fluid_steps_vs_oracle():
     for _ in range(nsteps):
         force = np.zeros((3,) + phi.shape)
         lbo.field_halo(p, phi, 2)
-        grad, delsq = lbo.grad_7pt(p, phi)
+        grad, delsq = lbo.grad(p, phi, npt)
         lbo.symm_force(p, a, b, kappa, phi, grad, delsq, force)
         lbo.field_halo(p, u, 1)
-        lbo.cahn_hilliard(p, a, b, kappa, mob, phi, delsq, u)
+        lbo.cahn_hilliard(p, a, b, kappa, mob, phi, delsq, u, order=order)
         u[...] = 0.0
         f, fp = lbo.step(p, f, fp, force, None, rho, u)
 
     # device
     lb = ludwig_amd.LB(19, nlocal, h, mode=ludwig_amd.FUSED)
     lb.relaxation_set("m10", 0.1, 0.3)
+    lb.fe_scheme_set(npt, order)
     hy = ludwig_amd.Hydro(lb.nall, lb.device, force=np.zeros((3,) + phi.shape))
     pa = _dev(lb, phi0)
     pb = torch.zeros_like(pa)
@@ -216,6 +230,7 @@ def test_symmetric_step_equals_separate_kernels(name):
     meta = g["meta"]
     h = meta["nhalo"]
     lb = ludwig_amd.LB(19, tuple(meta["nlocal"]), h)
+    _scheme(lb, meta)
     phi = _dev(lb, g["phi"])
     u0 = np.zeros_like(g["u"])
     interior(u0, h)[...] = interior(g["u"], h)
@@ -239,4 +254,81 @@ def test_symmetric_step_equals_separate_kernels(name):
     torch.cuda.synchronize()
     lb.symmetric_step(*args, meta["mobility"], phi, u, f3, o2, accumulate=False)
     assert np.array_equal(interior(_host(lb, f3), h), interior(_host(lb, f2), h))
+    # the same pass fed from the gradient arrays of field_grad
+    grad = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+    delsq = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    f4 = torch.zeros_like(f1)
+    o4 = torch.zeros_like(o1)
+    torch.cuda.synchronize()
+    lb.field_grad(phi, grad, delsq)
+    lb.symmetric_step_grad(*args, meta["mobility"], phi, grad, delsq, u, f4, o4)
+    assert relmax(interior(_host(lb, f4), h), interior(g["force"], h)) < 1e-12
+    assert relmax(interior(_host(lb, o4), h), interior(g["phi_new"], h)) < 1e-12
+    lb.free()
+
+
+def test_fe_scheme_rejects_what_the_reference_rejects():
+    import ludwig_amd
+    lb = ludwig_amd.LB(19, (4, 4, 4), 2)
+    for npt, order in ((9, 1), (7, 0), (7, 5), (27, 7)):
+        with pytest.raises(ludwig_amd.LbmiError):
+            lb.fe_scheme_set(npt, order)
+    lb.free()
+    lb = ludwig_amd.LB(19, (4, 4, 4), 1)
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.fe_scheme_set(7, 3)          # reaches two sites: needs nhalo 2
+    lb.fe_scheme_set(27, 2)
+    lb.free()
+
+
+@pytest.mark.parametrize("route", ["from_phi", "from_grad", "separate"])
+@pytest.mark.parametrize("name", ["iodrop-mpi1-io1", "serial-symm-dr1"])
+def test_drop_regression_log(name, route):
+    """BASELINE config 4 end to end against the reference's own regression
+    logs (a relaxing droplet: 27-point gradients, second-order advection,
+    stress-divergence force, Cahn-Hilliard, M10 collision with the force,
+    20 coupled steps): every printed statistic to its printed precision."""
+    import ludwig_amd
+    import torch
+    from tests.regression_cases import (check_drop_report, drop_phi,
+                                        drop_report, load_expected_drop, rest_f)
+    case = load_expected_drop()[name]
+    report_at = sorted(int(k) for k in case["reports"])
+    h = 2
+    a, b, kappa, mob = case["a"], case["b"], case["kappa"], case["mobility"]
+    lb = ludwig_amd.LB(19, tuple(case["size"]), h, mode=ludwig_amd.FUSED)
+    lb.relaxation_set("m10", case["eta"], case["zeta"])
+    lb.fe_scheme_set(case["grad_npt"], case["advection_order"])
+    phi0 = drop_phi(case, h)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, force=np.zeros((3,) + phi0.shape))
+    pa = _dev(lb, phi0)
+    pb = torch.zeros_like(pa)
+    grad = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+    delsq = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    lb.lb_memcpy_h2d(rest_f(ludwig_amd.model(19), lb.nall, h))
+    torch.cuda.synchronize()
+    for step in range(1, max(report_at) + 1):
+        lb.field_halo_n(pa, 2)
+        lb.field_halo_n(hy.u, 1)
+        if route == "from_phi":
+            lb.symmetric_step(a, b, kappa, mob, pa, hy.u, hy.force, pb,
+                              accumulate=False)
+        elif route == "from_grad":
+            lb.field_grad(pa, grad, delsq)
+            lb.symmetric_step_grad(a, b, kappa, mob, pa, grad, delsq, hy.u,
+                                   hy.force, pb, accumulate=False)
+        else:
+            lb.hydro_field_set(hy.force, (0, 0, 0))
+            lb.field_grad(pa, grad, delsq)
+            lb.symmetric_force(a, b, kappa, pa, hy.force, grad, delsq)
+            lb.cahn_hilliard(a, b, kappa, mob, pa, hy.u, pb, delsq)
+        if step in report_at and route == "from_phi":
+            lb.field_grad(pa, grad, delsq)        # of the start-of-step phi
+        pa, pb = pb, pa
+        lb.hydro_field_set(hy.u, (0, 0, 0))
+        lb.step(hy)
+        if step in report_at:
+            rep = drop_report(case, _host(lb, pa), _host(lb, grad),
+                              lb.moments(), _host(lb, hy.u), h)
+            check_drop_report(rep, case["reports"][str(step)])
     lb.free()

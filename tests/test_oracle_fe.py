@@ -1,6 +1,7 @@
-"""Pin the oracle's symmetric free-energy force chain (row f2) against the
-compiled reference: field_halo (width 2), grad_3d_7pt_fluid, and
-pth_stress_compute + pth_force_fluid_driver. CPU only."""
+"""Pin the oracle's symmetric free-energy chain (row f2) against the
+compiled reference: field_halo (width 2), grad_3d_7pt_fluid /
+grad_3d_27pt_fluid, pth_stress_compute + pth_force_fluid_driver, and
+phi_cahn_hilliard with advection of order 1..4. CPU only."""
 
 import numpy as np
 import pytest
@@ -26,11 +27,14 @@ def test_field_halo_width2_exact(name):
 
 
 @pytest.mark.parametrize("name", golden_fe_names())
-def test_gradient_7pt(name):
+def test_gradient(name):
+    """grad_3d_7pt_fluid / grad_3d_27pt_fluid, bit for bit (the oracle keeps
+    the reference's summation order)."""
     g = load_golden(name)
     meta = g["meta"]
     p = fe_param(meta)
-    grad, delsq = lbo.grad_7pt(p, np.ascontiguousarray(g["phi"]))
+    grad, delsq = lbo.grad(p, np.ascontiguousarray(g["phi"]),
+                           meta.get("grad_npt", 7))
     # computed region: interior + nextra = nhalo - 1 = 1 layer
     s = (slice(1, -1),) * 3
     assert np.array_equal(grad[(slice(None),) + s], g["grad"][(slice(None),) + s])
@@ -68,7 +72,8 @@ def test_u_halo_and_cahn_hilliard(name):
     assert np.array_equal(u[s1], g["u"][s1])
     phi = np.ascontiguousarray(g["phi"]).copy()
     lbo.cahn_hilliard(p, meta["a"], meta["b"], meta["kappa"], meta["mobility"],
-                      phi, np.ascontiguousarray(g["delsq"]), u)
+                      phi, np.ascontiguousarray(g["delsq"]), u,
+                      order=meta.get("advection_order", 1))
     assert relmax(interior(phi, h), interior(g["phi_new"], h)) < 1e-14
     # conservative: sum phi unchanged to rounding
     assert abs(interior(phi, h).sum() - interior(g["phi"], h).sum()) < 1e-13
