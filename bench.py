@@ -42,7 +42,9 @@ def parse():
     ap.add_argument("--nvel", type=int, default=19)
     ap.add_argument("--scheme", default="m10", choices=["m10", "bgk", "trt"])
     ap.add_argument("--mode", default="fused",
-                    choices=["fused", "eager", "inplace"])
+                    choices=["fused", "eager", "inplace", "blocked"],
+                    help="blocked: fused, with the deferred state in the "
+                    "block-contiguous order (single GPU)")
     ap.add_argument("--hydro", type=int, default=1,
                     help="1: lb_collide reads hydro->force and writes "
                     "hydro->rho,u as the reference does; 0: NULL hydro arrays")
@@ -55,6 +57,14 @@ def parse():
                     help="symmetric: the full binary-fluid step of BASELINE "
                     "config 4 (phi halo, thermodynamic force, Cahn-Hilliard, "
                     "LB step); 1 GPU, forces --nhalo 2")
+    ap.add_argument("--fe-grad", type=int, default=7, choices=[7, 27],
+                    help="fd_gradient_calculation 3d_7pt_fluid | 3d_27pt_fluid")
+    ap.add_argument("--fe-order", type=int, default=1, choices=[1, 2, 3, 4],
+                    help="fd_advection_scheme_order")
+    ap.add_argument("--fe-route", default="phi", choices=["phi", "grad"],
+                    help="phi: force + Cahn-Hilliard in one pass straight from "
+                    "phi; grad: gradient arrays first (lbmi_field_grad), then "
+                    "the one pass reading them")
     ap.add_argument("--selfring", type=int, default=0,
                     help="1 GPU only: route the X halo through a 1-rank RCCL "
                     "ring (exercises the N>1 step path: pack, send/recv, "
@@ -155,7 +165,8 @@ def main():
         ntotal = (args.size[0] * world, args.size[1], args.size[2])
     dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, nhalo=args.nhalo)
     mode = {"fused": ludwig_amd.FUSED, "eager": ludwig_amd.EAGER,
-            "inplace": ludwig_amd.INPLACE}[args.mode]
+            "inplace": ludwig_amd.INPLACE,
+            "blocked": ludwig_amd.FUSED_BLOCKED}[args.mode]
     lb = ludwig_amd.LB(args.nvel, dec.nlocal, args.nhalo, mode=mode,
                        halo_scheme=ludwig_amd.HALO_REDUCED, device=local_rank,
                        cartsz=world, cartrank=rank)
@@ -217,6 +228,12 @@ def main():
         h = args.nhalo
         fe["phi"][h:-h, h:-h, h:-h] = 0.05 * (torch.rand(
             lb.nlocal, dtype=torch.float64, device=lb.device, generator=g) - 0.5)
+        if args.fe_route == "grad":
+            fe["grad"] = torch.zeros((3,) + lb.nall, dtype=torch.float64,
+                                     device=lb.device)
+            fe["delsq"] = torch.zeros(lb.nall, dtype=torch.float64,
+                                      device=lb.device)
+        lb.fe_scheme_set(args.fe_grad, args.fe_order)
         torch.cuda.synchronize()
 
     def fe_step():
@@ -227,9 +244,16 @@ def main():
         lb.field_halo_n(fe["phi"], 2)                           # field_halo
         lb.field_halo_n(hydro.u, 1)                             # hydro_u_halo
         # phi_force_calculation + phi_cahn_hilliard, one pass over phi
-        lb.symmetric_step(fe["a"], fe["b"], fe["kappa"], fe["mobility"],
-                          fe["phi"], hydro.u, hydro.force, fe["phi2"],
-                          accumulate=False)
+        if args.fe_route == "grad":
+            lb.field_grad(fe["phi"], fe["grad"], fe["delsq"])
+            lb.symmetric_step_grad(fe["a"], fe["b"], fe["kappa"],
+                                   fe["mobility"], fe["phi"], fe["grad"],
+                                   fe["delsq"], hydro.u, hydro.force,
+                                   fe["phi2"], accumulate=False)
+        else:
+            lb.symmetric_step(fe["a"], fe["b"], fe["kappa"], fe["mobility"],
+                              fe["phi"], hydro.u, hydro.force, fe["phi2"],
+                              accumulate=False)
         fe["phi"], fe["phi2"] = fe["phi2"], fe["phi"]
 
     def one_step():
@@ -283,7 +307,7 @@ def main():
         algo_bytes = pop_bytes + (56 if args.hydro else 0)
         local_sites = dec.nlocal[0] * dec.nlocal[1] * dec.nlocal[2]
         roofline = None
-        if nlaunch > 0 and args.mode in ("fused", "inplace"):
+        if nlaunch > 0 and args.mode in ("fused", "inplace", "blocked"):
             t_launch = 1e-3 * kms / nlaunch
             achieved = 1e-9 * algo_bytes * local_sites / t_launch
             roofline = {
@@ -336,7 +360,9 @@ def main():
                             % (args.nvel, args.scheme.upper(), *ntotal),
                 "mode": args.mode,
                 "hydro_io": bool(args.hydro),
-                "free_energy": args.fe,
+                "free_energy": args.fe if args.fe == "none" else
+                "%s (%d-point gradients, advection order %d, from %s)"
+                % (args.fe, args.fe_grad, args.fe_order, args.fe_route),
                 "decomposition": "x-slab %d_1_1" % world
                                  + (" (1-rank RCCL ring)" if args.selfring else ""),
                 "halo": "index wrap (1 GPU); reduced X planes over RCCL (N>1)",

@@ -52,6 +52,9 @@ struct lbmi_s {
   int layout_swapped;                /* INPLACE: population p lives in slot opp(p) */
   int early_prop;                    /* INPLACE: k_aa_odd already propagated this step */
   int halo_seen;                     /* INPLACE: lb_halo called while early_prop */
+  int use_blocked;                   /* FUSED, 1 GPU: keep the deferred state in
+					the blocked order (lbmi_tune "blocked") */
+  int blocked;                       /* f is in the blocked order right now */
 
   /* moments workspace */
   double * mom_work;
@@ -535,6 +538,12 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
     lb->x_packed = (value != 0);
     return 0;
   }
+  if (strcmp(key, "blocked") == 0) {
+    /* takes effect at the next fused step; a state already blocked is
+     * converted back there or at the next flush */
+    lb->use_blocked = (value != 0);
+    return 0;
+  }
   if (strcmp(key, "lds_cap") == 0) {
     if (value < 0 || value > 163840) {
       return lbmi_fail(LBMI_ERR_ARGUMENT, "lds_cap = %d (0..163840)", value);
@@ -581,7 +590,7 @@ int lbmi_propagate_collide(lbmi_t * lb, const double * f, double * fprime,
   ifail = lbmi_time_begin(lb);
   if (ifail) return ifail;
   KCHECK(lbmi_k_propagate_collide(&lb->kp, f, fprime, &h,
-				  wrap ? lbmi_wrapmask(lb) : 0,
+				  wrap ? lbmi_wrapmask(lb) : 0, 0,
 				  lb->kp.nhalo,
 				  lb->kp.nhalo + lb->kp.nlocal[X] - 1, 0, -1,
 				  lb->stream));
@@ -806,6 +815,7 @@ int lbmi_lb_bind(lbmi_t * lb, double * f, double * fprime) {
   lb->layout_swapped = 0;
   lb->early_prop = 0;
   lb->halo_seen = 0;
+  lb->blocked = 0;
 
   if (f == NULL) {
     size_t sz = sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel;
@@ -853,6 +863,27 @@ static int lbmi_deferred(const lbmi_t * lb) {
 	  lb->opts.mode == LBMI_MODE_INPLACE);
 }
 
+/* The blocked order of a deferred state (lbmi_kernels.hip, faddr): single
+ * rank, every pull wrapped by index, and every site the kernel touches
+ * inside the whole blocks of the array */
+
+static int lbmi_blocked_ok(const lbmi_t * lb) {
+  int last = (lb->kp.nhalo + lb->kp.nlocal[X])*lb->kp.strx;
+  return (lb->use_blocked && lb->opts.mode == LBMI_MODE_FUSED &&
+	  lb->opts.cartsz == 1 && !lb->have_comm &&
+	  last <= lbmi_k_blocked_sites(&lb->kp));
+}
+
+/* Back to the reference's SoA order (same state, other addresses) */
+
+static int lbmi_unblock(lbmi_t * lb) {
+  if (!lb->blocked) return 0;
+  KCHECK(lbmi_k_relayout(&lb->kp, lb->f, lb->fprime, 0, lb->stream));
+  lbmi_swapf(lb);
+  lb->blocked = 0;
+  return 0;
+}
+
 /* FUSED step: exchange of the X planes on the comm stream overlapped with
  * the interior x-planes on the compute stream, boundary planes afterwards */
 
@@ -868,8 +899,15 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
   if (ifail) return ifail;
 
   if (lb->opts.cartsz == 1 && !lb->have_comm) {
+    /* lay: 0 SoA -> SoA; 1 SoA -> blocked; 2 blocked -> blocked */
+    int lay = lbmi_blocked_ok(lb) ? (lb->blocked ? 2 : 1) : 0;
+    if (lay == 0 && lb->blocked) {
+      ifail = lbmi_unblock(lb);
+      if (ifail) return ifail;
+    }
     KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				    xlo, xhi, 0, -1, lb->stream));
+				    lay, xlo, xhi, 0, -1, lb->stream));
+    lb->blocked = (lay != 0);
   }
   else {
     /* The interior planes need no x halo: enqueue them first so that the
@@ -878,7 +916,7 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
      * "previous step complete", i.e. the boundary planes of f are final. */
     HIPCHECK(hipEventRecord(lb->ev_ready, lb->stream));
     KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				    xlo + 1, xhi - 1, 0, -1, lb->stream));
+				    0, xlo + 1, xhi - 1, 0, -1, lb->stream));
 
     /* comm stream: exchange the boundary planes into the x halo planes */
     HIPCHECK(hipStreamWaitEvent(lb->comm_stream, lb->ev_ready, 0));
@@ -889,7 +927,7 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
     /* both boundary planes in one launch, after the halo has arrived */
     HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_halo, 0));
     KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				    xlo, xlo, xhi, (xhi > xlo) ? xhi : xhi - 1,
+				    0, xlo, xlo, xhi, (xhi > xlo) ? xhi : xhi - 1,
 				    lb->stream));
   }
 
@@ -973,6 +1011,10 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
 		     "lb_propagation");
   }
 
+  if (lb->blocked) {
+    int ifail = lbmi_unblock(lb);
+    if (ifail) return ifail;
+  }
   KCHECK(lbmi_k_collide(&lb->kp, lb->f, &h, lb->stream));
 
   return 0;
@@ -1033,6 +1075,10 @@ int lbmi_lb_propagation(lbmi_t * lb) {
 	KCHECK(lbmi_k_aa_unswap(&lb->kp, lb->f, lb->stream));
 	lb->layout_swapped = 0;
       }
+      if (lb->blocked) {
+	int ifail = lbmi_unblock(lb);
+	if (ifail) return ifail;
+      }
       KCHECK(lbmi_k_propagate(&lb->kp, lb->f, lb->fprime, lb->stream));
       lbmi_swapf(lb);
       return 0;
@@ -1081,6 +1127,10 @@ int lbmi_lb_flush(lbmi_t * lb) {
     KCHECK(lbmi_k_aa_unswap(&lb->kp, lb->f, lb->stream));
     lb->layout_swapped = 0;
   }
+  if (lb->blocked) {
+    int ifail = lbmi_unblock(lb);
+    if (ifail) return ifail;
+  }
 
   if (lb->pending_halo) {
     int ifail = lbmi_halo(lb, lb->f, lb->opts.halo_scheme);
@@ -1093,6 +1143,14 @@ int lbmi_lb_flush(lbmi_t * lb) {
     lb->pending_prop = 0;
   }
 
+  return 0;
+}
+
+int lbmi_lb_state(lbmi_t * lb, int state[3]) {
+  if (lb == NULL || state == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  state[0] = (lb->pending_halo || lb->halo_seen);
+  state[1] = (lb->pending_prop || lb->early_prop);
+  state[2] = lb->blocked ? 1 : (lb->layout_swapped ? 2 : 0);
   return 0;
 }
 
@@ -1113,6 +1171,7 @@ int lbmi_lb_memcpy_h2d(lbmi_t * lb, const double * f_host) {
   lb->layout_swapped = 0;
   lb->early_prop = 0;
   lb->halo_seen = 0;
+  lb->blocked = 0;
   HIPCHECK(hipMemcpyAsync(lb->f, f_host, sz, hipMemcpyHostToDevice, lb->stream));
   HIPCHECK(hipStreamSynchronize(lb->stream));
   return 0;
@@ -1331,6 +1390,7 @@ int lbmi_lb_records_unpack(lbmi_t * lb, const double * records) {
   lb->pending_prop = 0;
   lb->early_prop = 0;
   lb->halo_seen = 0;
+  lb->blocked = 0;
   if (lb->layout_swapped) {
     lb->layout_swapped = 0;
   }

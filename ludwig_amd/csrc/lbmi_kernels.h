@@ -67,10 +67,16 @@ int lbmi_k_propagate(const lbmi_kparam_t * kp, const double * f,
 /* xlo..xhi and xlo2..xhi2: 0-based x planes (in nall) to process,
  * inclusive, in ONE launch; an empty range has xhi < xlo.
  * wrapmask: bit d set = wrap direction d by index arithmetic. */
+/* lay: 0 SoA -> SoA; 1 SoA -> blocked; 2 blocked -> blocked (the blocked
+ * order [site/256][p][site%256] needs wrapmask != 0 in every direction that
+ * is pulled across: single GPU) */
 int lbmi_k_propagate_collide(const lbmi_kparam_t * kp, const double * f,
 			     double * fprime, const lbmi_hydro_dev_t * h,
-			     int wrapmask, int xlo, int xhi, int xlo2, int xhi2,
-			     void * stream);
+			     int wrapmask, int lay, int xlo, int xhi, int xlo2,
+			     int xhi2, void * stream);
+int lbmi_k_blocked_sites(const lbmi_kparam_t * kp);
+int lbmi_k_relayout(const lbmi_kparam_t * kp, const double * src,
+		    double * dst, int to_blocked, void * stream);
 
 /* In-place streaming (AA pattern), single GPU, all directions wrapped by
  * index: even = collide in place into swapped slots; odd = pull (from the

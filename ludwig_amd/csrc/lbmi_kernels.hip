@@ -516,6 +516,29 @@ void k_propagate(lbmi_kparam_t kp, const double * __restrict__ f,
  * y/z halo sites inside the processed x-planes copy in place (as
  * lb_propagation_kernel does), which keeps every store stream contiguous. */
 
+/* Orders of a distribution array. SoA is the reference's (-DADDR_SOA,
+ * memory.h:250-258): population p of site i at nsite*p + i, NVEL streams
+ * nsite*8 bytes apart. The blocked order keeps LBW consecutive sites of all
+ * populations together, [i/LBW][p][i%LBW]: one thread block then writes ONE
+ * contiguous NVEL*LBW*8-byte chunk instead of NVEL pieces 137 MB apart, and
+ * its pulls come from a few neighbouring chunks. It exists only as the
+ * internal order of a deferred (FUSED) state on a single GPU: whatever a
+ * caller can observe is converted back (lbmi_lb_flush). The two orders
+ * occupy the same nsite*NVEL doubles; sites beyond the last whole block
+ * (they lie in the last x halo plane) are not representable and never used. */
+
+constexpr int LBW = 256;
+
+template <int NVEL, bool BLK>
+__device__ __forceinline__ size_t faddr(size_t ns, int p, int i) {
+  if constexpr (BLK) {
+    return (size_t) (i >> 8)*(size_t) (NVEL*LBW) + (size_t) (p*LBW + (i & (LBW - 1)));
+  }
+  else {
+    return ns*p + i;
+  }
+}
+
 template <int NVEL>
 struct PulledSite {
   double fl[NVEL];
@@ -523,7 +546,7 @@ struct PulledSite {
 };
 
 /* phase 1: issue the NVEL pulls of site i */
-template <int NVEL, bool WRAP>
+template <int NVEL, bool WRAP, bool RB>
 __device__ __forceinline__
 void pc_pull(const lbmi_kparam_t & kp, const double * __restrict__ f,
 	     int wrapmask, int i, PulledSite<NVEL> & ps) {
@@ -560,7 +583,7 @@ void pc_pull(const lbmi_kparam_t & kp, const double * __restrict__ f,
       if constexpr (cz ==  1) off -= wlo[2];
       if constexpr (cz == -1) off -= whi[2];
     }
-    ps.fl[p] = ldf(&f[ns*p + (i - m*off)]);
+    ps.fl[p] = ldf(&f[faddr<NVEL, RB>(ns, p, i - m*off)]);
   });
 #else
   /* y/z halo lanes (2 per row) load nothing and store zeros: the halo of
@@ -580,14 +603,14 @@ void pc_pull(const lbmi_kparam_t & kp, const double * __restrict__ f,
 	if constexpr (cz ==  1) off -= wlo[2];
 	if constexpr (cz == -1) off -= whi[2];
       }
-      ps.fl[p] = ldf(&f[ns*p + (i - off)]);
+      ps.fl[p] = ldf(&f[faddr<NVEL, RB>(ns, p, i - off)]);
     });
   }
 #endif
 }
 
 /* phase 2: collide (interior fluid sites) and store site i */
-template <int NVEL, int SCHEME>
+template <int NVEL, int SCHEME, bool WB>
 __device__ __forceinline__
 void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
 		      const lbmi_hydro_dev_t & h, int i,
@@ -618,10 +641,14 @@ void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
     }
   }
 
-  static_for<0, NVEL>([&](auto P) { stf(&fp[ns*P + i], ps.fl[P]); });
+  static_for<0, NVEL>([&](auto P) {
+    stf(&fp[faddr<NVEL, WB>(ns, P, i)], ps.fl[P]);
+  });
 }
 
-template <int NVEL, int SCHEME, bool WRAP>
+/* LAY: 0 SoA -> SoA, 1 SoA -> blocked, 2 blocked -> blocked */
+
+template <int NVEL, int SCHEME, bool WRAP, int LAY>
 __global__ __launch_bounds__(BLOCK, LBMI_WAVES)
 void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
 			 double * __restrict__ fp, lbmi_hydro_dev_t h,
@@ -646,16 +673,39 @@ void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
   /* blocks start at multiples of LBMI_ALIGN sites so that every store of a
    * wave covers whole 64-byte sectors of every population array (nsite*8
    * is a multiple of 64 for the sizes of interest); lanes before i0 idle */
-  const int i0a = (i0/LBMI_ALIGN)*LBMI_ALIGN;
+  constexpr int ALIGNV = (LAY == 0) ? LBMI_ALIGN : LBW;
+  const int i0a = (i0/ALIGNV)*ALIGNV;
   static_for<0, SPT>([&](auto K) {
     constexpr int k = K;
     i[k] = i0a + (int) (lb*(BLOCK*SPT) + k*BLOCK + threadIdx.x);
-    if (i[k] >= i0 && i[k] < i1) pc_pull<NVEL, WRAP>(kp, f, wrapmask, i[k], ps[k]);
+    if (i[k] >= i0 && i[k] < i1) {
+      pc_pull<NVEL, WRAP, LAY == 2>(kp, f, wrapmask, i[k], ps[k]);
+    }
   });
   static_for<0, SPT>([&](auto K) {
     constexpr int k = K;
-    if (i[k] >= i0 && i[k] < i1) pc_collide_store<NVEL, SCHEME>(kp, fp, h, i[k], ps[k]);
+    if (i[k] >= i0 && i[k] < i1) {
+      pc_collide_store<NVEL, SCHEME, LAY != 0>(kp, fp, h, i[k], ps[k]);
+    }
   });
+}
+
+/* k_relayout: the whole array from one order to the other (every whole
+ * block of LBW sites, halo included), src != dst. Used when a deferred
+ * blocked state has to become observable again (lbmi_lb_flush). */
+
+template <int NVEL, bool TO_BLK>
+__global__ __launch_bounds__(BLOCK)
+void k_relayout(lbmi_kparam_t kp, const double * __restrict__ src,
+		double * __restrict__ dst, int nfull, unsigned nblk) {
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (int) (lb*BLOCK + threadIdx.x);
+  if (i >= nfull) return;
+  const size_t ns = (size_t) kp.nsite;
+  double v[NVEL];
+  static_for<0, NVEL>([&](auto P) { v[P] = src[faddr<NVEL, !TO_BLK>(ns, P, i)]; });
+  static_for<0, NVEL>([&](auto P) { dst[faddr<NVEL, TO_BLK>(ns, P, i)] = v[P]; });
 }
 
 /* ---- in-place streaming: the AA pattern --------------------------------------
@@ -1151,25 +1201,25 @@ void grad_at(const double * __restrict__ phi, size_t j, int strx, int stry,
  * The order is uniform over the launch. */
 
 __device__ __forceinline__
-double adv_flux(int order, bool west, double uf,
-		const double * __restrict__ phi, size_t l, int s) {
-  const size_t r = l + s;
+double adv_flux(int order, bool west, double uf, double pm, double pl,
+		double pr, double pp) {
+  /* pm, pl | pr, pp: phi at l - s, l, r, r + s */
   if (order == 1) {
-    if (west) return uf*((uf > 0.0) ? phi[l] : phi[r]);
-    return uf*((uf < 0.0) ? phi[r] : phi[l]);
+    if (west) return uf*((uf > 0.0) ? pl : pr);
+    return uf*((uf < 0.0) ? pr : pl);
   }
-  if (order == 2) return uf*0.5*(phi[l] + phi[r]);
+  if (order == 2) return uf*0.5*(pl + pr);
   if (order == 3) {
     const double a1 = -0.213933;
     const double a2 =  0.927865;
     const double a3 =  0.286067;
     const bool down = west ? !(uf > 0.0) : (uf < 0.0);
-    if (down) return uf*(a1*phi[r + s] + a2*phi[r] + a3*phi[l]);
-    return uf*(a1*phi[l - s] + a2*phi[l] + a3*phi[r]);
+    if (down) return uf*(a1*pp + a2*pr + a3*pl);
+    return uf*(a1*pm + a2*pl + a3*pr);
   }
   const double a1 = (1.0/16.0);
   const double a2 = (9.0/16.0);
-  return uf*(- a1*phi[l - s] + a2*phi[l] + a2*phi[r] - a1*phi[r + s]);
+  return uf*(- a1*pm + a2*pl + a2*pr - a1*pp);
 }
 
 template <int NPT>
@@ -1289,10 +1339,18 @@ void k_cahn_hilliard(lbmi_kparam_t kp, Symm q, double mobility, int order,
   static_for<0, 3>([&](auto D) {
     constexpr int id = D;
     const double ud0 = u[ns*id + i];
+    /* phi along the line through the site; two sites away only for the
+     * schemes that reach there (uniform branch) */
+    const double pm1 = phi[i - str[id]], pp1 = phi[i + str[id]];
+    double pm2 = 0.0, pp2 = 0.0;
+    if (order > 2) {
+      pm2 = phi[i - 2*str[id]];
+      pp2 = phi[i + 2*str[id]];
+    }
     {
       size_t j = (size_t) (i + str[id]);       /* face (i, i + e_d) */
       double uf = 0.5*(ud0 + u[ns*id + j]);
-      double f = adv_flux(order, false, uf, phi, (size_t) i, str[id]);
+      double f = adv_flux(order, false, uf, pm1, phi0, pp1, pp2);
       f -= mobility*(mu_at(j) - mu0);
       fhi[id] = f;
     }
@@ -1301,7 +1359,7 @@ void k_cahn_hilliard(lbmi_kparam_t kp, Symm q, double mobility, int order,
        * below, as the reference's update reads them */
       size_t j = (size_t) (i - str[id]);       /* face (i - e_d, i) */
       double uf = 0.5*(ud0 + u[ns*id + j]);
-      double f = adv_flux(order, id == 0, uf, phi, j, str[id]);
+      double f = adv_flux(order, id == 0, uf, pm2, pm1, phi0, pp1);
       f -= mobility*(mu0 - mu_at(j));
       flo[id] = f;
     }
@@ -1366,12 +1424,18 @@ void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility, int order,
   static_for<0, 3>([&](auto D) {
     constexpr int id = D;
     const double ud0 = u[ns*id + i];
+    double pm2 = 0.0, pp2 = 0.0;
+    if (order > 2) {
+      pm2 = phi[i - 2*str[id]];
+      pp2 = phi[i + 2*str[id]];
+    }
+    const double pm1 = phi[i - str[id]], pp1 = phi[i + str[id]];
     {
       size_t j = (size_t) (i + str[id]);
       at(j, pth1, mu1, phi1);
       for (int ia = 0; ia < 3; ia++) f[ia] -= 0.5*(pth1[ia][id] + pth0[ia][id]);
       double uf = 0.5*(ud0 + u[ns*id + j]);
-      double fl = adv_flux(order, false, uf, phi, (size_t) i, str[id]);
+      double fl = adv_flux(order, false, uf, pm1, phi0, pp1, pp2);
       fl -= mobility*(mu1 - mu0);
       fhi[id] = fl;
     }
@@ -1380,7 +1444,7 @@ void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility, int order,
       at(j, pth1, mu1, phi1);
       for (int ia = 0; ia < 3; ia++) f[ia] += 0.5*(pth1[ia][id] + pth0[ia][id]);
       double uf = 0.5*(ud0 + u[ns*id + j]);
-      double fl = adv_flux(order, id == 0, uf, phi, j, str[id]);
+      double fl = adv_flux(order, id == 0, uf, pm2, pm1, phi0, pp1);
       fl -= mobility*(mu0 - mu1);
       flo[id] = fl;
     }
@@ -1604,12 +1668,14 @@ int launch_collide(const lbmi_kparam_t & kp, double * f,
   return (int) hipGetLastError();
 }
 
-template <int NVEL, bool WRAP>
+template <int NVEL, bool WRAP, int LAY>
 int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
 	      const lbmi_hydro_dev_t & h, int wrapmask, int i0, int i1,
 	      int j0, int j1, hipStream_t st) {
-  const int i0a = (i0/LBMI_ALIGN)*LBMI_ALIGN;
-  const int j0a = (j0/LBMI_ALIGN)*LBMI_ALIGN;
+  constexpr int ALIGNV = (LAY == 0) ? LBMI_ALIGN : LBW;
+  static_assert(LAY == 0 || BLOCK*SPT == LBW, "blocked order: one thread block per layout block");
+  const int i0a = (i0/ALIGNV)*ALIGNV;
+  const int j0a = (j0/ALIGNV)*ALIGNV;
   unsigned nblk_first = (unsigned) ((i1 - i0a + BLOCK*SPT - 1)/(BLOCK*SPT));
   unsigned nblk = nblk_first;
   if (j1 > j0) nblk += (unsigned) ((j1 - j0a + BLOCK*SPT - 1)/(BLOCK*SPT));
@@ -1624,10 +1690,10 @@ int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
   if (lds > 65536u) {
     /* above 64 KiB the limit must be raised per kernel */
     const void * fn = nullptr;
-    if (kp.scheme == LBMI_M10) fn = (const void *) k_propagate_collide<NVEL, LBMI_M10, WRAP>;
-    if (kp.scheme == LBMI_BGK) fn = (const void *) k_propagate_collide<NVEL, LBMI_BGK, WRAP>;
+    if (kp.scheme == LBMI_M10) fn = (const void *) k_propagate_collide<NVEL, LBMI_M10, WRAP, LAY>;
+    if (kp.scheme == LBMI_BGK) fn = (const void *) k_propagate_collide<NVEL, LBMI_BGK, WRAP, LAY>;
     if constexpr (NVEL == 19) {
-      if (kp.scheme == LBMI_TRT) fn = (const void *) k_propagate_collide<NVEL, LBMI_TRT, WRAP>;
+      if (kp.scheme == LBMI_TRT) fn = (const void *) k_propagate_collide<NVEL, LBMI_TRT, WRAP, LAY>;
     }
     if (fn) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
@@ -1636,20 +1702,20 @@ int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
   }
   switch (kp.scheme) {
   case LBMI_M10:
-    hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_M10, WRAP>), grid,
+    hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_M10, WRAP, LAY>), grid,
 		       block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk,
 		       j0, j1, nblk_first);
     break;
   case LBMI_BGK:
-    hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_BGK, WRAP>), grid,
+    hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_BGK, WRAP, LAY>), grid,
 		       block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk,
 		       j0, j1, nblk_first);
     break;
   case LBMI_TRT:
     if constexpr (NVEL == 19) {
-      hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_TRT, WRAP>), grid,
+      hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_TRT, WRAP, LAY>), grid,
 			 block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk,
-		       j0, j1, nblk_first);
+			 j0, j1, nblk_first);
       break;
     }
     return (int) hipErrorInvalidValue;
@@ -1657,6 +1723,22 @@ int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
     return (int) hipErrorInvalidValue;
   }
   return (int) hipGetLastError();
+}
+
+template <int NVEL>
+int launch_pc_any(const lbmi_kparam_t & kp, const double * f, double * fp,
+		  const lbmi_hydro_dev_t & h, int wrapmask, int lay, int i0,
+		  int i1, int j0, int j1, hipStream_t st) {
+  if (!wrapmask) {
+    if (lay != 0) return (int) hipErrorInvalidValue;
+    return launch_pc<NVEL, false, 0>(kp, f, fp, h, 0, i0, i1, j0, j1, st);
+  }
+  if (lay == 0) return launch_pc<NVEL, true, 0>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
+#if LBMI_BLOCK*LBMI_SPT == 256
+  if (lay == 1) return launch_pc<NVEL, true, 1>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
+  if (lay == 2) return launch_pc<NVEL, true, 2>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
+#endif
+  return (int) hipErrorInvalidValue;
 }
 
 struct Range1D {
@@ -1781,8 +1863,9 @@ extern "C" int lbmi_k_propagate(const lbmi_kparam_t * kp, const double * f,
 extern "C" int lbmi_k_propagate_collide(const lbmi_kparam_t * kp,
 					const double * f, double * fprime,
 					const lbmi_hydro_dev_t * h,
-					int wrapmask, int xlo, int xhi,
-					int xlo2, int xhi2, void * stream) {
+					int wrapmask, int lay, int xlo,
+					int xhi, int xlo2, int xhi2,
+					void * stream) {
   hipStream_t st = (hipStream_t) stream;
   if (xhi < xlo) {
     if (xhi2 < xlo2) return 0;
@@ -1796,14 +1879,37 @@ extern "C" int lbmi_k_propagate_collide(const lbmi_kparam_t * kp,
     j1 = (xhi2 + 1)*kp->strx;
   }
   if (kp->nvel == 19) {
-    return wrapmask ? launch_pc<19, true>(*kp, f, fprime, *h, wrapmask, i0, i1, j0, j1, st)
-      : launch_pc<19, false>(*kp, f, fprime, *h, 0, i0, i1, j0, j1, st);
+    return launch_pc_any<19>(*kp, f, fprime, *h, wrapmask, lay, i0, i1, j0, j1, st);
   }
   if (kp->nvel == 27) {
-    return wrapmask ? launch_pc<27, true>(*kp, f, fprime, *h, wrapmask, i0, i1, j0, j1, st)
-      : launch_pc<27, false>(*kp, f, fprime, *h, 0, i0, i1, j0, j1, st);
+    return launch_pc_any<27>(*kp, f, fprime, *h, wrapmask, lay, i0, i1, j0, j1, st);
   }
   return (int) hipErrorInvalidValue;
+}
+
+extern "C" int lbmi_k_blocked_sites(const lbmi_kparam_t * kp) {
+  /* sites representable in the blocked order: whole blocks only */
+  return (int) ((kp->nsite/LBW)*LBW);
+}
+
+extern "C" int lbmi_k_relayout(const lbmi_kparam_t * kp, const double * src,
+			       double * dst, int to_blocked, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  int nfull = lbmi_k_blocked_sites(kp);
+  unsigned nblk = (unsigned) ((nfull + BLOCK - 1)/BLOCK);
+  dim3 grid(grid_for(nblk, (unsigned) kp->xcd_group)), block(BLOCK);
+  if (kp->nvel == 19) {
+    if (to_blocked) hipLaunchKernelGGL((k_relayout<19, true>), grid, block, 0, st, *kp, src, dst, nfull, nblk);
+    else hipLaunchKernelGGL((k_relayout<19, false>), grid, block, 0, st, *kp, src, dst, nfull, nblk);
+  }
+  else if (kp->nvel == 27) {
+    if (to_blocked) hipLaunchKernelGGL((k_relayout<27, true>), grid, block, 0, st, *kp, src, dst, nfull, nblk);
+    else hipLaunchKernelGGL((k_relayout<27, false>), grid, block, 0, st, *kp, src, dst, nfull, nblk);
+  }
+  else {
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
 }
 
 extern "C" int lbmi_k_aa_even(const lbmi_kparam_t * kp, double * f,

@@ -21,6 +21,9 @@ from . import lib as _l
 
 M10, BGK, TRT = 0, 1, 2                    # lb_relaxation_enum_t
 EAGER, FUSED, INPLACE = 0, 1, 2            # lbmi_mode_t
+# Python-side shorthand: FUSED with the deferred state kept in the blocked
+# order (lbmi_tune "blocked" = 1)
+FUSED_BLOCKED = 3
 HALO_FULL, HALO_REDUCED = 0, 2             # lbmi_halo_t
 _SCHEMES = {"m10": M10, "bgk": BGK, "trt": TRT}
 
@@ -94,7 +97,7 @@ class LB:
         opts.nlocal[:] = list(nlocal)
         opts.nhalo = nhalo
         opts.device = device
-        opts.mode = mode
+        opts.mode = FUSED if mode == FUSED_BLOCKED else mode
         opts.halo_scheme = halo_scheme
         opts.cartsz = cartsz
         opts.cartrank = cartrank
@@ -115,6 +118,8 @@ class LB:
             st = torch.cuda.current_stream(self.device).cuda_stream
             _l.check(self._lib.lbmi_set_stream(self._h, ctypes.c_void_p(st)))
         _l.check(self._lib.lbmi_lb_bind(self._h, _ptr(self._a), _ptr(self._b)))
+        if mode == FUSED_BLOCKED:
+            self.tune("blocked", 1)
 
     # -- life cycle ---------------------------------------------------------
 
@@ -333,6 +338,12 @@ class LB:
 
     def synchronize(self):
         _l.check(self._lib.lbmi_synchronize(self._h))
+
+    def state(self):
+        """(halo pending, propagation pending, order of f) -- lbmi_lb_state."""
+        st = (ctypes.c_int * 3)()
+        _l.check(self._lib.lbmi_lb_state(self._h, st))
+        return tuple(st)
 
     def tune(self, key, value):
         _l.check(self._lib.lbmi_tune(self._h, key.encode(), int(value)))

@@ -71,6 +71,7 @@ SYMBOLS = [
     ("lbmi_lb_halo", _i, [_vp]),
     ("lbmi_lb_propagation", _i, [_vp]),
     ("lbmi_lb_flush", _i, [_vp]),
+    ("lbmi_lb_state", _i, [_vp, ctypes.POINTER(_i)]),
     ("lbmi_lb_memcpy_h2d", _i, [_vp, _vp]),
     ("lbmi_lb_memcpy_d2h", _i, [_vp, _vp]),
     ("lbmi_lb_moments", _i, [_vp, _vp, _pd]),

@@ -128,7 +128,7 @@ def test_reduced_halo_same_interior(name):
 
 # --- whole time steps: EAGER and FUSED against the reference -----------------
 
-@pytest.mark.parametrize("mode", [0, 1, 2], ids=["eager", "fused", "inplace"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "blocked"])
 @pytest.mark.parametrize("halo_scheme", [0, 2], ids=["full", "reduced"])
 @pytest.mark.parametrize("name", golden_names())
 def test_steps_vs_reference(name, mode, halo_scheme):
@@ -165,7 +165,7 @@ def test_fused_equals_eager_bitwise_inputs(name):
     meta = g["meta"]
     h = meta["nhalo"]
     out = []
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         lb = make_lb(meta, mode=mode)
         hy = make_hydro(lb, g, meta)
         lb.lb_memcpy_h2d(g["f0"])
@@ -175,9 +175,10 @@ def test_fused_equals_eager_bitwise_inputs(name):
         lb.free()
     assert relmax(out[1], out[0]) < 1e-14
     assert relmax(out[2], out[0]) < 1e-14
+    assert np.array_equal(out[3], out[1])       # blocked order: same arithmetic
 
 
-@pytest.mark.parametrize("mode", [1, 2], ids=["fused", "inplace"])
+@pytest.mark.parametrize("mode", [1, 2, 3], ids=["fused", "inplace", "blocked"])
 @pytest.mark.parametrize("name", ["q19_bgk_ffield", "q27_m10_ffield", "q19_m10_solid"])
 def test_flush_at_every_call_point(name, mode):
     """A device-to-host copy (which flushes) placed after ANY call of ANY
@@ -290,7 +291,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2], ids=["eager", "fused", "inplace"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "blocked"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "q%d-%s-%s" % (c[0], "x".join(map(str, c[1])), c[3]))
 def test_seeded_vs_oracle(case, mode):
     import ludwig_amd
@@ -355,7 +356,7 @@ def test_field_halo(nhalo):
 
 # --- reference regression log on the device ---------------------------------
 
-@pytest.mark.parametrize("mode", [0, 1, 2], ids=["eager", "fused", "inplace"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "blocked"])
 def test_regression_log_1dp(mode):
     import ludwig_amd
     case = load_expected()["serial-dist-1dp"]
@@ -501,3 +502,73 @@ def test_slabs_equal_single_domain(nvel, nslab, halo_scheme, fused):
     assert relmax(got, interior(f, 1)) < RTOL_F
     for lb in lbs:
         lb.free()
+
+
+# --- FUSED with the deferred state in the blocked order ----------------------
+
+@pytest.mark.parametrize("nvel,nlocal,nhalo", [(19, (24, 10, 18), 1),
+                                                (27, (9, 16, 14), 1),
+                                                (19, (12, 12, 12), 2)])
+def test_blocked_order_is_invisible(nvel, nlocal, nhalo):
+    """lbmi_tune("blocked"): the deferred state lives in another order, and
+    nothing a caller can observe changes -- a copy out (which flushes) after
+    ANY call of ANY step returns what EAGER holds there, bit for bit with
+    the unblocked FUSED run, and the run continues undisturbed."""
+    import ludwig_amd
+    p = lbo.make_param(nvel, nlocal, nhalo, "m10", 0.1, 0.3, 1.0, (1e-6, 0, 2e-6))
+    f0 = lbo.init_synthetic(p)
+    nsteps = 4
+
+    def run(mode, probe):
+        lb = ludwig_amd.LB(nvel, nlocal, nhalo, mode=mode)
+        lb.relaxation_set("m10", 0.1, 0.3)
+        lb.body_force_set((1e-6, 0, 2e-6))
+        hy = ludwig_amd.Hydro(lb.nall, lb.device)
+        lb.lb_memcpy_h2d(f0)
+        seen, orders = None, []
+        for n in range(nsteps):
+            for k, call in enumerate((lambda: lb.lb_collide(hy), lb.lb_halo,
+                                      lb.lb_propagation)):
+                call()
+                orders.append(lb.state()[2])
+                if probe == (n, k):
+                    seen = interior(lb.lb_memcpy_d2h(), nhalo).copy()
+                    assert lb.state() == (0, 0, 0)
+        final = interior(lb.lb_memcpy_d2h(), nhalo).copy()
+        u = host(lb, hy.u)
+        lb.free()
+        return seen, final, u, orders
+
+    _, ref_final, ref_u, _ = run(1, None)
+    _, final, u, orders = run(3, None)
+    assert 1 in orders, "the blocked order was never used"
+    assert np.array_equal(final, ref_final)
+    assert np.array_equal(u, ref_u)
+    for n in range(nsteps):
+        for k in range(3):
+            ref_seen, ref_final = run(0, (n, k))
+            seen, final, _, _ = run(3, (n, k))
+            assert relmax(seen, ref_seen) < 1e-14, (n, k)
+            assert relmax(final, ref_final) < 1e-14, (n, k)
+
+
+def test_blocked_order_switch_mid_run():
+    """Turning the blocked order on and off between steps converts the
+    state at the next step or flush."""
+    import ludwig_amd
+    nlocal = (20, 12, 16)
+    p = lbo.make_param(19, nlocal, 1, "bgk", 0.1, 0.1)
+    f0 = lbo.init_synthetic(p)
+    outs = []
+    for toggle in (False, True):
+        lb = ludwig_amd.LB(19, nlocal, 1, mode=ludwig_amd.FUSED)
+        lb.relaxation_set("bgk", 0.1, 0.1)
+        hy = ludwig_amd.Hydro(lb.nall, lb.device)
+        lb.lb_memcpy_h2d(f0)
+        for n in range(8):
+            if toggle and n in (2, 5, 6):
+                lb.tune("blocked", 1 if n != 5 else 0)
+            lb.step(hy)
+        outs.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+        lb.free()
+    assert np.array_equal(outs[0], outs[1])
