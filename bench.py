@@ -42,9 +42,10 @@ def parse():
     ap.add_argument("--nvel", type=int, default=19)
     ap.add_argument("--scheme", default="m10", choices=["m10", "bgk", "trt"])
     ap.add_argument("--mode", default="fused",
-                    choices=["fused", "eager", "inplace", "blocked"],
-                    help="blocked: fused, with the deferred state in the "
-                    "block-contiguous order (single GPU)")
+                    choices=["fused", "eager", "inplace", "fused_soa"],
+                    help="fused (default): on one GPU the deferred state is "
+                    "kept in the block-contiguous order; fused_soa: in the "
+                    "reference's SoA order")
     ap.add_argument("--hydro", type=int, default=1,
                     help="1: lb_collide reads hydro->force and writes "
                     "hydro->rho,u as the reference does; 0: NULL hydro arrays")
@@ -166,7 +167,7 @@ def main():
     dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, nhalo=args.nhalo)
     mode = {"fused": ludwig_amd.FUSED, "eager": ludwig_amd.EAGER,
             "inplace": ludwig_amd.INPLACE,
-            "blocked": ludwig_amd.FUSED_BLOCKED}[args.mode]
+            "fused_soa": ludwig_amd.FUSED_SOA}[args.mode]
     lb = ludwig_amd.LB(args.nvel, dec.nlocal, args.nhalo, mode=mode,
                        halo_scheme=ludwig_amd.HALO_REDUCED, device=local_rank,
                        cartsz=world, cartrank=rank)
@@ -293,6 +294,8 @@ def main():
 
     kms, nlaunch = lb.timing_read()
     lb.timing(False)
+    order = {0: "soa", 1: "blocked [site/256][p][site%256] (deferred state)",
+             2: "slot-swapped (AA)"}[lb.state()[2]]
     mom1 = allsum(lb.moments()[[1, 5, 6, 7]])
 
     sites = ntotal[0] * ntotal[1] * ntotal[2]
@@ -307,7 +310,7 @@ def main():
         algo_bytes = pop_bytes + (56 if args.hydro else 0)
         local_sites = dec.nlocal[0] * dec.nlocal[1] * dec.nlocal[2]
         roofline = None
-        if nlaunch > 0 and args.mode in ("fused", "inplace", "blocked"):
+        if nlaunch > 0 and args.mode in ("fused", "inplace", "fused_soa"):
             t_launch = 1e-3 * kms / nlaunch
             achieved = 1e-9 * algo_bytes * local_sites / t_launch
             roofline = {
@@ -326,9 +329,13 @@ def main():
             # inside this process (they need their own rocprofv3 --pmc
             # passes): quote the committed measurement of the same kernel
             # on the same workload, if this run is that workload
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+            pmc = os.path.join(ROOT, "profiles",
+                               "r01_blocked_pmc_hbm_traffic.json"
+                               if order.startswith("blocked")
+                               else "r01_pmc_hbm_traffic.json")
             same = (args.nvel == 19 and tuple(args.size) == (256, 256, 256)
-                    and args.hydro and world == 1 and args.mode == "fused"
+                    and args.hydro and world == 1
+                    and args.mode in ("fused", "fused_soa")
                     and args.scheme == "m10" and args.fe == "none")
             if same and os.path.exists(pmc):
                 with open(pmc) as fp:
@@ -336,10 +343,12 @@ def main():
                 roofline["traffic"] = int(t["traffic_bytes"])
                 roofline["traffic_unit"] = "bytes per launch"
                 roofline["traffic_source"] = (
-                    "profiles/r01_pmc_hbm_traffic.json: separate rocprofv3 "
+                    "profiles/%s: separate rocprofv3 "
                     "--pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                     "FETCH_SIZE x2 (gfx950); algorithmic = %d"
-                    % t["algorithmic_bytes_360_per_lup"])
+                    % (os.path.basename(pmc),
+                       t.get("algorithmic_bytes",
+                             t.get("algorithmic_bytes_360_per_lup"))))
         out = {
             "metric": "MLUPS (million lattice updates/sec) D3Q%d %dx%dx%d"
                       % (args.nvel, *ntotal),
@@ -359,6 +368,7 @@ def main():
                             "lb_collide+lb_halo+lb_propagation per step"
                             % (args.nvel, args.scheme.upper(), *ntotal),
                 "mode": args.mode,
+                "order": order,
                 "hydro_io": bool(args.hydro),
                 "free_energy": args.fe if args.fe == "none" else
                 "%s (%d-point gradients, advection order %d, from %s)"

@@ -299,6 +299,7 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   lb->kp.xcd_group = 16;
   lb->kp.lds_cap = 65536;
   lb->x_packed = 1;
+  lb->use_blocked = 1;               /* profiles/r01_blocked_order.txt */
   lb->grad_npt = 7;
   lb->adv_order = 1;
 

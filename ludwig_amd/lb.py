@@ -21,9 +21,9 @@ from . import lib as _l
 
 M10, BGK, TRT = 0, 1, 2                    # lb_relaxation_enum_t
 EAGER, FUSED, INPLACE = 0, 1, 2            # lbmi_mode_t
-# Python-side shorthand: FUSED with the deferred state kept in the blocked
-# order (lbmi_tune "blocked" = 1)
-FUSED_BLOCKED = 3
+# Python-side shorthand: FUSED with the deferred state kept in the reference's
+# SoA order (lbmi_tune "blocked" = 0) instead of the default blocked order
+FUSED_SOA = 3
 HALO_FULL, HALO_REDUCED = 0, 2             # lbmi_halo_t
 _SCHEMES = {"m10": M10, "bgk": BGK, "trt": TRT}
 
@@ -97,7 +97,7 @@ class LB:
         opts.nlocal[:] = list(nlocal)
         opts.nhalo = nhalo
         opts.device = device
-        opts.mode = FUSED if mode == FUSED_BLOCKED else mode
+        opts.mode = FUSED if mode == FUSED_SOA else mode
         opts.halo_scheme = halo_scheme
         opts.cartsz = cartsz
         opts.cartrank = cartrank
@@ -118,8 +118,8 @@ class LB:
             st = torch.cuda.current_stream(self.device).cuda_stream
             _l.check(self._lib.lbmi_set_stream(self._h, ctypes.c_void_p(st)))
         _l.check(self._lib.lbmi_lb_bind(self._h, _ptr(self._a), _ptr(self._b)))
-        if mode == FUSED_BLOCKED:
-            self.tune("blocked", 1)
+        if mode == FUSED_SOA:
+            self.tune("blocked", 0)
 
     # -- life cycle ---------------------------------------------------------
 

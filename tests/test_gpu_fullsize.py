@@ -86,7 +86,7 @@ def test_modes_agree_256():
     nsteps = 4
     res = []
     for mode in (ludwig_amd.EAGER, ludwig_amd.FUSED, ludwig_amd.INPLACE,
-                 ludwig_amd.FUSED_BLOCKED):
+                 ludwig_amd.FUSED_SOA):
         lb = _setup(mode, (1e-6, 0.0, 0.0))
         hy = ludwig_amd.Hydro(lb.nall, lb.device)
         for _ in range(nsteps):

@@ -128,7 +128,7 @@ def test_reduced_halo_same_interior(name):
 
 # --- whole time steps: EAGER and FUSED against the reference -----------------
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "blocked"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "fused_soa"])
 @pytest.mark.parametrize("halo_scheme", [0, 2], ids=["full", "reduced"])
 @pytest.mark.parametrize("name", golden_names())
 def test_steps_vs_reference(name, mode, halo_scheme):
@@ -175,10 +175,10 @@ def test_fused_equals_eager_bitwise_inputs(name):
         lb.free()
     assert relmax(out[1], out[0]) < 1e-14
     assert relmax(out[2], out[0]) < 1e-14
-    assert np.array_equal(out[3], out[1])       # blocked order: same arithmetic
+    assert np.array_equal(out[3], out[1])       # blocked / SoA order: same arithmetic
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3], ids=["fused", "inplace", "blocked"])
+@pytest.mark.parametrize("mode", [1, 2, 3], ids=["fused", "inplace", "fused_soa"])
 @pytest.mark.parametrize("name", ["q19_bgk_ffield", "q27_m10_ffield", "q19_m10_solid"])
 def test_flush_at_every_call_point(name, mode):
     """A device-to-host copy (which flushes) placed after ANY call of ANY
@@ -291,7 +291,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "blocked"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "fused_soa"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "q%d-%s-%s" % (c[0], "x".join(map(str, c[1])), c[3]))
 def test_seeded_vs_oracle(case, mode):
     import ludwig_amd
@@ -356,7 +356,7 @@ def test_field_halo(nhalo):
 
 # --- reference regression log on the device ---------------------------------
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "blocked"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "fused_soa"])
 def test_regression_log_1dp(mode):
     import ludwig_amd
     case = load_expected()["serial-dist-1dp"]
@@ -510,7 +510,7 @@ def test_slabs_equal_single_domain(nvel, nslab, halo_scheme, fused):
                                                 (27, (9, 16, 14), 1),
                                                 (19, (12, 12, 12), 2)])
 def test_blocked_order_is_invisible(nvel, nlocal, nhalo):
-    """lbmi_tune("blocked"): the deferred state lives in another order, and
+    """FUSED default ("blocked" = 1): the deferred state lives in another order, and
     nothing a caller can observe changes -- a copy out (which flushes) after
     ANY call of ANY step returns what EAGER holds there, bit for bit with
     the unblocked FUSED run, and the run continues undisturbed."""
@@ -539,15 +539,16 @@ def test_blocked_order_is_invisible(nvel, nlocal, nhalo):
         lb.free()
         return seen, final, u, orders
 
-    _, ref_final, ref_u, _ = run(1, None)
-    _, final, u, orders = run(3, None)
+    _, ref_final, ref_u, ref_orders = run(3, None)     # FUSED, SoA order
+    _, final, u, orders = run(1, None)                 # FUSED, default
+    assert 1 not in ref_orders
     assert 1 in orders, "the blocked order was never used"
     assert np.array_equal(final, ref_final)
     assert np.array_equal(u, ref_u)
     for n in range(nsteps):
         for k in range(3):
-            ref_seen, ref_final = run(0, (n, k))
-            seen, final, _, _ = run(3, (n, k))
+            ref_seen, ref_final, _, _ = run(0, (n, k))
+            seen, final, _, _ = run(1, (n, k))
             assert relmax(seen, ref_seen) < 1e-14, (n, k)
             assert relmax(final, ref_final) < 1e-14, (n, k)
 
@@ -562,6 +563,7 @@ def test_blocked_order_switch_mid_run():
     outs = []
     for toggle in (False, True):
         lb = ludwig_amd.LB(19, nlocal, 1, mode=ludwig_amd.FUSED)
+        lb.tune("blocked", 0)
         lb.relaxation_set("bgk", 0.1, 0.1)
         hy = ludwig_amd.Hydro(lb.nall, lb.device)
         lb.lb_memcpy_h2d(f0)
