@@ -321,6 +321,32 @@ int lbmi_symmetric_step_grad(lbmi_t * lb, double a, double b, double kappa,
 int lbmi_lb_records_pack(lbmi_t * lb, double * records);
 int lbmi_lb_records_unpack(lbmi_t * lb, const double * records);
 
+/* The distribution files of the reference's MPI-IO mode with one file
+ * (lb_io_write / lb_io_read, model.c:1568-1649; io_impl_mpio.c:179-272):
+ *   <dir>/dist-metadata.001-001          JSON, io_metadata_write
+ *                                        (io_metadata.c), written once
+ *   <dir>/dist-%9.9d.001-001 (timestep)  the record stream of the GLOBAL
+ *                                        lattice in (ic, jc, kc) order
+ * A rank of an X-slab decomposition owns the contiguous byte range of its
+ * x-planes: ntotal_x = global extent in X, offset_x = global index of this
+ * rank's first plane (single rank: nlocal[X], 0). Every rank writes / reads
+ * its range with pwrite / pread (no MPI needed); the rank with offset_x == 0
+ * writes the metadata. The records pass through fprime (dead at that point
+ * of a step) and a pinned staging buffer: no extra device memory.
+ * lbmi_lb_io_read replaces the state (nothing stays pending). */
+int lbmi_lb_io_write(lbmi_t * lb, const char * dir, int timestep,
+		     int ntotal_x, int offset_x);
+int lbmi_lb_io_read(lbmi_t * lb, const char * dir, int timestep,
+		    int ntotal_x, int offset_x);
+
+/* Host-only helpers (no device needed): the metadata file for a lattice of
+ * ntotal sites with nel = ndist*nvel doubles per record, and the data file
+ * name of a time step (io_subfile_name, io_subfile.c). */
+int lbmi_io_metadata_write(const char * dir, const char * stub, int nel,
+			   const int ntotal[3]);
+int lbmi_io_filename(const char * dir, const char * stub, int timestep,
+		     char * buf, size_t bufsz);
+
 /* ---- streams / synchronisation ----------------------------------------- */
 
 int lbmi_synchronize(lbmi_t * lb);

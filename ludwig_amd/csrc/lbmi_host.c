@@ -14,10 +14,13 @@
 
 #define __HIP_PLATFORM_AMD__ 1
 
+#include <errno.h>
+#include <fcntl.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -1397,6 +1400,189 @@ int lbmi_lb_records_unpack(lbmi_t * lb, const double * records) {
   }
   KCHECK(lbmi_k_records(&lb->kp, lb->f, (double *) records, 0, lb->stream));
   return 0;
+}
+
+/*****************************************************************************
+ *
+ *  Distribution files (lb_io_write / lb_io_read, model.c:1568-1649, in the
+ *  reference's MPI-IO mode with an i/o grid 1_1_1)
+ *
+ *****************************************************************************/
+
+int lbmi_io_filename(const char * dir, const char * stub, int timestep,
+		     char * buf, size_t bufsz) {
+  int n;
+  if (dir == NULL || stub == NULL || buf == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  /* io_subfile_name: "%s-%9.9d.%3.3d-%3.3d", file index 1 of 1 */
+  n = snprintf(buf, bufsz, "%s/%s-%9.9d.%3.3d-%3.3d", dir, stub, timestep, 1, 1);
+  if (n < 0 || (size_t) n >= bufsz) return lbmi_fail(LBMI_ERR_ARGUMENT, "file name too long");
+  return 0;
+}
+
+int lbmi_io_metadata_write(const char * dir, const char * stub, int nel,
+			   const int ntotal[3]) {
+  char fn[1024];
+  FILE * fp = NULL;
+  int n;
+  if (dir == NULL || stub == NULL || ntotal == NULL || nel < 1) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_io_metadata_write: bad argument");
+  }
+  n = snprintf(fn, sizeof(fn), "%s/%s-metadata.%3.3d-%3.3d", dir, stub, 1, 1);
+  if (n < 0 || (size_t) n >= sizeof(fn)) return lbmi_fail(LBMI_ERR_ARGUMENT, "file name too long");
+  fp = fopen(fn, "w");
+  if (fp == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "%s: %s", fn, strerror(errno));
+  /* The objects and keys of io_metadata_to_json (io_metadata.c): cs_to_json,
+   * io_options_to_json (defaults of io_options_with_mode(IO_MODE_MPIIO)),
+   * io_element_to_json, io_subfile_to_json; laid out as cJSON_Print does */
+  fprintf(fp, "{\n");
+  fprintf(fp, "\t\"coords\":\t{\n");
+  fprintf(fp, "\t\t\"options\":\t{\n");
+  fprintf(fp, "\t\t\t\"System size (total)\":\t[%d, %d, %d],\n", ntotal[0], ntotal[1], ntotal[2]);
+  fprintf(fp, "\t\t\t\"Periodic boundaries\":\t[1, 1, 1],\n");
+  fprintf(fp, "\t\t\t\"Left-end limit Lmin\":\t[0.5, 0.5, 0.5]\n");
+  fprintf(fp, "\t\t},\n");
+  fprintf(fp, "\t\t\"lees_edwards\":\t{\n");
+  fprintf(fp, "\t\t\t\"Number of planes\":\t0\n");
+  fprintf(fp, "\t\t}\n");
+  fprintf(fp, "\t},\n");
+  fprintf(fp, "\t\"io_options\":\t{\n");
+  fprintf(fp, "\t\t\"Mode\":\t\"mpiio\",\n");
+  fprintf(fp, "\t\t\"Record format\":\t\"binary\",\n");
+  fprintf(fp, "\t\t\"Metadata version\":\t3,\n");
+  fprintf(fp, "\t\t\"Report\":\ttrue,\n");
+  fprintf(fp, "\t\t\"Asynchronous\":\tfalse,\n");
+  fprintf(fp, "\t\t\"Compression level\":\t0,\n");
+  fprintf(fp, "\t\t\"I/O grid\":\t[1, 1, 1]\n");
+  fprintf(fp, "\t},\n");
+  fprintf(fp, "\t\"io_element\":\t{\n");
+  fprintf(fp, "\t\t\"MPI_Datatype\":\t\"MPI_DOUBLE\",\n");
+  fprintf(fp, "\t\t\"Size (bytes)\":\t8,\n");
+  fprintf(fp, "\t\t\"Count\":\t%d,\n", nel);
+  fprintf(fp, "\t\t\"Endianness\":\t\"LITTLE_ENDIAN\"\n");
+  fprintf(fp, "\t},\n");
+  fprintf(fp, "\t\"io_subfile\":\t{\n");
+  fprintf(fp, "\t\t\"Number of files\":\t1,\n");
+  fprintf(fp, "\t\t\"File index\":\t0,\n");
+  fprintf(fp, "\t\t\"Topology\":\t[1, 1, 1],\n");
+  fprintf(fp, "\t\t\"Coordinate\":\t[0, 0, 0],\n");
+  fprintf(fp, "\t\t\"Data ndims\":\t3,\n");
+  fprintf(fp, "\t\t\"File size (sites)\":\t[%d, %d, %d],\n", ntotal[0], ntotal[1], ntotal[2]);
+  fprintf(fp, "\t\t\"File offset (sites)\":\t[0, 0, 0]\n");
+  fprintf(fp, "\t}\n");
+  fprintf(fp, "}");
+  if (fclose(fp) != 0) return lbmi_fail(LBMI_ERR_ARGUMENT, "%s: %s", fn, strerror(errno));
+  return 0;
+}
+
+/* records <-> file through a pinned staging buffer; dev = fprime */
+
+#define LBMI_IO_CHUNK ((size_t) 32*1024*1024)
+
+static int lbmi_io_transfer(lbmi_t * lb, const char * fn, int writing,
+			    double * dev, size_t nbytes, off_t offset) {
+  void * stage = NULL;
+  size_t done = 0;
+  int fd = -1;
+  int ifail = 0;
+
+  fd = writing ? open(fn, O_WRONLY | O_CREAT, 0644) : open(fn, O_RDONLY);
+  if (fd < 0) return lbmi_fail(LBMI_ERR_ARGUMENT, "%s: %s", fn, strerror(errno));
+  if (hipHostMalloc(&stage, LBMI_IO_CHUNK, hipHostMallocDefault) != hipSuccess) {
+    close(fd);
+    return lbmi_fail(LBMI_ERR_HIP, "hipHostMalloc of the i/o staging buffer");
+  }
+  while (done < nbytes && ifail == 0) {
+    size_t n = nbytes - done;
+    size_t io = 0;
+    if (n > LBMI_IO_CHUNK) n = LBMI_IO_CHUNK;
+    if (writing) {
+      if (hipMemcpyAsync(stage, (char *) dev + done, n, hipMemcpyDeviceToHost,
+			 lb->stream) != hipSuccess ||
+	  hipStreamSynchronize(lb->stream) != hipSuccess) {
+	ifail = lbmi_fail(LBMI_ERR_HIP, "device to host copy of records");
+	break;
+      }
+    }
+    while (io < n) {
+      ssize_t r = writing
+	? pwrite(fd, (char *) stage + io, n - io, offset + (off_t) (done + io))
+	: pread(fd, (char *) stage + io, n - io, offset + (off_t) (done + io));
+      if (r <= 0) {
+	ifail = lbmi_fail(LBMI_ERR_ARGUMENT, "%s: %s", fn,
+			  (r == 0) ? "file too short" : strerror(errno));
+	break;
+      }
+      io += (size_t) r;
+    }
+    if (ifail) break;
+    if (!writing) {
+      if (hipMemcpyAsync((char *) dev + done, stage, n, hipMemcpyHostToDevice,
+			 lb->stream) != hipSuccess ||
+	  hipStreamSynchronize(lb->stream) != hipSuccess) {
+	ifail = lbmi_fail(LBMI_ERR_HIP, "host to device copy of records");
+	break;
+      }
+    }
+    done += n;
+  }
+  hipHostFree(stage);
+  if (close(fd) != 0 && ifail == 0) {
+    ifail = lbmi_fail(LBMI_ERR_ARGUMENT, "%s: %s", fn, strerror(errno));
+  }
+  return ifail;
+}
+
+static int lbmi_io_args(lbmi_t * lb, const char * dir, int ntotal_x,
+			int offset_x) {
+  if (lb == NULL || dir == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+  if (offset_x < 0 || offset_x + lb->kp.nlocal[X] > ntotal_x) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "planes %d..%d outside 0..%d", offset_x,
+		     offset_x + lb->kp.nlocal[X] - 1, ntotal_x - 1);
+  }
+  return 0;
+}
+
+int lbmi_lb_io_write(lbmi_t * lb, const char * dir, int timestep,
+		     int ntotal_x, int offset_x) {
+  char fn[1024];
+  size_t plane, nbytes;
+  int ifail = lbmi_io_args(lb, dir, ntotal_x, offset_x);
+  if (ifail) return ifail;
+  HIPCHECK(hipSetDevice(lb->device));
+  ifail = lbmi_lb_flush(lb);
+  if (ifail) return ifail;
+  if (offset_x == 0) {
+    int ntotal[3] = {ntotal_x, lb->kp.nlocal[Y], lb->kp.nlocal[Z]};
+    ifail = lbmi_io_metadata_write(dir, "dist", lb->kp.nvel, ntotal);
+    if (ifail) return ifail;
+  }
+  ifail = lbmi_io_filename(dir, "dist", timestep, fn, sizeof(fn));
+  if (ifail) return ifail;
+  /* fprime is dead between steps once nothing is pending: pack there */
+  KCHECK(lbmi_k_records(&lb->kp, lb->f, lb->fprime, 1, lb->stream));
+  plane = sizeof(double)*(size_t) lb->kp.nvel*lb->kp.nlocal[Y]*lb->kp.nlocal[Z];
+  nbytes = plane*(size_t) lb->kp.nlocal[X];
+  return lbmi_io_transfer(lb, fn, 1, lb->fprime, nbytes,
+			  (off_t) (plane*(size_t) offset_x));
+}
+
+int lbmi_lb_io_read(lbmi_t * lb, const char * dir, int timestep,
+		    int ntotal_x, int offset_x) {
+  char fn[1024];
+  size_t plane, nbytes;
+  int ifail = lbmi_io_args(lb, dir, ntotal_x, offset_x);
+  if (ifail) return ifail;
+  HIPCHECK(hipSetDevice(lb->device));
+  ifail = lbmi_io_filename(dir, "dist", timestep, fn, sizeof(fn));
+  if (ifail) return ifail;
+  plane = sizeof(double)*(size_t) lb->kp.nvel*lb->kp.nlocal[Y]*lb->kp.nlocal[Z];
+  nbytes = plane*(size_t) lb->kp.nlocal[X];
+  ifail = lbmi_io_transfer(lb, fn, 0, lb->fprime, nbytes,
+			   (off_t) (plane*(size_t) offset_x));
+  if (ifail) return ifail;
+  /* replaces the state: whatever was pending is dropped */
+  return lbmi_lb_records_unpack(lb, lb->fprime);
 }
 
 int lbmi_synchronize(lbmi_t * lb) {

@@ -339,6 +339,20 @@ class LB:
     def synchronize(self):
         _l.check(self._lib.lbmi_synchronize(self._h))
 
+    def lb_io_write(self, directory, timestep, ntotal_x=None, offset_x=0):
+        """lb_io_write (model.c:1568): dist-metadata.001-001 and
+        dist-<timestep>.001-001 in `directory` (MPI-IO mode, one file)."""
+        nx = self.nlocal[0] if ntotal_x is None else ntotal_x
+        _l.check(self._lib.lbmi_lb_io_write(self._h, str(directory).encode(),
+                                            int(timestep), nx, offset_x))
+
+    def lb_io_read(self, directory, timestep, ntotal_x=None, offset_x=0):
+        """lb_io_read (model.c:1622): replace the state by the records of
+        dist-<timestep>.001-001."""
+        nx = self.nlocal[0] if ntotal_x is None else ntotal_x
+        _l.check(self._lib.lbmi_lb_io_read(self._h, str(directory).encode(),
+                                           int(timestep), nx, offset_x))
+
     def state(self):
         """(halo pending, propagation pending, order of f) -- lbmi_lb_state."""
         st = (ctypes.c_int * 3)()
@@ -367,6 +381,21 @@ class LB:
     def comm_init(self, unique_id):
         buf = ctypes.create_string_buffer(bytes(unique_id), _l.UNIQUE_ID_BYTES)
         _l.check(self._lib.lbmi_comm_init(self._h, buf))
+
+
+def io_metadata_write(directory, stub, nel, ntotal):
+    """io_metadata_write (io_metadata.c): <stub>-metadata.001-001. Host only."""
+    n = (ctypes.c_int * 3)(*[int(x) for x in ntotal])
+    _l.check(_l.library().lbmi_io_metadata_write(str(directory).encode(),
+                                                 stub.encode(), int(nel), n))
+
+
+def io_filename(directory, stub, timestep):
+    """io_subfile_name: <stub>-%9.9d.001-001. Host only."""
+    buf = ctypes.create_string_buffer(1024)
+    _l.check(_l.library().lbmi_io_filename(str(directory).encode(),
+                                           stub.encode(), int(timestep), buf, 1024))
+    return buf.value.decode()
 
 
 def model(nvel):

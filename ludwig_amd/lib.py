@@ -88,6 +88,12 @@ SYMBOLS = [
                                       _vp, _vp, _i]),
     ("lbmi_lb_records_pack", _i, [_vp, _vp]),
     ("lbmi_lb_records_unpack", _i, [_vp, _vp]),
+    ("lbmi_lb_io_write", _i, [_vp, ctypes.c_char_p, _i, _i, _i]),
+    ("lbmi_lb_io_read", _i, [_vp, ctypes.c_char_p, _i, _i, _i]),
+    ("lbmi_io_metadata_write", _i, [ctypes.c_char_p, ctypes.c_char_p, _i,
+                                    ctypes.POINTER(_i)]),
+    ("lbmi_io_filename", _i, [ctypes.c_char_p, ctypes.c_char_p, _i,
+                              ctypes.c_char_p, ctypes.c_size_t]),
     ("lbmi_synchronize", _i, [_vp]),
     ("lbmi_stream", _i, [_vp, ctypes.POINTER(_vp)]),
     ("lbmi_set_stream", _i, [_vp, _vp]),

@@ -114,6 +114,32 @@ def run_fe_case(case, tmp):
             "phi_new": load("phi_new", ())}
 
 
+# name, nvel, (nx, ny, nz), timestep
+IO_CASES = [
+    ("io_q19", 19, (6, 5, 4), 7),
+    ("io_q27", 27, (5, 4, 6), 123456),
+]
+
+
+def run_io_case(case, tmp):
+    """lb_io_write of the reference (MPI-IO mode, one file): the metadata
+    file (text), the data file (bytes) and the f they were written from."""
+    name, nvel, n, timestep = case
+    exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
+    d = os.path.join(tmp, name)
+    os.makedirs(d)
+    subprocess.run([exe, "io", d, *map(str, n), str(timestep)], check=True,
+                   stdout=subprocess.DEVNULL)
+    datafile = "dist-%9.9d.001-001" % timestep
+    nall = tuple(m + 2 for m in n)
+    return {"metadata": np.array(open(os.path.join(d, "dist-metadata.001-001")).read()),
+            "datafile": np.array(datafile),
+            "data": np.fromfile(os.path.join(d, datafile), dtype=np.uint8),
+            "f0": np.fromfile(os.path.join(d, "written.f0.f64"),
+                              dtype="<f8").reshape((nvel,) + nall),
+            "timestep": np.array(timestep)}
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
@@ -124,6 +150,11 @@ def main():
             print("wrote", fn, os.path.getsize(fn))
         for case in FE_CASES:
             out = run_fe_case(case, tmp)
+            fn = os.path.join(GOLD, case[0] + ".npz")
+            np.savez_compressed(fn, **out)
+            print("wrote", fn, os.path.getsize(fn))
+        for case in IO_CASES:
+            out = run_io_case(case, tmp)
             fn = os.path.join(GOLD, case[0] + ".npz")
             np.savez_compressed(fn, **out)
             print("wrote", fn, os.path.getsize(fn))

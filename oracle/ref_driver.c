@@ -33,6 +33,9 @@
  *               pth_force_fluid_driver, then phi_cahn_hilliard with advection
  *               of order 1..4 in a prescribed velocity field; nhalo = 2)
  *
+ *    ref_driver io <dir> nx ny nz timestep      (lb_io_write into <dir>)
+ *    ref_driver ioread <dir> nx ny nz timestep  (lb_io_read from <dir>)
+ *
  *  scheme: m10 | bgk | trt
  *
  *****************************************************************************/
@@ -44,6 +47,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -335,6 +339,75 @@ static int run_fe(int argc, char ** argv) {
   return 0;
 }
 
+/*****************************************************************************
+ *
+ *  run_io
+ *
+ *  "io" mode: ref_driver io <dir> nx ny nz timestep
+ *    lb_io_write (model.c:1568-1614, MPI-IO mode) of the synthetic state in
+ *    <dir>: the metadata file dist.json and the data file; also <dir>/f0.f64.
+ *  "ioread" mode: ref_driver ioread <dir> nx ny nz timestep
+ *    lb_io_read (model.c:1622-1649) of the data file found in <dir>, then
+ *    <dir>/readback.f64 = the whole f array.
+ *
+ *****************************************************************************/
+
+static int run_io(int argc, char ** argv) {
+
+  int reading = (strcmp(argv[1], "ioread") == 0);
+  const char * dir = argv[2];
+  case_t c = {0};
+  int timestep = atoi(argv[6]);
+  pe_t * pe = NULL;
+  cs_t * cs = NULL;
+  lb_t * lb = NULL;
+
+  c.ntotal[X] = atoi(argv[3]);
+  c.ntotal[Y] = atoi(argv[4]);
+  c.ntotal[Z] = atoi(argv[5]);
+  c.nhalo = 1;
+
+  if (chdir(dir) != 0) {
+    fprintf(stderr, "cannot chdir to %s\n", dir);
+    return 1;
+  }
+
+  MPI_Init(&argc, &argv);
+  pe_create(MPI_COMM_WORLD, PE_QUIET, &pe);
+  cs_create(pe, &cs);
+  cs_ntotal_set(cs, c.ntotal);
+  cs_nhalo_set(cs, c.nhalo);
+  cs_init(cs);
+  {
+    lb_data_options_t opts = lb_data_options_default();
+    opts.ndim = NDIM;
+    opts.nvel = NVEL;
+    opts.ndist = 1;
+    opts.iodata.input = io_options_with_mode(IO_MODE_MPIIO);
+    opts.iodata.output = io_options_with_mode(IO_MODE_MPIIO);
+    lb_data_create(pe, cs, &opts, &lb);
+  }
+  {
+    io_event_t event = {0};
+    size_t nf = (size_t) lb->nsite*lb->model.nvel;
+    if (reading) {
+      lb_io_read(lb, timestep, &event);
+      dump("readback", "f", lb->f, nf);
+    }
+    else {
+      init_f(cs, lb, &c);
+      dump("written", "f0", lb->f, nf);
+      lb_io_write(lb, timestep, &event);
+    }
+  }
+  lb_free(lb);
+  cs_free(cs);
+  pe_free(pe);
+  MPI_Finalize();
+
+  return 0;
+}
+
 int main(int argc, char ** argv) {
 
   int timing = 0;
@@ -351,6 +424,10 @@ int main(int argc, char ** argv) {
 
   if ((argc == 10 || argc == 12) && strcmp(argv[1], "fe") == 0) {
     return run_fe(argc, argv);
+  }
+  if (argc == 7 && (strcmp(argv[1], "io") == 0 ||
+		    strcmp(argv[1], "ioread") == 0)) {
+    return run_io(argc, argv);
   }
 
   if (argc >= 2 && strcmp(argv[1], "dump") == 0 && argc == 16) {

@@ -27,6 +27,15 @@ def golden_fe_names():
                   for f in glob.glob(os.path.join(GOLDEN_DIR, "fe_*.npz")))
 
 
+def load_io_golden(name):
+    """Files written by the reference's lb_io_write (io_q19, io_q27): the
+    metadata text, the data file name and bytes, and the f they hold."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    return {"metadata": str(z["metadata"]), "datafile": str(z["datafile"]),
+            "data": z["data"].tobytes(), "f0": z["f0"],
+            "timestep": int(z["timestep"])}
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     g = {k: z[k] for k in z.files}

@@ -1,0 +1,153 @@
+"""Row f3 on the device: lbmi_lb_io_write / lbmi_lb_io_read against files the
+compiled reference wrote (tests/golden/io_*.npz), and -- where oracle/_ref
+travelled to this box -- the reference reading files written here."""
+
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.common import interior, load_io_golden          # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.path.join(HERE, "..", "oracle", "_ref")
+CASES = [("io_q19", 19), ("io_q27", 27)]
+
+
+def _nlocal(g):
+    return tuple(n - 2 for n in g["f0"].shape[1:])
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["eager", "fused", "inplace"])
+@pytest.mark.parametrize("name,nvel", CASES)
+def test_write_identical_to_reference_files(name, nvel, mode, tmp_path):
+    import ludwig_amd
+    g = load_io_golden(name)
+    lb = ludwig_amd.LB(nvel, _nlocal(g), 1, mode=mode)
+    lb.lb_memcpy_h2d(g["f0"])
+    lb.lb_io_write(tmp_path, g["timestep"])
+    lb.synchronize()
+    assert open(tmp_path / "dist-metadata.001-001").read() == g["metadata"]
+    assert open(tmp_path / g["datafile"], "rb").read() == g["data"]
+    # the state is untouched by writing
+    assert np.array_equal(interior(lb.lb_memcpy_d2h(), 1), interior(g["f0"], 1))
+    lb.free()
+
+
+@pytest.mark.parametrize("name,nvel", CASES)
+def test_read_reference_file(name, nvel, tmp_path):
+    import ludwig_amd
+    g = load_io_golden(name)
+    with open(tmp_path / g["datafile"], "wb") as fp:
+        fp.write(g["data"])
+    lb = ludwig_amd.LB(nvel, _nlocal(g), 1, mode=ludwig_amd.FUSED)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device)
+    lb.relaxation_set("bgk", 0.1, 0.1)
+    lb.step(hy)                                # leave something pending
+    lb.lb_io_read(tmp_path, g["timestep"])
+    assert lb.state() == (0, 0, 0)             # reading replaces the state
+    assert np.array_equal(interior(lb.lb_memcpy_d2h(), 1), interior(g["f0"], 1))
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.lb_io_read(tmp_path, g["timestep"] + 1)       # no such file
+    lb.free()
+
+
+def test_restart_continues_bitwise(tmp_path):
+    """Write in the middle of a FUSED run (deferred, blocked state), read
+    into a fresh EAGER handle, continue both: same distributions."""
+    import ludwig_amd
+    from oracle import lb_oracle as lbo
+    nlocal = (20, 12, 16)
+    p = lbo.make_param(19, nlocal, 1, "m10", 0.1, 0.3)
+    f0 = lbo.init_synthetic(p)
+    a = ludwig_amd.LB(19, nlocal, 1, mode=ludwig_amd.FUSED)
+    a.relaxation_set("m10", 0.1, 0.3)
+    ha = ludwig_amd.Hydro(a.nall, a.device)
+    a.lb_memcpy_h2d(f0)
+    for _ in range(3):
+        a.step(ha)
+    assert a.state()[2] == 1
+    a.lb_io_write(tmp_path, 3)
+    b = ludwig_amd.LB(19, nlocal, 1, mode=ludwig_amd.EAGER)
+    b.relaxation_set("m10", 0.1, 0.3)
+    hb = ludwig_amd.Hydro(b.nall, b.device)
+    b.lb_io_read(tmp_path, 3)
+    for _ in range(3):
+        a.step(ha)
+        b.step(hb)
+    assert np.array_equal(interior(a.lb_memcpy_d2h(), 1), interior(b.lb_memcpy_d2h(), 1))
+    a.free()
+    b.free()
+
+
+def test_slabs_write_one_file(tmp_path):
+    """Two X slabs write their byte ranges of ONE file; a third handle reads
+    the whole, and each slab reads its part back."""
+    import ludwig_amd
+    g = load_io_golden("io_q19")
+    n = _nlocal(g)
+    cuts = [(0, 2), (2, 6)]
+    for x0, x1 in reversed(cuts):              # order must not matter
+        lb = ludwig_amd.LB(19, (x1 - x0, n[1], n[2]), 1)
+        f = np.zeros((19, x1 - x0 + 2, n[1] + 2, n[2] + 2))
+        interior(f, 1)[...] = interior(g["f0"], 1)[:, x0:x1]
+        lb.lb_memcpy_h2d(f)
+        lb.lb_io_write(tmp_path, 7, ntotal_x=n[0], offset_x=x0)
+        lb.free()
+    assert open(tmp_path / g["datafile"], "rb").read() == g["data"]
+    assert open(tmp_path / "dist-metadata.001-001").read() == g["metadata"]
+    x0, x1 = cuts[1]
+    lb = ludwig_amd.LB(19, (x1 - x0, n[1], n[2]), 1)
+    lb.lb_io_read(tmp_path, 7, ntotal_x=n[0], offset_x=x0)
+    assert np.array_equal(interior(lb.lb_memcpy_d2h(), 1),
+                          interior(g["f0"], 1)[:, x0:x1])
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.lb_io_write(tmp_path, 7, ntotal_x=n[0], offset_x=x0 + 1)   # outside
+    lb.free()
+
+
+@pytest.mark.parametrize("name,nvel", CASES)
+def test_reference_reads_files_written_here(name, nvel, tmp_path):
+    exe = os.path.join(REF, "ref_driver_d3q%d" % nvel)
+    if not os.path.exists(exe):
+        pytest.skip("compiled reference (oracle/_ref) not on this box")
+    import ludwig_amd
+    g = load_io_golden(name)
+    n = _nlocal(g)
+    rng = np.random.default_rng(11)
+    f = np.zeros_like(g["f0"])
+    interior(f, 1)[...] = rng.random((nvel,) + n)
+    lb = ludwig_amd.LB(nvel, n, 1)
+    lb.lb_memcpy_h2d(f)
+    lb.lb_io_write(tmp_path, 42)
+    lb.free()
+    subprocess.run([exe, "ioread", str(tmp_path), *map(str, n), "42"], check=True,
+                   stdout=subprocess.DEVNULL)
+    back = np.fromfile(tmp_path / "readback.f.f64", dtype="<f8").reshape(f.shape)
+    assert np.array_equal(interior(back, 1), interior(f, 1))
+
+
+def test_large_file_chunks(tmp_path):
+    """More than one staging chunk (32 MiB): 96^3 D3Q19 = 134 MB."""
+    import ludwig_amd
+    import torch
+    n = (96, 96, 96)
+    lb = ludwig_amd.LB(19, n, 1)
+    g = torch.Generator(device=lb.device)
+    g.manual_seed(5)
+    lb.f[:, 1:-1, 1:-1, 1:-1] = torch.rand((19,) + n, dtype=torch.float64,
+                                           device=lb.device, generator=g)
+    ref = lb.f[:, 1:-1, 1:-1, 1:-1].clone()
+    lb.lb_io_write(tmp_path, 1)
+    assert os.path.getsize(tmp_path / "dist-000000001.001-001") == 19 * 8 * 96 ** 3
+    rec = np.fromfile(tmp_path / "dist-000000001.001-001", dtype="<f8")
+    assert np.array_equal(rec.reshape(n + (19,)),
+                          ref.permute(1, 2, 3, 0).cpu().numpy())
+    lb.f.zero_()
+    lb.lb_io_read(tmp_path, 1)
+    lb.synchronize()
+    assert torch.equal(lb.f[:, 1:-1, 1:-1, 1:-1], ref)
+    lb.free()

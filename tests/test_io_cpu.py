@@ -1,0 +1,73 @@
+"""Row f3, host side: the distribution files of the reference's MPI-IO mode
+(lb_io_write, model.c:1568-1614) -- metadata JSON, file names and the record
+stream -- against files the compiled reference wrote (tests/golden/io_*.npz).
+No GPU: the metadata writer and the file-name helper are host-only entry
+points of the C-ABI; the record stream is checked on the oracle."""
+
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import lb_oracle as lbo
+from tests.common import interior, load_io_golden
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.path.join(HERE, "..", "oracle", "_ref")
+CASES = [("io_q19", 19), ("io_q27", 27)]
+
+
+def _nlocal(g):
+    return tuple(n - 2 for n in g["f0"].shape[1:])
+
+
+@pytest.mark.parametrize("name,nvel", CASES)
+def test_metadata_file_identical_to_reference(name, nvel, tmp_path):
+    import ludwig_amd
+    g = load_io_golden(name)
+    ludwig_amd.io_metadata_write(tmp_path, "dist", nvel, _nlocal(g))
+    text = open(tmp_path / "dist-metadata.001-001").read()
+    assert text == g["metadata"]                  # byte for byte
+
+
+@pytest.mark.parametrize("name,nvel", CASES)
+def test_data_file_name(name, nvel, tmp_path):
+    import ludwig_amd
+    g = load_io_golden(name)
+    fn = ludwig_amd.io_filename(tmp_path, "dist", g["timestep"])
+    assert fn == str(tmp_path / g["datafile"])
+
+
+@pytest.mark.parametrize("name,nvel", CASES)
+def test_oracle_record_stream_is_the_reference_file(name, nvel):
+    g = load_io_golden(name)
+    p = lbo.make_param(nvel, _nlocal(g), 1)
+    rec = lbo.records_pack(p, np.ascontiguousarray(g["f0"]))
+    assert rec.tobytes() == g["data"]
+    f = np.zeros_like(g["f0"])
+    lbo.records_unpack(p, f, np.frombuffer(g["data"], dtype="<f8").copy())
+    assert np.array_equal(interior(f, 1), interior(g["f0"], 1))
+
+
+@pytest.mark.parametrize("name,nvel", CASES)
+def test_reference_reads_our_files(name, nvel, tmp_path):
+    """lb_io_read of the compiled reference on a file pair produced by our
+    host side (metadata by the C-ABI helper, records by the oracle)."""
+    exe = os.path.join(REF, "ref_driver_d3q%d" % nvel)
+    if not os.path.exists(exe):
+        pytest.skip("compiled reference (oracle/_ref) not present")
+    import ludwig_amd
+    g = load_io_golden(name)
+    n = _nlocal(g)
+    p = lbo.make_param(nvel, n, 1)
+    rng = np.random.default_rng(3)
+    f = np.zeros_like(g["f0"])
+    interior(f, 1)[...] = rng.random((nvel,) + n)
+    ludwig_amd.io_metadata_write(tmp_path, "dist", nvel, n)
+    with open(ludwig_amd.io_filename(tmp_path, "dist", 42), "wb") as fp:
+        fp.write(lbo.records_pack(p, f).tobytes())
+    subprocess.run([exe, "ioread", str(tmp_path), *map(str, n), "42"], check=True,
+                   stdout=subprocess.DEVNULL)
+    back = np.fromfile(tmp_path / "readback.f.f64", dtype="<f8").reshape(f.shape)
+    assert np.array_equal(interior(back, 1), interior(f, 1))
