@@ -354,6 +354,197 @@ int lbo_collide(const lbo_param_t * p, double * f, const double * force,
 }
 
 /*
+ * lbo_phi_from_g, lbo_collide_binary
+ *
+ * The two-distribution ("symmetric_lb") step. f2 holds both distributions,
+ * f2[(n*nvel + p)*nsite + index], n = 0 (LB_RHO) and n = 1 (LB_PHI).
+ *
+ * lbo_phi_from_g: phi_lb_to_field (phi_lb_coupler.c:39-112): phi = sum_p g_p
+ * in p order at the interior sites.
+ *
+ * lbo_collide_binary: lb_collision_mrt2_site (collision.c:720-1027) without
+ * noise. The density distribution relaxes as in lbo_collide with the
+ * thermodynamic stress added to the equilibrium stress,
+ *   seq_ab = rho u_a u_b + P_ab,  P_ab of fe_symm_str_v (symmetric.c:371-420,
+ *   see symm_stress below), at EVERY interior site (no status test), and
+ *   writes hydro->u only. The order-parameter distribution is re-projected
+ *   (:955-1024): jphi_a = sum_{p>=1} c_pa g_p relaxed towards phi u_a at rate
+ *   rtau2 = 2/(1 + 2 M) (:1968), sphi_ab = phi u_a u_b + mu delta_ab,
+ *   g_p = w_p (3 jphi.c_p + 4.5 sphi:(c_p c_p - delta/3)) + phi delta_p0,
+ *   mu = a phi + b phi^3 - kappa delsq (symmetric.c:303-316).
+ * For D3Q19 the f -> mode transform carries the reference's literal
+ * coefficient (see lbo_collide).
+ */
+
+int lbo_phi_from_g(const lbo_param_t * p, const double * f2, double * phi) {
+
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+  const double * g;
+
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+  g = f2 + (ptrdiff_t) p->nvel*nsite;
+
+  for (int ic = 1; ic <= p->nlocal[X]; ic++) {
+    for (int jc = 1; jc <= p->nlocal[Y]; jc++) {
+      for (int kc = 1; kc <= p->nlocal[Z]; kc++) {
+	ptrdiff_t index = str[X]*(p->nhalo + ic - 1)
+	  + str[Y]*(p->nhalo + jc - 1) + (p->nhalo + kc - 1);
+	double sum = 0.0;
+	for (int q = 0; q < p->nvel; q++) sum += g[nsite*q + index];
+	phi[index] = sum;
+      }
+    }
+  }
+
+  return 0;
+}
+
+static void symm_stress(double a, double b, double kappa, double phi,
+			const double g[3], double delsq, double s[3][3]);
+
+int lbo_collide_binary(const lbo_param_t * p, double * f2,
+		       const double * force, double a, double b, double kappa,
+		       double mobility, const double * phi,
+		       const double * grad, const double * delsq,
+		       double * u_out) {
+
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+  int nvel = p->nvel;
+  double rtau, rtau_bulk, rtau_ghost[LBO_NVEL_MAX];
+  double rtau2 = 2.0/(1.0 + 2.0*mobility);
+  lbo_model_t model, mphi;
+  const double rdim = 1.0/3.0;
+  double * g;
+
+  if (lbo_model_create(nvel, &model) != 0) return -1;
+  if (lbo_model_create(nvel, &mphi) != 0) return -1;
+  if (relaxation_rates(p, &rtau, &rtau_bulk, rtau_ghost) != 0) return -1;
+  if (nvel == 19) model.ma[13][4] = 0.0;      /* see lbo_collide */
+
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+  g = f2 + (ptrdiff_t) nvel*nsite;
+
+  for (int ic = 1; ic <= p->nlocal[X]; ic++) {
+    for (int jc = 1; jc <= p->nlocal[Y]; jc++) {
+      for (int kc = 1; kc <= p->nlocal[Z]; kc++) {
+
+	ptrdiff_t index = str[X]*(p->nhalo + ic - 1)
+	  + str[Y]*(p->nhalo + jc - 1) + (p->nhalo + kc - 1);
+	double mode[LBO_NVEL_MAX];
+	double fl[LBO_NVEL_MAX];
+	double frc[3], u[3], gr[3];
+	double s[3][3], seq[3][3], sth[3][3], sphi[3][3];
+	double jphi[3] = {0.0, 0.0, 0.0};
+	double rho, rrho, tr_s, tr_seq, ph, mu;
+	int m;
+
+	for (int q = 0; q < nvel; q++) fl[q] = f2[nsite*q + index];
+	for (int ia = 0; ia < 3; ia++) {
+	  frc[ia] = p->fbody[ia];
+	  if (force) frc[ia] += force[nsite*ia + index];
+	}
+	for (m = 0; m < nvel; m++) {
+	  double sum = 0.0;
+	  for (int q = 0; q < nvel; q++) sum += fl[q]*model.ma[m][q];
+	  mode[m] = sum;
+	}
+	rho = mode[0];
+	m = 0;
+	for (int ia = 0; ia < 3; ia++) {
+	  for (int ib = ia; ib < 3; ib++) {
+	    s[ia][ib] = mode[4 + m];
+	    s[ib][ia] = mode[4 + m];
+	    m++;
+	  }
+	}
+	rrho = 1.0/rho;
+	for (int ia = 0; ia < 3; ia++) u[ia] = rrho*(mode[1+ia] + 0.5*frc[ia]);
+
+	ph = phi[index];
+	for (int ia = 0; ia < 3; ia++) gr[ia] = grad[nsite*ia + index];
+	symm_stress(a, b, kappa, ph, gr, delsq[index], sth);
+
+	tr_s = 0.0; tr_seq = 0.0;
+	for (int ia = 0; ia < 3; ia++) {
+	  for (int ib = 0; ib < 3; ib++) {
+	    seq[ia][ib] = rho*u[ia]*u[ib] + sth[ia][ib];
+	  }
+	  tr_s   += s[ia][ia];
+	  tr_seq += seq[ia][ia];
+	}
+	for (int ia = 0; ia < 3; ia++) {
+	  s[ia][ia]   -= rdim*tr_s;
+	  seq[ia][ia] -= rdim*tr_seq;
+	}
+	tr_s = tr_s - rtau_bulk*(tr_s - tr_seq);
+	for (int ia = 0; ia < 3; ia++) {
+	  for (int ib = 0; ib < 3; ib++) {
+	    double dab = (ia == ib);
+	    s[ia][ib] -= rtau*(s[ia][ib] - seq[ia][ib]);
+	    s[ia][ib] += dab*rdim*tr_s;
+	    s[ia][ib] += (2.0 - rtau)*(u[ia]*frc[ib] + frc[ia]*u[ib]);
+	  }
+	}
+	for (int ia = 0; ia < 3; ia++) mode[1+ia] += frc[ia];
+	m = 0;
+	for (int ia = 0; ia < 3; ia++) {
+	  for (int ib = ia; ib < 3; ib++) {
+	    mode[4 + m] = s[ia][ib];
+	    m++;
+	  }
+	}
+	for (m = NHYDRO; m < nvel; m++) {
+	  mode[m] = mode[m] - rtau_ghost[m]*(mode[m] - 0.0);
+	}
+	for (int q = 0; q < nvel; q++) {
+	  double sum = 0.0;
+	  for (m = 0; m < nvel; m++) sum += model.mi[q][m]*mode[m];
+	  f2[nsite*q + index] = sum;
+	}
+	if (u_out) {
+	  for (int ia = 0; ia < 3; ia++) u_out[nsite*ia + index] = u[ia];
+	}
+
+	/* order-parameter distribution (collision.c:955-1024) */
+	mu = a*ph + b*ph*ph*ph - kappa*delsq[index];
+	for (int q = 1; q < nvel; q++) {
+	  for (int ia = 0; ia < 3; ia++) {
+	    jphi[ia] += mphi.cv[q][ia]*g[nsite*q + index];
+	  }
+	}
+	for (int ia = 0; ia < 3; ia++) {
+	  for (int ib = 0; ib < 3; ib++) {
+	    sphi[ia][ib] = ph*u[ia]*u[ib] + mu*(ia == ib);
+	  }
+	  jphi[ia] = jphi[ia] - rtau2*(jphi[ia] - ph*u[ia]);
+	}
+	for (int q = 0; q < nvel; q++) {
+	  double jdotc = 0.0;
+	  double sphidotq = 0.0;
+	  for (int ia = 0; ia < 3; ia++) {
+	    jdotc += jphi[ia]*mphi.cv[q][ia];
+	    for (int ib = 0; ib < 3; ib++) {
+	      sphidotq += sphi[ia][ib]*(mphi.cv[q][ia]*mphi.cv[q][ib]
+					- cs2*(ia == ib));
+	    }
+	  }
+	  g[nsite*q + index] = mphi.wv[q]*(jdotc*3.0 + sphidotq*4.5)
+	    + ph*(q == 0);
+	}
+      }
+    }
+  }
+
+  return 0;
+}
+
+/*
  * lbo_halo
  *
  * Net effect on one rank with periodic boundaries of lb_halo() with the

@@ -53,6 +53,12 @@ int lbo_nsite(const lbo_param_t * p);
 
 int lbo_collide(const lbo_param_t * p, double * f, const double * force,
 		const char * status, double * rho, double * u);
+int lbo_phi_from_g(const lbo_param_t * p, const double * f2, double * phi);
+int lbo_collide_binary(const lbo_param_t * p, double * f2,
+		       const double * force, double a, double b, double kappa,
+		       double mobility, const double * phi,
+		       const double * grad, const double * delsq,
+		       double * u_out);
 int lbo_halo(const lbo_param_t * p, int nel, double * data);
 int lbo_halo_dirs(const lbo_param_t * p, int nel, double * data, int dirmask);
 int lbo_halo_width(const lbo_param_t * p, int nel, double * data, int dirmask,

@@ -70,6 +70,10 @@ def lib():
         _lib.lbo_propagate.argtypes = [pp, dp, dp]
         _lib.lbo_halo_width.argtypes = [pp, ctypes.c_int, dp, ctypes.c_int,
                                         ctypes.c_int]
+        _lib.lbo_phi_from_g.argtypes = [pp, dp, dp]
+        _lib.lbo_collide_binary.argtypes = [pp, dp, dp, ctypes.c_double,
+                                            ctypes.c_double, ctypes.c_double,
+                                            ctypes.c_double, dp, dp, dp, dp]
         _lib.lbo_grad_7pt.argtypes = [pp, dp, dp, dp]
         _lib.lbo_grad_27pt.argtypes = [pp, dp, dp, dp]
         _lib.lbo_cahn_hilliard.argtypes = [pp, ctypes.c_double, ctypes.c_double,
@@ -159,6 +163,38 @@ def field_halo(p, data, nswap):
     nel = 1 if data.ndim == 3 else data.shape[0]
     rc = lib().lbo_halo_width(ctypes.byref(p), nel, _ptr(data), 7, nswap)
     assert rc == 0
+
+
+def phi_from_g(p, f2):
+    """phi_lb_to_field: phi = sum_p g_p (f2: (2*nvel,) + nall)."""
+    phi = np.zeros(f2.shape[1:])
+    rc = lib().lbo_phi_from_g(ctypes.byref(p), _ptr(f2), _ptr(phi))
+    assert rc == 0
+    return phi
+
+
+def collide_binary(p, f2, force, a, b, kappa, mobility, phi, grad, delsq, u=None):
+    """lb_collision_binary: both distributions in place, u written."""
+    assert f2.shape[0] == 2 * p.nvel
+    rc = lib().lbo_collide_binary(ctypes.byref(p), _ptr(f2), _ptr(force), a, b,
+                                  kappa, mobility, _ptr(phi), _ptr(grad),
+                                  _ptr(delsq), _ptr(u))
+    assert rc == 0
+
+
+def step_binary(p, f2, fp2, a, b, kappa, mobility, force=None, u=None, npt=27):
+    """One symmetric_lb step (ludwig.c:558-578, 802-860): phi from g, halo,
+    gradients, binary collision, halo and propagation of both distributions.
+    Returns (f2, fp2) swapped, and phi, grad, delsq of this step."""
+    phi = phi_from_g(p, f2)
+    field_halo(p, phi, 1)
+    gr, d2 = grad(p, phi, npt)
+    collide_binary(p, f2, force, a, b, kappa, mobility, phi, gr, d2, u)
+    halo(p, f2)
+    nv = p.nvel
+    propagate(p, f2[:nv], fp2[:nv])
+    propagate(p, f2[nv:], fp2[nv:])
+    return fp2, f2, phi, gr, d2
 
 
 def grad_7pt(p, phi):

@@ -114,6 +114,38 @@ def run_fe_case(case, tmp):
             "phi_new": load("phi_new", ())}
 
 
+# name, nvel, (nx, ny, nz), a, b, kappa, mobility, eta, zeta, fbody_x, nsteps
+BINARY_CASES = [
+    ("bin_q19_a", 19, (6, 5, 4), -0.0625, 0.0625, 0.04, 0.15, 0.1, 0.1, 1e-5, 4),
+    ("bin_q19_b", 19, (5, 8, 7), -0.00625, 0.00625, 0.004, 3.75, 0.00625, 0.00625, 0.0, 4),
+    ("bin_q27_a", 27, (6, 5, 4), -0.0625, 0.0625, 0.04, 0.5, 0.1, 0.3, 0.0, 4),
+]
+
+
+def run_binary_case(case, tmp):
+    """The two-distribution (symmetric_lb) step: lb_collision_binary with
+    27-point gradients, lb_halo and lb_propagation of both distributions.
+    Arrays (2*nvel, nall) are n-major: [0:nvel] density, [nvel:] order
+    parameter."""
+    name, nvel, n, a, b, kappa, mob, eta, zeta, fx, nsteps = case
+    exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
+    prefix = os.path.join(tmp, name)
+    subprocess.run([exe, "binary", prefix, *map(str, n), repr(a), repr(b),
+                    repr(kappa), repr(mob), repr(eta), repr(zeta), repr(fx),
+                    str(nsteps)], check=True)
+    meta = json.load(open(prefix + ".json"))
+    meta["name"] = name
+    nall = tuple(meta["nall"])
+
+    def load(key, lead):
+        return np.fromfile("%s.%s.f64" % (prefix, key), dtype="<f8").reshape(lead + nall)
+
+    return {"meta": np.array(json.dumps(meta)), "f0": load("f0", (2 * nvel,)),
+            "phi": load("phi", ()), "grad": load("grad", (3,)),
+            "delsq": load("delsq", ()), "f_collide": load("f_collide", (2 * nvel,)),
+            "u": load("u", (3,)), "f_final": load("f_final", (2 * nvel,))}
+
+
 # name, nvel, (nx, ny, nz), timestep
 IO_CASES = [
     ("io_q19", 19, (6, 5, 4), 7),
@@ -150,6 +182,11 @@ def main():
             print("wrote", fn, os.path.getsize(fn))
         for case in FE_CASES:
             out = run_fe_case(case, tmp)
+            fn = os.path.join(GOLD, case[0] + ".npz")
+            np.savez_compressed(fn, **out)
+            print("wrote", fn, os.path.getsize(fn))
+        for case in BINARY_CASES:
+            out = run_binary_case(case, tmp)
             fn = os.path.join(GOLD, case[0] + ".npz")
             np.savez_compressed(fn, **out)
             print("wrote", fn, os.path.getsize(fn))

@@ -33,6 +33,8 @@
  *               pth_force_fluid_driver, then phi_cahn_hilliard with advection
  *               of order 1..4 in a prescribed velocity field; nhalo = 2)
  *
+ *    ref_driver binary <prefix> nx ny nz a b kappa mobility eta zeta fx nsteps
+ *               (two-distribution symmetric_lb step, collision.c:610-1027)
  *    ref_driver io <dir> nx ny nz timestep      (lb_io_write into <dir>)
  *    ref_driver ioread <dir> nx ny nz timestep  (lb_io_read from <dir>)
  *
@@ -71,6 +73,7 @@
 #include "phi_force_colloid.h"
 #include "phi_cahn_hilliard.h"
 #include "advection.h"
+#include "phi_lb_coupler.h"
 
 #define PI_ 3.14159265358979323846
 
@@ -341,6 +344,178 @@ static int run_fe(int argc, char ** argv) {
 
 /*****************************************************************************
  *
+ *  run_binary
+ *
+ *  "binary" mode: ref_driver binary <prefix> nx ny nz a b kappa mobility \
+ *                 eta zeta fx nsteps
+ *    The two-distribution step of free_energy symmetric_lb (ludwig.c:
+ *    558-578, 802-860): phi_lb_to_field, field_halo, field_grad_compute
+ *    (27-point), hydro_u_zero, lb_collide -> lb_collision_binary
+ *    (collision.c:610-1027), lb_halo, lb_propagation; nhalo = 1.
+ *    Dumps f0 (both distributions), and after the first collision phi,
+ *    grad, delsq, f_collide, u; f_final after nsteps.
+ *
+ *****************************************************************************/
+
+static int run_binary(int argc, char ** argv) {
+
+  const char * prefix = argv[2];
+  case_t c = {0};
+  fe_symm_param_t param = {0};
+  double mobility = atof(argv[9]);
+  double fzero[3] = {0.0, 0.0, 0.0};
+  int nsteps = atoi(argv[13]);
+
+  pe_t * pe = NULL;
+  cs_t * cs = NULL;
+  lees_edw_t * le = NULL;
+  physics_t * phys = NULL;
+  lb_t * lb = NULL;
+  field_t * phi = NULL;
+  field_grad_t * dphi = NULL;
+  fe_symm_t * fe = NULL;
+  hydro_t * hydro = NULL;
+  map_t * map = NULL;
+  noise_t * noise = NULL;
+  int nlocal[3];
+
+  c.ntotal[X] = atoi(argv[3]);
+  c.ntotal[Y] = atoi(argv[4]);
+  c.ntotal[Z] = atoi(argv[5]);
+  c.nhalo = 1;
+  param.a = atof(argv[6]);
+  param.b = atof(argv[7]);
+  param.kappa = atof(argv[8]);
+  c.eta = atof(argv[10]);
+  c.zeta = atof(argv[11]);
+  c.fbody[X] = atof(argv[12]);
+
+  MPI_Init(&argc, &argv);
+  pe_create(MPI_COMM_WORLD, PE_QUIET, &pe);
+  cs_create(pe, &cs);
+  cs_ntotal_set(cs, c.ntotal);
+  cs_nhalo_set(cs, c.nhalo);
+  cs_init(cs);
+  cs_nlocal(cs, nlocal);
+
+  physics_create(pe, &phys);
+  physics_rho0_set(phys, 1.0);
+  physics_eta_shear_set(phys, c.eta);
+  physics_eta_bulk_set(phys, c.zeta);
+  physics_fbody_set(phys, c.fbody);
+  physics_mobility_set(phys, mobility);
+
+  {
+    lees_edw_options_t opts = {0};
+    opts.nplanes = 0;
+    lees_edw_create(pe, cs, &opts, &le);
+  }
+  {
+    lb_data_options_t opts = lb_data_options_default();
+    opts.ndim = NDIM;
+    opts.nvel = NVEL;
+    opts.ndist = 2;
+    opts.nrelax = LB_RELAXATION_M10;
+    opts.halo = LB_HALO_TARGET;
+    lb_data_create(pe, cs, &opts, &lb);
+  }
+  {
+    field_options_t opts = field_options_ndata_nhalo(1, 1);
+    field_create(pe, cs, le, "phi", &opts, &phi);
+  }
+  field_grad_create(pe, phi, 2, &dphi);
+  field_grad_set(dphi, grad_3d_27pt_fluid_d2, NULL);
+  fe_symm_create(pe, cs, phi, dphi, &fe);
+  fe_symm_param_set(fe, param);
+  {
+    hydro_options_t hopts = hydro_options_nhalo(1);
+    hydro_create(pe, cs, le, &hopts, &hydro);
+  }
+  map_create(pe, cs, 0, &map);
+  noise_create(pe, cs, &noise);
+  noise_init(noise, 0);
+
+  init_f(cs, lb, &c);
+  init_map(cs, map, &c);
+  hydro_f_zero(hydro, fzero);
+
+  /* second distribution: g_p = w_p phi0 (1 + 1e-2 (r - 1/2)) */
+  for (int ic = 1; ic <= nlocal[X]; ic++) {
+    for (int jc = 1; jc <= nlocal[Y]; jc++) {
+      for (int kc = 1; kc <= nlocal[Z]; kc++) {
+	int index = cs_index(cs, ic, jc, kc);
+	double x = (ic - 1.0)/c.ntotal[X];
+	double y = (jc - 1.0)/c.ntotal[Y];
+	double z = (kc - 1.0)/c.ntotal[Z];
+	double phi0 = 0.4*sin(2.0*PI_*x)*cos(2.0*PI_*y) + 0.3*sin(2.0*PI_*z + 1.0);
+	for (int p = 0; p < lb->model.nvel; p++) {
+	  double r = lcg_uniform();
+	  lb_f_set(lb, index, p, LB_PHI,
+		   lb->model.wv[p]*phi0*(1.0 + 1.0e-2*(r - 0.5)));
+	}
+      }
+    }
+  }
+
+  {
+    size_t nf = (size_t) lb->nsite*lb->model.nvel*2;
+    size_t ns = (size_t) lb->nsite;
+    int nall[3];
+    char fn[1024];
+    FILE * fp = NULL;
+
+    dump(prefix, "f0", lb->f, nf);
+    for (int n = 0; n < nsteps; n++) {
+      phi_lb_to_field(phi, lb);
+      field_halo(phi);
+      field_grad_compute(dphi);
+      hydro_u_zero(hydro, fzero);
+      lb_collide(lb, hydro, map, noise, (fe_t *) fe, NULL);
+      if (n == 0) {
+	dump(prefix, "phi", phi->data, ns);
+	dump(prefix, "grad", dphi->grad, 3*ns);
+	dump(prefix, "delsq", dphi->delsq, ns);
+	dump(prefix, "f_collide", lb->f, nf);
+	dump(prefix, "u", hydro->u->data, 3*ns);
+      }
+      lb_halo(lb);
+      lb_propagation(lb);
+    }
+    dump(prefix, "f_final", lb->f, nf);
+
+    cs_nall(cs, nall);
+    snprintf(fn, sizeof(fn), "%s.json", prefix);
+    fp = fopen(fn, "w");
+    fprintf(fp, "{\"nvel\": %d, \"ndist\": 2, \"nlocal\": [%d, %d, %d],"
+	    " \"nhalo\": 1, \"nall\": [%d, %d, %d], \"nsite\": %d,"
+	    " \"a\": %.17g, \"b\": %.17g, \"kappa\": %.17g,"
+	    " \"mobility\": %.17g, \"eta\": %.17g, \"zeta\": %.17g,"
+	    " \"fbody\": [%.17g, 0.0, 0.0], \"nsteps\": %d,"
+	    " \"layout\": \"soa\"}\n",
+	    NVEL, c.ntotal[X], c.ntotal[Y], c.ntotal[Z],
+	    nall[X], nall[Y], nall[Z], lb->nsite, param.a, param.b,
+	    param.kappa, mobility, c.eta, c.zeta, c.fbody[X], nsteps);
+    fclose(fp);
+  }
+
+  noise_free(noise);
+  map_free(map);
+  hydro_free(hydro);
+  fe_symm_free(fe);
+  field_grad_free(dphi);
+  field_free(phi);
+  lb_free(lb);
+  lees_edw_free(le);
+  physics_free(phys);
+  cs_free(cs);
+  pe_free(pe);
+  MPI_Finalize();
+
+  return 0;
+}
+
+/*****************************************************************************
+ *
  *  run_io
  *
  *  "io" mode: ref_driver io <dir> nx ny nz timestep
@@ -424,6 +599,9 @@ int main(int argc, char ** argv) {
 
   if ((argc == 10 || argc == 12) && strcmp(argv[1], "fe") == 0) {
     return run_fe(argc, argv);
+  }
+  if (argc == 14 && strcmp(argv[1], "binary") == 0) {
+    return run_binary(argc, argv);
   }
   if (argc == 7 && (strcmp(argv[1], "io") == 0 ||
 		    strcmp(argv[1], "ioread") == 0)) {

@@ -27,6 +27,12 @@ def golden_fe_names():
                   for f in glob.glob(os.path.join(GOLDEN_DIR, "fe_*.npz")))
 
 
+def golden_binary_names():
+    """Fixtures of the two-distribution (symmetric_lb) step (bin_*)."""
+    return sorted(os.path.basename(f)[:-4]
+                  for f in glob.glob(os.path.join(GOLDEN_DIR, "bin_*.npz")))
+
+
 def load_io_golden(name):
     """Files written by the reference's lb_io_write (io_q19, io_q27): the
     metadata text, the data file name and bytes, and the f they hold."""
