@@ -222,6 +222,30 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro);  /* lb_collide */
 int lbmi_lb_halo(lbmi_t * lb);                                 /* lb_halo    */
 int lbmi_lb_propagation(lbmi_t * lb);                          /* lb_propagation */
 int lbmi_lb_flush(lbmi_t * lb);
+
+/* ndist = 2, free_energy symmetric_lb (LBMI_MODE_EAGER, one rank): the
+ * second distribution carries the order parameter. f holds both,
+ * f[(n*nvel + p)*nsite + index]; lbmi_lb_halo and lbmi_lb_propagation move
+ * both; lbmi_lb_moments looks at n = 0 (as stats_distribution.c does).
+ *   lbmi_lb_phi_to_field   phi_lb_to_field (phi_lb_coupler.c:39-112):
+ *                          phi = sum_p g_p at the interior sites.
+ *   lbmi_lb_collide_binary lb_collide -> lb_collision_binary
+ *                          (collision.c:143-163, 610-1027) without noise:
+ *                          reads hydro->force, writes hydro->u (not rho; no
+ *                          status test, as the reference); phi, grad, delsq =
+ *                          the field and its field_grad_compute arrays at
+ *                          the interior sites; mobility M gives the
+ *                          relaxation rate 2/(1 + 2M) of the phi flux. */
+typedef struct lbmi_fe_symm_s {
+  double a, b, kappa;        /* fe_symm_param_t, symmetric.h */
+  double mobility;           /* physics_mobility */
+  const double * phi;        /* device, nsite */
+  const double * grad;       /* device, 3*nsite */
+  const double * delsq;      /* device, nsite */
+} lbmi_fe_symm_t;
+int lbmi_lb_phi_to_field(lbmi_t * lb, double * phi);
+int lbmi_lb_collide_binary(lbmi_t * lb, const lbmi_hydro_t * hydro,
+			   const lbmi_fe_symm_t * fe);
 /* What lbmi_lb_flush would have to do right now: state[0] = a halo swap is
  * pending, state[1] = a propagation is pending (or, INPLACE, already applied
  * early), state[2] = the order of f: 0 the reference's SoA, 1 the internal

@@ -197,9 +197,13 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
     return lbmi_fail(LBMI_ERR_UNSUPPORTED, "nvel = %d: only d3q19 and d3q27",
 		     opts->nvel);
   }
-  if (opts->ndist != 1) {
-    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = %d: single-fluid only",
-		     opts->ndist);
+  if (opts->ndist != 1 && opts->ndist != 2) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = %d: 1 or 2", opts->ndist);
+  }
+  if (opts->ndist == 2 && (opts->mode != LBMI_MODE_EAGER || opts->cartsz != 1)) {
+    /* the two-distribution (symmetric_lb) step: three stages, one rank */
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = 2 needs LBMI_MODE_EAGER "
+		     "and cartsz = 1");
   }
   if (opts->nhalo < 1) return lbmi_fail(LBMI_ERR_ARGUMENT, "nhalo < 1");
   for (int d = 0; d < 3; d++) {
@@ -822,7 +826,8 @@ int lbmi_lb_bind(lbmi_t * lb, double * f, double * fprime) {
   lb->blocked = 0;
 
   if (f == NULL) {
-    size_t sz = sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel;
+    size_t sz = sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel
+    *(size_t) lb->opts.ndist;
     HIPCHECK(hipMalloc((void **) &lb->f, sz));
     HIPCHECK(hipMalloc((void **) &lb->fprime, sz));
     HIPCHECK(hipMemsetAsync(lb->f, 0, sz, lb->stream));
@@ -955,6 +960,9 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
 
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+  if (lb->opts.ndist != 1) {
+    return lbmi_fail(LBMI_ERR_STATE, "ndist = 2: lbmi_lb_collide_binary");
+  }
   HIPCHECK(hipSetDevice(lb->device));
 
   if (lbmi_inplace(lb)) {
@@ -1026,6 +1034,46 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
 
 /*****************************************************************************
  *
+ *  The two-distribution step of free_energy symmetric_lb:
+ *  phi_lb_to_field (phi_lb_coupler.c:39-112) and lb_collision_binary
+ *  (collision.c:610-1027)
+ *
+ *****************************************************************************/
+
+int lbmi_lb_phi_to_field(lbmi_t * lb, double * phi) {
+  if (lb == NULL || phi == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+  if (lb->opts.ndist != 2) return lbmi_fail(LBMI_ERR_STATE, "needs ndist = 2");
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_phi_from_g(&lb->kp, lb->f, phi, lb->stream));
+  return 0;
+}
+
+int lbmi_lb_collide_binary(lbmi_t * lb, const lbmi_hydro_t * hydro,
+			   const lbmi_fe_symm_t * fe) {
+  lbmi_hydro_dev_t h = lbmi_hydro_dev(hydro);
+  if (lb == NULL || fe == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+  if (lb->opts.ndist != 2) return lbmi_fail(LBMI_ERR_STATE, "needs ndist = 2");
+  if (!fe->phi || !fe->grad || !fe->delsq) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_lb_collide_binary: phi, grad "
+		     "and delsq are required");
+  }
+  /* lb_collide returns at once without a hydro object (collision.c:149);
+   * the binary collision has no use for rho and status */
+  if (hydro == NULL) return 0;
+  h.rho = NULL;
+  h.status = NULL;
+  HIPCHECK(hipSetDevice(lb->device));
+  /* (1/tau_2) = 2/(2M + 1), collision.c:1965-1968 */
+  KCHECK(lbmi_k_collide_binary(&lb->kp, lb->f, &h, fe->a, fe->b, fe->kappa,
+			       2.0/(1.0 + 2.0*fe->mobility), fe->phi,
+			       fe->grad, fe->delsq, lb->stream));
+  return 0;
+}
+
+/*****************************************************************************
+ *
  *  lbmi_lb_halo  (lb_halo, model.c:553-563)
  *
  *****************************************************************************/
@@ -1047,7 +1095,13 @@ int lbmi_lb_halo(lbmi_t * lb) {
     return 0;
   }
 
-  return lbmi_halo(lb, lb->f, lb->opts.halo_scheme);
+  /* every distribution (halo_swap_packed moves ndist*nvel values per site) */
+  for (int n = 0; n < lb->opts.ndist; n++) {
+    size_t off = (size_t) n*(size_t) lb->kp.nvel*(size_t) lb->kp.nsite;
+    int ifail = lbmi_halo(lb, lb->f + off, lb->opts.halo_scheme);
+    if (ifail) return ifail;
+  }
+  return 0;
 }
 
 /*****************************************************************************
@@ -1092,7 +1146,10 @@ int lbmi_lb_propagation(lbmi_t * lb) {
   }
 
   HIPCHECK(hipSetDevice(lb->device));
-  KCHECK(lbmi_k_propagate(&lb->kp, lb->f, lb->fprime, lb->stream));
+  for (int n = 0; n < lb->opts.ndist; n++) {
+    size_t off = (size_t) n*(size_t) lb->kp.nvel*(size_t) lb->kp.nsite;
+    KCHECK(lbmi_k_propagate(&lb->kp, lb->f + off, lb->fprime + off, lb->stream));
+  }
   lbmi_swapf(lb);
 
   return 0;
@@ -1169,7 +1226,8 @@ int lbmi_lb_memcpy_h2d(lbmi_t * lb, const double * f_host) {
   if (lb == NULL || f_host == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   HIPCHECK(hipSetDevice(lb->device));
-  sz = sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel;
+  sz = sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel
+    *(size_t) lb->opts.ndist;
   lb->pending_halo = 0;
   lb->pending_prop = 0;
   lb->layout_swapped = 0;
@@ -1187,7 +1245,8 @@ int lbmi_lb_memcpy_d2h(lbmi_t * lb, double * f_host) {
   if (lb == NULL || f_host == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   ifail = lbmi_lb_flush(lb);
   if (ifail) return ifail;
-  sz = sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel;
+  sz = sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel
+    *(size_t) lb->opts.ndist;
   HIPCHECK(hipMemcpyAsync(f_host, lb->f, sz, hipMemcpyDeviceToHost, lb->stream));
   HIPCHECK(hipStreamSynchronize(lb->stream));
   return 0;
@@ -1379,6 +1438,7 @@ int lbmi_symmetric_step_grad(lbmi_t * lb, double a, double b, double kappa,
 int lbmi_lb_records_pack(lbmi_t * lb, double * records) {
   int ifail;
   if (lb == NULL || records == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->opts.ndist != 1) return lbmi_fail(LBMI_ERR_UNSUPPORTED, "records: ndist = 1 only");
   ifail = lbmi_lb_flush(lb);
   if (ifail) return ifail;
   KCHECK(lbmi_k_records(&lb->kp, lb->f, records, 1, lb->stream));
@@ -1387,6 +1447,7 @@ int lbmi_lb_records_pack(lbmi_t * lb, double * records) {
 
 int lbmi_lb_records_unpack(lbmi_t * lb, const double * records) {
   if (lb == NULL || records == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->opts.ndist != 1) return lbmi_fail(LBMI_ERR_UNSUPPORTED, "records: ndist = 1 only");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   HIPCHECK(hipSetDevice(lb->device));
   /* reading a checkpoint replaces the state: nothing stays pending */
@@ -1535,6 +1596,7 @@ static int lbmi_io_transfer(lbmi_t * lb, const char * fn, int writing,
 static int lbmi_io_args(lbmi_t * lb, const char * dir, int ntotal_x,
 			int offset_x) {
   if (lb == NULL || dir == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->opts.ndist != 1) return lbmi_fail(LBMI_ERR_UNSUPPORTED, "i/o: ndist = 1 only");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   if (offset_x < 0 || offset_x + lb->kp.nlocal[X] > ntotal_x) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "planes %d..%d outside 0..%d", offset_x,

@@ -137,6 +137,15 @@ int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, int npt, int order,
 			const double * delsq, const double * u, double * force,
 			double * phi_out, int accumulate, void * stream);
 
+/* Two distributions (symmetric_lb): f2[(n*nvel + p)*nsite + i] */
+int lbmi_k_phi_from_g(const lbmi_kparam_t * kp, const double * f2,
+		      double * phi, void * stream);
+int lbmi_k_collide_binary(const lbmi_kparam_t * kp, double * f2,
+			  const lbmi_hydro_dev_t * h, double a, double b,
+			  double kappa, double rtau2, const double * phi,
+			  const double * grad, const double * delsq,
+			  void * stream);
+
 /* Moments: partial (nblk x 12 doubles workspace) then final (out_dev[9]) */
 int lbmi_k_moments_nblk(void);
 int lbmi_k_moments(const lbmi_kparam_t * kp, const double * f,

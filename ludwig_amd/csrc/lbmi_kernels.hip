@@ -236,10 +236,15 @@ struct Relax {
   double rtau_s, rtau_b, rtau_e, rtau_o;
 };
 
-template <int NVEL, int SCHEME>
+/* STH: add the thermodynamic stress sth (xx xy xz yy yz zz) to the
+ * equilibrium stress, as the two-distribution collision does
+ * (collision.c:838-850) */
+
+template <int NVEL, int SCHEME, bool STH>
 __device__ __forceinline__
-void collide_site(double (&f)[NVEL], const double (&frc)[3], const Relax & rx,
-		  double & rho, double (&u)[3]) {
+void collide_site_impl(double (&f)[NVEL], const double (&frc)[3],
+		       const Relax & rx, const double (&sth)[6],
+		       double & rho, double (&u)[3]) {
 
   using M = Model<NVEL>;
   constexpr bool keepf  = (SCHEME != LBMI_M10);
@@ -289,8 +294,11 @@ void collide_site(double (&f)[NVEL], const double (&frc)[3], const Relax & rx,
   double ds[6];
   {
     const double keep = keepf ? (1.0 - rx.rtau_e) : 0.0;
-    const double seq[6] = {rho*u[0]*u[0], rho*u[0]*u[1], rho*u[0]*u[2],
-			   rho*u[1]*u[1], rho*u[1]*u[2], rho*u[2]*u[2]};
+    double seq[6] = {rho*u[0]*u[0], rho*u[0]*u[1], rho*u[0]*u[2],
+		     rho*u[1]*u[1], rho*u[1]*u[2], rho*u[2]*u[2]};
+    if constexpr (STH) {
+      static_for<0, 6>([&](auto K) { seq[K] += sth[K]; });
+    }
     const double fc = 2.0 - rx.rtau_s;
     const double uf[6] = {2.0*u[0]*frc[0], u[0]*frc[1] + frc[0]*u[1],
 			  u[0]*frc[2] + frc[0]*u[2], 2.0*u[1]*frc[1],
@@ -387,6 +395,14 @@ void collide_site(double (&f)[NVEL], const double (&frc)[3], const Relax & rx,
     }
     f[p] = fn;
   });
+}
+
+template <int NVEL, int SCHEME>
+__device__ __forceinline__
+void collide_site(double (&f)[NVEL], const double (&frc)[3], const Relax & rx,
+		  double & rho, double (&u)[3]) {
+  const double none[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  collide_site_impl<NVEL, SCHEME, false>(f, frc, rx, none, rho, u);
 }
 
 /* ---- helpers -------------------------------------------------------------- */
@@ -1468,6 +1484,131 @@ void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility, int order,
 		       + wz*fhi[2] - wz*flo[2]);
 }
 
+/* ---- two distributions: the symmetric_lb step (row f4) ------------------------
+ *
+ * k_phi_from_g: phi_lb_to_field (phi_lb_coupler.c:39-112), phi = sum_p g_p.
+ * k_collide_binary: lb_collision_mrt2_site (collision.c:720-1027) without
+ * noise: the density distribution (n = 0) relaxes as in k_collide with the
+ * thermodynamic stress of the symmetric free energy in the equilibrium
+ * stress, at every interior site; the order-parameter distribution (n = 1)
+ * is re-projected from phi, jphi (relaxed towards phi u at rtau2) and
+ * sphi = phi u u + mu delta. f2[(n*NVEL + p)*nsite + i]. */
+
+template <int NVEL>
+__global__ __launch_bounds__(BLOCK)
+void k_phi_from_g(lbmi_kparam_t kp, const double * __restrict__ f2,
+		  double * __restrict__ phi, int i0, int i1, unsigned nblk) {
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+  Site s = decode(kp, i);
+  if (!s.interior) return;
+  const size_t ns = (size_t) kp.nsite;
+  const double * __restrict__ g = f2 + ns*NVEL;
+  double sum = 0.0;
+  static_for<0, NVEL>([&](auto P) { sum += g[ns*P + i]; });
+  phi[i] = sum;
+}
+
+template <int NVEL, int SCHEME>
+__global__ __launch_bounds__(BLOCK)
+void k_collide_binary(lbmi_kparam_t kp, double * __restrict__ f2,
+		      lbmi_hydro_dev_t h, Symm q, double rtau2,
+		      const double * __restrict__ phi,
+		      const double * __restrict__ grad,
+		      const double * __restrict__ delsq,
+		      int i0, int i1, unsigned nblk) {
+
+  using M = Model<NVEL>;
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+  Site s = decode(kp, i);
+  if (!s.interior) return;
+
+  const size_t ns = (size_t) kp.nsite;
+  double * __restrict__ g = f2 + ns*NVEL;
+
+  double fl[NVEL];
+  static_for<0, NVEL>([&](auto P) { fl[P] = f2[ns*P + i]; });
+  double gl[NVEL];
+  static_for<1, NVEL>([&](auto P) { gl[P] = g[ns*P + i]; });
+
+  double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
+  if (h.force) {
+    frc[0] += h.force[i];
+    frc[1] += h.force[ns + i];
+    frc[2] += h.force[2*ns + i];
+  }
+
+  const double ph = phi[i];
+  const double d2 = delsq[i];
+  const double gr[3] = {grad[i], grad[ns + i], grad[2*ns + i]};
+  double pth[3][3];
+  symm_stress(q, ph, gr, d2, pth);
+  const double sth[6] = {pth[0][0], pth[0][1], pth[0][2],
+			 pth[1][1], pth[1][2], pth[2][2]};
+
+  Relax rx = {kp.rtau_shear, kp.rtau_bulk, kp.rtau_even, kp.rtau_odd};
+  double rho, u[3];
+  collide_site_impl<NVEL, SCHEME, true>(fl, frc, rx, sth, rho, u);
+
+  static_for<0, NVEL>([&](auto P) { f2[ns*P + i] = fl[P]; });
+  if (h.u) {
+    h.u[i] = u[0];
+    h.u[ns + i] = u[1];
+    h.u[2*ns + i] = u[2];
+  }
+
+  /* order-parameter distribution, collision.c:955-1024 */
+  const double mu = q.a*ph + q.b*ph*ph*ph - q.kappa*d2;
+  double jphi[3] = {0.0, 0.0, 0.0};
+  static_for<1, NVEL>([&](auto P) {
+    constexpr int p = P;
+    static_for<0, 3>([&](auto A) {
+      constexpr int a = A;
+      if constexpr (M::c(p,a) ==  1) jphi[a] += gl[p];
+      if constexpr (M::c(p,a) == -1) jphi[a] -= gl[p];
+    });
+  });
+  for (int ia = 0; ia < 3; ia++) {
+    jphi[ia] = jphi[ia] - rtau2*(jphi[ia] - ph*u[ia]);
+  }
+  /* sphi_ab = phi u_a u_b + mu delta_ab */
+  const double sp[6] = {ph*u[0]*u[0] + mu, ph*u[0]*u[1], ph*u[0]*u[2],
+			ph*u[1]*u[1] + mu, ph*u[1]*u[2], ph*u[2]*u[2] + mu};
+  const double r3 = 1.0/3.0;
+  const double trsp = r3*(sp[0] + sp[3] + sp[5]);
+
+  static_for<0, NVEL>([&](auto P) {
+    constexpr int p = P;
+    constexpr int cx = M::c(p,0), cy = M::c(p,1), cz = M::c(p,2);
+    double jdotc = 0.0;
+    if constexpr (cx ==  1) jdotc += jphi[0];
+    if constexpr (cx == -1) jdotc -= jphi[0];
+    if constexpr (cy ==  1) jdotc += jphi[1];
+    if constexpr (cy == -1) jdotc -= jphi[1];
+    if constexpr (cz ==  1) jdotc += jphi[2];
+    if constexpr (cz == -1) jdotc -= jphi[2];
+    /* sphi : (c c - delta/3) */
+    double sq = -trsp;
+    if constexpr (cx != 0) sq += sp[0];
+    if constexpr (cy != 0) sq += sp[3];
+    if constexpr (cz != 0) sq += sp[5];
+    if constexpr (cx*cy ==  1) sq += 2.0*sp[1];
+    if constexpr (cx*cy == -1) sq -= 2.0*sp[1];
+    if constexpr (cx*cz ==  1) sq += 2.0*sp[2];
+    if constexpr (cx*cz == -1) sq -= 2.0*sp[2];
+    if constexpr (cy*cz ==  1) sq += 2.0*sp[4];
+    if constexpr (cy*cz == -1) sq -= 2.0*sp[4];
+    double gn = M::w(p)*(jdotc*3.0 + sq*4.5);
+    if constexpr (p == 0) gn += ph;
+    g[ns*p + i] = gn;
+  });
+}
+
 /* ---- moments ----------------------------------------------------------------
  *
  * Per interior fluid site: rho = sum_p f_p in p order (lb_0th_moment,
@@ -2161,6 +2302,68 @@ extern "C" int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, int npt,
 			  force, phi_out, st);
   }
   return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_phi_from_g(const lbmi_kparam_t * kp, const double * f2,
+				 double * phi, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  Range1D r = interior_range(*kp);
+  dim3 grid(r.grid), block(BLOCK);
+  if (kp->nvel == 19) {
+    hipLaunchKernelGGL((k_phi_from_g<19>), grid, block, 0, st, *kp, f2, phi,
+		       r.i0, r.i1, r.nblk);
+  }
+  else if (kp->nvel == 27) {
+    hipLaunchKernelGGL((k_phi_from_g<27>), grid, block, 0, st, *kp, f2, phi,
+		       r.i0, r.i1, r.nblk);
+  }
+  else {
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
+template <int NVEL>
+static int launch_collide_binary(const lbmi_kparam_t & kp, double * f2,
+				 const lbmi_hydro_dev_t & h, Symm q,
+				 double rtau2, const double * phi,
+				 const double * grad, const double * delsq,
+				 hipStream_t st) {
+  Range1D r = interior_range(kp);
+  dim3 grid(r.grid), block(BLOCK);
+  switch (kp.scheme) {
+  case LBMI_M10:
+    hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_M10>), grid, block, 0, st,
+		       kp, f2, h, q, rtau2, phi, grad, delsq, r.i0, r.i1, r.nblk);
+    break;
+  case LBMI_BGK:
+    hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_BGK>), grid, block, 0, st,
+		       kp, f2, h, q, rtau2, phi, grad, delsq, r.i0, r.i1, r.nblk);
+    break;
+  case LBMI_TRT:
+    if constexpr (NVEL == 19) {
+      hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_TRT>), grid, block, 0,
+			 st, kp, f2, h, q, rtau2, phi, grad, delsq, r.i0, r.i1,
+			 r.nblk);
+      break;
+    }
+    return (int) hipErrorInvalidValue;
+  default:
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_collide_binary(const lbmi_kparam_t * kp, double * f2,
+				     const lbmi_hydro_dev_t * h, double a,
+				     double b, double kappa, double rtau2,
+				     const double * phi, const double * grad,
+				     const double * delsq, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  Symm q = {a, b, kappa};
+  if (kp->nvel == 19) return launch_collide_binary<19>(*kp, f2, *h, q, rtau2, phi, grad, delsq, st);
+  if (kp->nvel == 27) return launch_collide_binary<27>(*kp, f2, *h, q, rtau2, phi, grad, delsq, st);
+  return (int) hipErrorInvalidValue;
 }
 
 extern "C" int lbmi_k_moments_nblk(void) { return MOM_NBLK; }

@@ -80,7 +80,7 @@ class LB:
 
     def __init__(self, nvel=19, nlocal=(64, 64, 64), nhalo=1, mode=EAGER,
                  halo_scheme=HALO_FULL, device=0, cartsz=1, cartrank=0,
-                 own_stream=False):
+                 own_stream=False, ndist=1):
         """own_stream=False (default): the library works on torch's current
         stream of `device`, so its kernels are ordered with torch operations
         on the same tensors. own_stream=True keeps the handle's private
@@ -93,7 +93,7 @@ class LB:
         opts = _l.Options()
         _l.check(self._lib.lbmi_options_default(ctypes.byref(opts)))
         opts.nvel = nvel
-        opts.ndist = 1
+        opts.ndist = ndist
         opts.nlocal[:] = list(nlocal)
         opts.nhalo = nhalo
         opts.device = device
@@ -103,6 +103,7 @@ class LB:
         opts.cartrank = cartrank
         _l.check(self._lib.lbmi_create(ctypes.byref(opts), ctypes.byref(self._h)))
         self.nvel = nvel
+        self.ndist = ndist
         self.nlocal = tuple(nlocal)
         self.nhalo = nhalo
         self.mode = mode
@@ -110,7 +111,7 @@ class LB:
         self.nsite = self.nall[0] * self.nall[1] * self.nall[2]
         self.device = torch.device("cuda", device)
         # lb_data_create zero-initialises f and fprime (model.c:106-147)
-        self._a = torch.zeros((nvel,) + self.nall, dtype=torch.float64,
+        self._a = torch.zeros((ndist * nvel,) + self.nall, dtype=torch.float64,
                               device=self.device)
         self._b = torch.zeros_like(self._a)
         torch.cuda.synchronize(self.device)
@@ -166,12 +167,12 @@ class LB:
 
     def lb_memcpy_h2d(self, f_host):
         f_host = np.ascontiguousarray(f_host, dtype=np.float64)
-        assert f_host.shape == (self.nvel,) + self.nall
+        assert f_host.shape == (self.ndist * self.nvel,) + self.nall
         _l.check(self._lib.lbmi_lb_memcpy_h2d(
             self._h, f_host.ctypes.data_as(ctypes.c_void_p)))
 
     def lb_memcpy_d2h(self):
-        out = np.empty((self.nvel,) + self.nall, dtype=np.float64)
+        out = np.empty((self.ndist * self.nvel,) + self.nall, dtype=np.float64)
         _l.check(self._lib.lbmi_lb_memcpy_d2h(
             self._h, out.ctypes.data_as(ctypes.c_void_p)))
         return out
@@ -338,6 +339,23 @@ class LB:
 
     def synchronize(self):
         _l.check(self._lib.lbmi_synchronize(self._h))
+
+    def phi_to_field(self, phi):
+        """phi_lb_to_field (ndist = 2): phi = sum_p g_p."""
+        _l.check(self._lib.lbmi_lb_phi_to_field(self._h, _ptr(phi)))
+
+    def lb_collide_binary(self, hydro, a, b, kappa, mobility, phi, grad, delsq):
+        """lb_collide with ndist = 2 (lb_collision_binary)."""
+        fe = _l.FeSymm()
+        fe.a, fe.b, fe.kappa, fe.mobility = a, b, kappa, mobility
+        fe.phi, fe.grad, fe.delsq = _ptr(phi), _ptr(grad), _ptr(delsq)
+        if hydro is None:
+            _l.check(self._lib.lbmi_lb_collide_binary(self._h, None,
+                                                      ctypes.byref(fe)))
+        else:
+            h = hydro.ptrs()
+            _l.check(self._lib.lbmi_lb_collide_binary(self._h, ctypes.byref(h),
+                                                      ctypes.byref(fe)))
 
     def lb_io_write(self, directory, timestep, ntotal_x=None, offset_x=0):
         """lb_io_write (model.c:1568): dist-metadata.001-001 and

@@ -38,6 +38,19 @@ class HydroPtrs(ctypes.Structure):
     ]
 
 
+class FeSymm(ctypes.Structure):
+    """lbmi_fe_symm_t"""
+    _fields_ = [
+        ("a", ctypes.c_double),
+        ("b", ctypes.c_double),
+        ("kappa", ctypes.c_double),
+        ("mobility", ctypes.c_double),
+        ("phi", ctypes.c_void_p),
+        ("grad", ctypes.c_void_p),
+        ("delsq", ctypes.c_void_p),
+    ]
+
+
 # Every symbol declared in include/lbmi.h: (name, restype, argtypes)
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -72,6 +85,9 @@ SYMBOLS = [
     ("lbmi_lb_propagation", _i, [_vp]),
     ("lbmi_lb_flush", _i, [_vp]),
     ("lbmi_lb_state", _i, [_vp, ctypes.POINTER(_i)]),
+    ("lbmi_lb_phi_to_field", _i, [_vp, _vp]),
+    ("lbmi_lb_collide_binary", _i, [_vp, ctypes.POINTER(HydroPtrs),
+                                    ctypes.POINTER(FeSymm)]),
     ("lbmi_lb_memcpy_h2d", _i, [_vp, _vp]),
     ("lbmi_lb_memcpy_d2h", _i, [_vp, _vp]),
     ("lbmi_lb_moments", _i, [_vp, _vp, _pd]),

@@ -1,0 +1,154 @@
+"""Row f4 on the device: the two-distribution (symmetric_lb) step --
+phi_lb_to_field, lb_collision_binary, lb_halo and lb_propagation of both
+distributions -- through the C-ABI against the compiled-reference fixtures
+and the oracle. Needs an MI355X."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lb_oracle as lbo                                    # noqa: E402
+from tests.common import golden_binary_names, interior, load_golden, relmax  # noqa: E402
+
+
+def _lb(meta, scheme="m10"):
+    import ludwig_amd
+    lb = ludwig_amd.LB(meta["nvel"], tuple(meta["nlocal"]), 1, ndist=2)
+    lb.relaxation_set(scheme, meta["eta"], meta["zeta"])
+    lb.body_force_set(meta["fbody"])
+    return lb
+
+
+def _dev(lb, a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(lb.device)
+
+
+def _host(lb, t):
+    lb.synchronize()
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", golden_binary_names())
+def test_phi_to_field_exact(name):
+    import torch
+    g = load_golden(name)
+    lb = _lb(g["meta"])
+    lb.lb_memcpy_h2d(g["f0"])
+    phi = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    lb.phi_to_field(phi)
+    assert np.array_equal(interior(_host(lb, phi), 1), interior(g["phi"], 1))
+    lb.free()
+
+
+@pytest.mark.parametrize("name", golden_binary_names())
+def test_binary_collision_vs_reference(name):
+    import ludwig_amd
+    g = load_golden(name)
+    meta = g["meta"]
+    lb = _lb(meta)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device)
+    lb.lb_memcpy_h2d(g["f0"])
+    lb.lb_collide_binary(hy, meta["a"], meta["b"], meta["kappa"], meta["mobility"],
+                         _dev(lb, g["phi"]), _dev(lb, g["grad"]), _dev(lb, g["delsq"]))
+    f = lb.lb_memcpy_d2h()
+    nv = meta["nvel"]
+    assert relmax(interior(f[:nv], 1), interior(g["f_collide"][:nv], 1)) < 1e-12
+    assert relmax(interior(f[nv:], 1), interior(g["f_collide"][nv:], 1)) < 1e-12
+    assert relmax(interior(_host(lb, hy.u), 1), interior(g["u"], 1)) < 1e-12
+    lb.free()
+
+
+@pytest.mark.parametrize("name", golden_binary_names())
+def test_binary_steps_vs_reference(name):
+    """Whole steps as ludwig.c runs them with free_energy symmetric_lb."""
+    import ludwig_amd
+    import torch
+    g = load_golden(name)
+    meta = g["meta"]
+    lb = _lb(meta)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device)
+    lb.fe_scheme_set(27, 1)
+    phi = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    grad = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+    delsq = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    lb.lb_memcpy_h2d(g["f0"])
+    for _ in range(meta["nsteps"]):
+        lb.phi_to_field(phi)
+        lb.field_halo_n(phi, 1)
+        lb.field_grad(phi, grad, delsq)
+        lb.hydro_field_set(hy.u, (0, 0, 0))
+        lb.lb_collide_binary(hy, meta["a"], meta["b"], meta["kappa"],
+                             meta["mobility"], phi, grad, delsq)
+        lb.lb_halo()
+        lb.lb_propagation()
+    f = lb.lb_memcpy_d2h()
+    assert relmax(interior(f, 1), interior(g["f_final"], 1)) < 1e-12
+    # moments look at the density distribution
+    mo = lb.moments()
+    nv = meta["nvel"]
+    assert abs(mo[1] - interior(g["f_final"][:nv], 1).sum()) < 1e-10
+    lb.free()
+
+
+@pytest.mark.parametrize("nvel,scheme", [(19, "bgk"), (19, "trt"), (27, "bgk")])
+def test_binary_seeded_vs_oracle(nvel, scheme):
+    """Larger box, other relaxation schemes, a force field: oracle parity."""
+    import ludwig_amd
+    import torch
+    nlocal = (20, 12, 16)
+    a, b, kappa, mob = -0.00625, 0.00625, 0.004, 1.25
+    p = lbo.make_param(nvel, nlocal, 1, scheme, 0.1, 0.2, 1.0, (1e-6, 0, 0))
+    rng = np.random.default_rng(21)
+    f2 = np.zeros((2 * nvel,) + lbo.nall(p))
+    f2[:nvel] = lbo.init_synthetic(p)
+    w = lbo.model(nvel)["wv"]
+    ph0 = 0.3 * rng.standard_normal(nlocal)
+    for q in range(nvel):
+        interior(f2[nvel + q], 1)[...] = w[q] * ph0 * (1 + 0.01 * rng.standard_normal(nlocal))
+    force = 1e-6 * rng.standard_normal((3,) + lbo.nall(p))
+    f0 = f2.copy()
+    fp2 = np.zeros_like(f2)
+    u = np.zeros((3,) + lbo.nall(p))
+    for _ in range(3):
+        f2, fp2, _, _, _ = lbo.step_binary(p, f2, fp2, a, b, kappa, mob, force, u)
+
+    lb = ludwig_amd.LB(nvel, nlocal, 1, ndist=2)
+    lb.relaxation_set(scheme, 0.1, 0.2)
+    lb.body_force_set((1e-6, 0, 0))
+    lb.fe_scheme_set(27, 1)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, force=force)
+    phi = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    grad = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+    delsq = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    lb.lb_memcpy_h2d(f0)
+    for _ in range(3):
+        lb.phi_to_field(phi)
+        lb.field_halo_n(phi, 1)
+        lb.field_grad(phi, grad, delsq)
+        lb.lb_collide_binary(hy, a, b, kappa, mob, phi, grad, delsq)
+        lb.lb_halo()
+        lb.lb_propagation()
+    assert relmax(interior(lb.lb_memcpy_d2h(), 1), interior(f2, 1)) < 1e-12
+    assert relmax(interior(_host(lb, hy.u), 1), interior(u, 1)) < 1e-12
+    lb.free()
+
+
+def test_binary_rejections():
+    import ludwig_amd
+    with pytest.raises(ludwig_amd.LbmiError):
+        ludwig_amd.LB(19, (4, 4, 4), 1, ndist=2, mode=ludwig_amd.FUSED)
+    with pytest.raises(ludwig_amd.LbmiError):
+        ludwig_amd.LB(19, (4, 4, 4), 1, ndist=3)
+    lb = ludwig_amd.LB(19, (4, 4, 4), 1, ndist=2)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device)
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.lb_collide(hy)                      # the single-fluid entry point
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.lb_io_aggr_pack()
+    lb.free()
+    lb = ludwig_amd.LB(19, (4, 4, 4), 1)
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.phi_to_field(hy.rho)                # needs ndist = 2
+    lb.free()
