@@ -71,8 +71,13 @@ def test_create_argument_errors(lib):
     assert lib.lbmi_create(ctypes.byref(o), ctypes.byref(h)) == -2
     assert b"d3q19" in lib.lbmi_last_error()
     lib.lbmi_options_default(ctypes.byref(o))
-    o.ndist = 2
+    o.ndist = 3
     assert lib.lbmi_create(ctypes.byref(o), ctypes.byref(h)) == -2
+    lib.lbmi_options_default(ctypes.byref(o))
+    o.ndist = 2                      # two distributions: EAGER, one rank only
+    o.mode = 1
+    assert lib.lbmi_create(ctypes.byref(o), ctypes.byref(h)) == -2
+    assert b"EAGER" in lib.lbmi_last_error()
     lib.lbmi_options_default(ctypes.byref(o))
     o.cartrank = 3
     assert lib.lbmi_create(ctypes.byref(o), ctypes.byref(h)) == -1
