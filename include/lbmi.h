@@ -58,9 +58,9 @@ typedef struct lbmi_s lbmi_t;           /* opaque handle ~ lb_t + halo_swap_t */
 typedef enum lbmi_error_e {
   LBMI_SUCCESS         =  0,
   LBMI_ERR_ARGUMENT    = -1,            /* bad argument (assert() upstream) */
-  LBMI_ERR_UNSUPPORTED = -2,            /* e.g. d3q27 + TRT, ndist = 2      */
+  LBMI_ERR_UNSUPPORTED = -2,            /* e.g. d3q27 + TRT, ndist = 3      */
   LBMI_ERR_NODEVICE    = -3,            /* no HIP device / wrong arch       */
-  LBMI_ERR_HIP         = -4,            /* a HIP runtime call failed        */
+  LBMI_ERR_HIP         = -4,            /* a HIP call or an allocation failed */
   LBMI_ERR_RCCL        = -5,            /* an RCCL call failed              */
   LBMI_ERR_STATE       = -6             /* call out of order                */
 } lbmi_error_t;
@@ -236,6 +236,46 @@ int lbmi_lb_flush(lbmi_t * lb);
  *                          the field and its field_grad_compute arrays at
  *                          the interior sites; mobility M gives the
  *                          relaxation rate 2/(1 + 2M) of the phi flux. */
+/* Flat walls and solid sites with bounce-back on links (wall.c), EAGER mode.
+ * The step with walls is lb_collide, lb_halo, wall_bbl, lb_propagation
+ * (ludwig.c:802-860): "no halo updates between bounce back and propagation".
+ *   lbmi_wall_map        wall_init_map (wall.c:1219-1268): MAP_BOUNDARY (1)
+ *                        into the DEVICE map `status` (nsite chars) at every
+ *                        site, halo included, whose coordinate in a wall
+ *                        direction is 0 or nlocal+1. One rank.
+ *   lbmi_wall_links_build  wall_init_boundaries + wall_init_uw (wall.c:
+ *                        381-470, 864-890): a link for every interior
+ *                        MAP_FLUID site i and p >= 1 with i + c_p
+ *                        MAP_BOUNDARY, in the reference's order; with walls
+ *                        in exactly one direction the links carry the
+ *                        top/bottom wall velocity. Built on the host from a
+ *                        copy of the map (initialisation only).
+ *   lbmi_wall_links      copy the links out (host arrays of nlink ints, any
+ *                        may be NULL): fluid site, solid site, p, velocity id.
+ *   lbmi_wall_velocity_set  wall_param_t ubot / utop.
+ *   lbmi_wall_bbl        wall_bbl (wall.c:960-1107): f[j, nvel-p] =
+ *                        f[i, p] - 2 rcs2 w_p rho0 c_p.u_w on every link (both
+ *                        distributions with ndist = 2) and the momentum
+ *                        given to the walls accumulated on the device.
+ *   lbmi_wall_momentum   wall_momentum (wall.c:1299-1330): read the
+ *                        accumulated momentum and zero it. */
+int lbmi_wall_map(lbmi_t * lb, const int isboundary[3], char * status);
+int lbmi_wall_links_build(lbmi_t * lb, const char * status,
+			  const int isboundary[3], int * nlink);
+int lbmi_wall_links(lbmi_t * lb, int * linki, int * linkj, int * linkp,
+		    int * linku);
+int lbmi_wall_velocity_set(lbmi_t * lb, const double ubot[3],
+			   const double utop[3]);
+int lbmi_wall_bbl(lbmi_t * lb);
+/* The same on DEVICE link arrays the caller owns (the reference's
+ * wall->target->linki, linkj, linkp, linku), fnet = 3 doubles on the device
+ * that the momentum is added to (wall->target->fnet). */
+int lbmi_wall_bbl_arrays(lbmi_t * lb, int nlink, const int * linki,
+			 const int * linkj, const int * linkp,
+			 const int * linku, const double ubot[3],
+			 const double utop[3], double * fnet);
+int lbmi_wall_momentum(lbmi_t * lb, double fnet[3]);
+
 typedef struct lbmi_fe_symm_s {
   double a, b, kappa;        /* fe_symm_param_t, symmetric.h */
   double mobility;           /* physics_mobility */

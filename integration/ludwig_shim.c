@@ -11,6 +11,8 @@
  *      lb_halo_swap()    lb_data.h:160     (replaces model.c:565-595)
  *      lb_propagation()  propagation.h:21  (replaces propagation.c:43-98)
  *      lb_memcpy()       lb_data.h:156     (wraps  model.c:228-266)
+ *      wall_bbl()        wall.h:99         (replaces wall.c:960-989; no slip)
+ *      phi_lb_to_field() phi_lb_coupler.h  (replaces phi_lb_coupler.c:39-64)
  *
  *  by unpacking lb_t / hydro_t / map_t and calling the C-ABI of
  *  include/lbmi.h. The other contents of collision.c / model.c /
@@ -21,8 +23,10 @@
  *      -Dlb_halo_swap=lb_halo_swap_ref -Dlb_propagation=lb_propagation_ref
  *      -Dlb_memcpy=lb_memcpy_ref
  *
- *  so that their originals remain available as fall-backs (ndist = 2, walls,
- *  colloids, Lees-Edwards, host halo schemes), and this file is compiled
+ *  (and wall.c with -Dwall_bbl=wall_bbl_ref, phi_lb_coupler.c with
+ *  -Dphi_lb_to_field=phi_lb_to_field_ref) so that their originals remain
+ *  available as fall-backs (slip walls, colloids, Lees-Edwards, host halo
+ *  schemes, noise), and this file is compiled
  *  with the same -D_D3Q19_|-D_D3Q27_ -DADDR_SOA as the rest of libludwig.a
  *  and linked with -llbmi. See INTEGRATION.md.
  *
@@ -35,6 +39,7 @@
 
 #include <assert.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdlib.h>
 
 #include "pe.h"
@@ -47,6 +52,11 @@
 #include "map.h"
 #include "noise.h"
 #include "util.h"
+#include "field.h"
+#include "field_grad.h"
+#include "symmetric.h"
+#include "wall.h"
+#include "phi_lb_coupler.h"
 
 #include "lbmi.h"
 
@@ -56,6 +66,8 @@ int lb_collide_ref(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
 int lb_halo_swap_ref(lb_t * lb, lb_halo_enum_t flag);
 int lb_propagation_ref(lb_t * lb);
 int lb_memcpy_ref(lb_t * lb, tdpMemcpyKind flag);
+int wall_bbl_ref(wall_t * wall);
+int phi_lb_to_field_ref(field_t * phi, lb_t * lb);
 
 /* One liblbmi handle per lb_t (Ludwig has one lb_t per rank) */
 
@@ -76,17 +88,19 @@ static shim_t shim_ = {NULL, NULL, 0};
     }									\
   } while (0)
 
-/* Can liblbmi take this lb_t? Single distribution, SoA build, device halo
- * scheme, decomposition along X only. Anything else uses the originals. */
+/* Can liblbmi take this lb_t? SoA build, device halo scheme, decomposition
+ * along X only; two distributions (symmetric_lb) on a single rank. Anything
+ * else uses the originals. */
 
 static int shim_supported(lb_t * lb) {
   int cartsz[3];
   if (DATA_MODEL != DATA_MODEL_SOA) return 0;
-  if (lb->ndist != 1) return 0;
+  if (lb->ndist != 1 && lb->ndist != 2) return 0;
   if (lb->model.nvel != 19 && lb->model.nvel != 27) return 0;
   if (lb->haloscheme != LB_HALO_TARGET) return 0;
   cs_cartsz(lb->cs, cartsz);
   if (cartsz[Y] != 1 || cartsz[Z] != 1) return 0;
+  if (lb->ndist == 2 && cartsz[X] != 1) return 0;
   return 1;
 }
 
@@ -145,7 +159,7 @@ static lbmi_t * shim_handle(lb_t * lb) {
     opts.device = -1;                            /* ludwig.c:467-492 chose it */
     opts.halo_scheme = LBMI_HALO_FULL;           /* halo_swap_packed semantics */
     opts.mode = LBMI_MODE_EAGER;
-    if (mode && mode[0] == 'f') opts.mode = LBMI_MODE_FUSED;
+    if (mode && mode[0] == 'f' && lb->ndist == 1) opts.mode = LBMI_MODE_FUSED;
 
     SHIM_CHECK(lb, lbmi_create(&opts, &shim_.h));
     /* Ludwig launches all its kernels on the default stream
@@ -189,9 +203,11 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
   assert(map);
 
   /* Not covered by liblbmi: fluctuations, free-energy stress relaxation,
-   * viscosity models, two distributions */
+   * viscosity models; two distributions only with the symmetric free energy
+   * (as the reference, collision.c:160) */
   if (!shim_supported(lb) || noise->on[NOISE_RHO] ||
-      (fe && fe->use_stress_relaxation) || visc != NULL) {
+      (fe && fe->use_stress_relaxation) || visc != NULL ||
+      (lb->ndist == 2 && (fe == NULL || fe->id != FE_SYMMETRIC))) {
     if (shim_.h && shim_.lb == lb) {
       SHIM_CHECK(lb, lbmi_lb_flush(shim_.h));
       shim_sync_pointers(lb, shim_.h);
@@ -236,8 +252,90 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
     hy.rho    = shim_field_data(hydro->rho);
     hy.u      = shim_field_data(hydro->u);
 
-    SHIM_CHECK(lb, lbmi_lb_collide(h, &hy));
+    if (lb->ndist == 2) {
+      /* lb_collision_binary (collision.c:610-1027) */
+      fe_symm_t * fs = (fe_symm_t *) fe;
+      fe_symm_param_t param;
+      lbmi_fe_symm_t bin;
+      fe_symm_param(fs, &param);
+      bin.a = param.a;
+      bin.b = param.b;
+      bin.kappa = param.kappa;
+      physics_mobility(phys, &bin.mobility);
+      bin.phi = shim_field_data(fs->phi);
+      tdpAssert(tdpMemcpy(&bin.grad, &fs->dphi->target->grad, sizeof(double *),
+			  tdpMemcpyDeviceToHost));
+      tdpAssert(tdpMemcpy(&bin.delsq, &fs->dphi->target->delsq,
+			  sizeof(double *), tdpMemcpyDeviceToHost));
+      SHIM_CHECK(lb, lbmi_lb_collide_binary(h, &hy, &bin));
+    }
+    else {
+      SHIM_CHECK(lb, lbmi_lb_collide(h, &hy));
+    }
     shim_sync_pointers(lb, h);                   /* FUSED swaps here */
+  }
+
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  phi_lb_to_field  (phi_lb_coupler.c:39-64)
+ *
+ *****************************************************************************/
+
+int phi_lb_to_field(field_t * phi, lb_t * lb) {
+
+  assert(phi);
+  assert(lb);
+
+  if (!shim_supported(lb) || lb->ndist != 2) return phi_lb_to_field_ref(phi, lb);
+
+  SHIM_CHECK(lb, lbmi_lb_phi_to_field(shim_handle(lb), shim_field_data(phi)));
+
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  wall_bbl  (wall.c:960-989): bounce-back on the reference's own links
+ *
+ *  The link arrays and the momentum accumulator are members of the DEVICE
+ *  copy of wall_t; the kernel works on them where they are.
+ *
+ *****************************************************************************/
+
+int wall_bbl(wall_t * wall) {
+
+  assert(wall);
+  assert(wall->target);
+
+  if (wall->nlink == 0) return 0;                /* wall.c:967 */
+
+  if (wall->param->slip.active || !shim_supported(wall->lb)) {
+    return wall_bbl_ref(wall);
+  }
+  if (shim_.fused) {
+    pe_fatal(wall->pe, "liblbmi: LBMI_MODE=fused cannot be used with walls "
+	     "(bounce-back acts between lb_halo and lb_propagation)\n");
+  }
+
+  {
+    int * link[4] = {NULL, NULL, NULL, NULL};
+    double * fnet = (double *) ((char *) wall->target + offsetof(wall_t, fnet));
+    tdpAssert(tdpMemcpy(&link[0], &wall->target->linki, sizeof(int *),
+			tdpMemcpyDeviceToHost));
+    tdpAssert(tdpMemcpy(&link[1], &wall->target->linkj, sizeof(int *),
+			tdpMemcpyDeviceToHost));
+    tdpAssert(tdpMemcpy(&link[2], &wall->target->linkp, sizeof(int *),
+			tdpMemcpyDeviceToHost));
+    tdpAssert(tdpMemcpy(&link[3], &wall->target->linku, sizeof(int *),
+			tdpMemcpyDeviceToHost));
+    SHIM_CHECK(wall->lb, lbmi_wall_bbl_arrays(shim_handle(wall->lb),
+					       wall->nlink, link[0], link[1],
+					       link[2], link[3],
+					       wall->param->ubot,
+					       wall->param->utop, fnet));
   }
 
   return 0;

@@ -74,6 +74,17 @@ struct lbmi_s {
   int grad_npt;
   int adv_order;
 
+  /* walls: links (device), their host copy, momentum accounting */
+  int nlink;
+  int * link_dev[4];                 /* i, j, p, u */
+  int * link_host[4];
+  double * wall_part;                /* per-block momentum partials */
+  int wall_part_nblk;
+  double * wall_fnet;                /* device accumulator, 3 doubles */
+  double wall_ubot[3];
+  double wall_utop[3];
+  double rho0;
+
   /* kernel timing */
   int timing;
   int nev;
@@ -341,6 +352,8 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
  *
  *****************************************************************************/
 
+static void lbmi_wall_release(lbmi_t * lb);
+
 int lbmi_free(lbmi_t * lb) {
 
   if (lb == NULL) return 0;
@@ -357,6 +370,7 @@ int lbmi_free(lbmi_t * lb) {
   }
   if (lb->mom_work) hipFree(lb->mom_work);
   if (lb->mom_out) hipFree(lb->mom_out);
+  lbmi_wall_release(lb);
   if (lb->ev_created) {
     for (int n = 0; n < LBMI_NEVENT; n++) {
       if (lb->ev0[n]) hipEventDestroy(lb->ev0[n]);
@@ -405,6 +419,7 @@ int lbmi_set_relaxation(lbmi_t * lb, int scheme, double rho0,
 
   rtau = 1.0/(0.5 + eta_shear/(rho0*cs2));
   rtau_bulk = 1.0/(0.5 + eta_bulk/(rho0*cs2));
+  lb->rho0 = rho0;
 
   switch (scheme) {
   case LBMI_RELAXATION_M10:
@@ -1029,6 +1044,246 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
   }
   KCHECK(lbmi_k_collide(&lb->kp, lb->f, &h, lb->stream));
 
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  Flat walls and bounce-back on links (wall.c)
+ *
+ *****************************************************************************/
+
+enum {LBMI_MAP_FLUID = 0, LBMI_MAP_BOUNDARY = 1};        /* map.h:23 */
+
+static void lbmi_wall_release(lbmi_t * lb) {
+  for (int k = 0; k < 4; k++) {
+    if (lb->link_dev[k]) hipFree(lb->link_dev[k]);
+    free(lb->link_host[k]);
+    lb->link_dev[k] = NULL;
+    lb->link_host[k] = NULL;
+  }
+  if (lb->wall_part) hipFree(lb->wall_part);
+  if (lb->wall_fnet) hipFree(lb->wall_fnet);
+  lb->wall_part = NULL;
+  lb->wall_part_nblk = 0;
+  lb->wall_fnet = NULL;
+  lb->nlink = 0;
+}
+
+static int lbmi_wall_args(const lbmi_t * lb, const int isboundary[3]) {
+  if (lb == NULL || isboundary == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->opts.cartsz != 1) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "walls: one rank (cartsz = 1)");
+  }
+  return 0;
+}
+
+int lbmi_wall_map(lbmi_t * lb, const int isboundary[3], char * status) {
+  char * host = NULL;
+  const int h = lb ? lb->kp.nhalo : 0;
+  size_t ns;
+  int ifail = lbmi_wall_args(lb, isboundary);
+  if (ifail) return ifail;
+  if (status == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  HIPCHECK(hipSetDevice(lb->device));
+  ns = (size_t) lb->kp.nsite;
+  host = (char *) malloc(ns);
+  if (host == NULL) return lbmi_fail(LBMI_ERR_HIP, "wall map");
+  if (hipMemcpy(host, status, ns, hipMemcpyDeviceToHost) != hipSuccess) {
+    free(host);
+    return lbmi_fail(LBMI_ERR_HIP, "wall map: device to host");
+  }
+  for (int ic = 0; ic < lb->kp.nall[X]; ic++) {
+    for (int jc = 0; jc < lb->kp.nall[Y]; jc++) {
+      for (int kc = 0; kc < lb->kp.nall[Z]; kc++) {
+	/* coordinate 0 or nlocal + 1 in the reference's numbering */
+	int wall = 0;
+	if (isboundary[X] && (ic == h - 1 || ic == h + lb->kp.nlocal[X])) wall = 1;
+	if (isboundary[Y] && (jc == h - 1 || jc == h + lb->kp.nlocal[Y])) wall = 1;
+	if (isboundary[Z] && (kc == h - 1 || kc == h + lb->kp.nlocal[Z])) wall = 1;
+	if (wall) {
+	  host[(size_t) ic*lb->kp.strx + (size_t) jc*lb->kp.stry + kc] = LBMI_MAP_BOUNDARY;
+	}
+      }
+    }
+  }
+  if (hipMemcpy(status, host, ns, hipMemcpyHostToDevice) != hipSuccess) {
+    free(host);
+    return lbmi_fail(LBMI_ERR_HIP, "wall map: host to device");
+  }
+  free(host);
+  return 0;
+}
+
+int lbmi_wall_links_build(lbmi_t * lb, const char * status,
+			  const int isboundary[3], int * nlink_out) {
+  char * host = NULL;
+  size_t ns;
+  int nlink = 0;
+  int iw = -1;
+  const int h = lb ? lb->kp.nhalo : 0;
+  int ifail = lbmi_wall_args(lb, isboundary);
+  if (ifail) return ifail;
+  if (status == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  HIPCHECK(hipSetDevice(lb->device));
+  HIPCHECK(hipStreamSynchronize(lb->stream));
+  lbmi_wall_release(lb);
+
+  ns = (size_t) lb->kp.nsite;
+  host = (char *) malloc(ns);
+  if (host == NULL) return lbmi_fail(LBMI_ERR_HIP, "wall links");
+  if (hipMemcpy(host, status, ns, hipMemcpyDeviceToHost) != hipSuccess) {
+    free(host);
+    return lbmi_fail(LBMI_ERR_HIP, "wall links: device to host");
+  }
+  if (isboundary[X] + isboundary[Y] + isboundary[Z] == 1) {
+    iw = isboundary[X] ? X : (isboundary[Y] ? Y : Z);
+  }
+
+  /* wall_init_boundaries: count, allocate, fill (wall.c:381-470) */
+  for (int pass = 0; pass < 2; pass++) {
+    int n = 0;
+    for (int ic = h; ic < h + lb->kp.nlocal[X]; ic++) {
+      for (int jc = h; jc < h + lb->kp.nlocal[Y]; jc++) {
+	for (int kc = h; kc < h + lb->kp.nlocal[Z]; kc++) {
+	  size_t i = (size_t) ic*lb->kp.strx + (size_t) jc*lb->kp.stry + kc;
+	  if (host[i] != LBMI_MAP_FLUID) continue;
+	  for (int p = 1; p < lb->kp.nvel; p++) {
+	    size_t j = i + lb->cv[p][X]*lb->kp.strx + lb->cv[p][Y]*lb->kp.stry
+	      + lb->cv[p][Z];
+	    if (host[j] != LBMI_MAP_BOUNDARY) continue;
+	    if (pass == 1) {
+	      lb->link_host[0][n] = (int) i;
+	      lb->link_host[1][n] = (int) j;
+	      lb->link_host[2][n] = p;
+	      lb->link_host[3][n] = 0;                       /* WALL_UZERO */
+	      /* wall_init_uw (wall.c:864-890) */
+	      if (iw >= 0 && lb->cv[p][iw] == -1) lb->link_host[3][n] = 2;
+	      if (iw >= 0 && lb->cv[p][iw] == +1) lb->link_host[3][n] = 1;
+	    }
+	    n += 1;
+	  }
+	}
+      }
+    }
+    if (pass == 0) {
+      nlink = n;
+      for (int k = 0; k < 4 && ifail == 0; k++) {
+	lb->link_host[k] = (int *) calloc((size_t) (nlink > 0 ? nlink : 1), sizeof(int));
+	if (lb->link_host[k] == NULL) ifail = lbmi_fail(LBMI_ERR_HIP, "wall links");
+      }
+      if (ifail) break;
+    }
+  }
+  free(host);
+  if (ifail) {
+    lbmi_wall_release(lb);
+    return ifail;
+  }
+
+  for (int k = 0; k < 4; k++) {
+    size_t sz = sizeof(int)*(size_t) (nlink > 0 ? nlink : 1);
+    if (hipMalloc((void **) &lb->link_dev[k], sz) != hipSuccess ||
+	hipMemcpy(lb->link_dev[k], lb->link_host[k], sz, hipMemcpyHostToDevice) != hipSuccess) {
+      lbmi_wall_release(lb);
+      return lbmi_fail(LBMI_ERR_HIP, "wall links: device arrays");
+    }
+  }
+  if (hipMalloc((void **) &lb->wall_fnet, 3*sizeof(double)) != hipSuccess ||
+      hipMemset(lb->wall_fnet, 0, 3*sizeof(double)) != hipSuccess) {
+    lbmi_wall_release(lb);
+    return lbmi_fail(LBMI_ERR_HIP, "wall momentum workspace");
+  }
+  lb->nlink = nlink;
+  if (nlink_out) *nlink_out = nlink;
+  return 0;
+}
+
+int lbmi_wall_links(lbmi_t * lb, int * linki, int * linkj, int * linkp,
+		    int * linku) {
+  int * out[4] = {linki, linkj, linkp, linku};
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->link_host[0] == NULL) return lbmi_fail(LBMI_ERR_STATE, "no links built");
+  for (int k = 0; k < 4; k++) {
+    if (out[k]) memcpy(out[k], lb->link_host[k], sizeof(int)*(size_t) lb->nlink);
+  }
+  return 0;
+}
+
+int lbmi_wall_velocity_set(lbmi_t * lb, const double ubot[3],
+			   const double utop[3]) {
+  if (lb == NULL || ubot == NULL || utop == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  for (int ia = 0; ia < 3; ia++) {
+    lb->wall_ubot[ia] = ubot[ia];
+    lb->wall_utop[ia] = utop[ia];
+  }
+  return 0;
+}
+
+/* wall_bbl on link arrays owned by the caller (the reference keeps
+ * wall->target->linki, linkj, linkp, linku and fnet on the device) */
+
+int lbmi_wall_bbl_arrays(lbmi_t * lb, int nlink, const int * linki,
+			 const int * linkj, const int * linkp,
+			 const int * linku, const double ubot[3],
+			 const double utop[3], double * fnet) {
+  lbmi_wall_tab_t tab;
+  double na[LBMI_NVEL_MAX];
+  double ma[LBMI_NVEL_MAX*LBMI_NVEL_MAX];
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+  if (lb->opts.mode != LBMI_MODE_EAGER) {
+    /* bounce-back acts on the post-collision state between lb_halo and
+     * lb_propagation: that state must exist (ludwig.c:836-858) */
+    return lbmi_fail(LBMI_ERR_STATE, "walls need LBMI_MODE_EAGER");
+  }
+  if (nlink == 0) return 0;                          /* wall.c:967 */
+  if (nlink < 0 || !linki || !linkj || !linkp || !linku || !ubot || !utop || !fnet) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_wall_bbl_arrays: bad argument");
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  if (lb->wall_part == NULL || lb->wall_part_nblk < lbmi_k_wall_nblk(nlink)) {
+    if (lb->wall_part) HIPCHECK(hipFree(lb->wall_part));
+    lb->wall_part = NULL;
+    lb->wall_part_nblk = lbmi_k_wall_nblk(nlink);
+    HIPCHECK(hipMalloc((void **) &lb->wall_part,
+		       sizeof(double)*3*(size_t) lb->wall_part_nblk));
+  }
+  memset(&tab, 0, sizeof(tab));
+  tab.nvel = lb->kp.nvel;
+  tab.ndist = lb->opts.ndist;
+  tab.rho0 = lb->rho0;
+  if (lbmi_k_model(lb->kp.nvel, &tab.cv[0][0], tab.wv, na, ma) != 0) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "model tables");
+  }
+  for (int ia = 0; ia < 3; ia++) {
+    tab.uw[0][ia] = 0.0;
+    tab.uw[1][ia] = utop[ia];
+    tab.uw[2][ia] = ubot[ia];
+  }
+  KCHECK(lbmi_k_wall_bbl(&lb->kp, &tab, lb->f, nlink, linki, linkj, linkp,
+			 linku, lb->wall_part, fnet, lb->stream));
+  return 0;
+}
+
+int lbmi_wall_bbl(lbmi_t * lb) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->link_host[0] == NULL) return lbmi_fail(LBMI_ERR_STATE, "no links built");
+  return lbmi_wall_bbl_arrays(lb, lb->nlink, lb->link_dev[0], lb->link_dev[1],
+			      lb->link_dev[2], lb->link_dev[3], lb->wall_ubot,
+			      lb->wall_utop, lb->wall_fnet);
+}
+
+int lbmi_wall_momentum(lbmi_t * lb, double fnet[3]) {
+  if (lb == NULL || fnet == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  fnet[0] = fnet[1] = fnet[2] = 0.0;
+  if (lb->wall_fnet == NULL) return 0;
+  HIPCHECK(hipSetDevice(lb->device));
+  /* accumulate to the host and zero the device total (wall.c:1306-1325) */
+  HIPCHECK(hipMemcpyAsync(fnet, lb->wall_fnet, 3*sizeof(double),
+			  hipMemcpyDeviceToHost, lb->stream));
+  HIPCHECK(hipMemsetAsync(lb->wall_fnet, 0, 3*sizeof(double), lb->stream));
+  HIPCHECK(hipStreamSynchronize(lb->stream));
   return 0;
 }
 

@@ -146,6 +146,23 @@ int lbmi_k_collide_binary(const lbmi_kparam_t * kp, double * f2,
 			  const double * grad, const double * delsq,
 			  void * stream);
 
+/* Bounce-back on links (wall_bbl_kernel, wall.c:996-1107). Tables travel by
+ * value; part: nblk*3 doubles of per-block momentum, added to fnet[3] (device)
+ * by a one-thread epilogue in block order (deterministic). */
+typedef struct lbmi_wall_tab_s {
+  int nvel;
+  int ndist;
+  int8_t cv[LBMI_NVEL_MAX][3];
+  double wv[LBMI_NVEL_MAX];
+  double rho0;
+  double uw[3][3];              /* WALL_UZERO, WALL_UWTOP, WALL_UWBOT */
+} lbmi_wall_tab_t;
+int lbmi_k_wall_nblk(int nlink);
+int lbmi_k_wall_bbl(const lbmi_kparam_t * kp, const lbmi_wall_tab_t * tab,
+		    double * f, int nlink, const int * linki,
+		    const int * linkj, const int * linkp, const int * linku,
+		    double * part, double * fnet, void * stream);
+
 /* Moments: partial (nblk x 12 doubles workspace) then final (out_dev[9]) */
 int lbmi_k_moments_nblk(void);
 int lbmi_k_moments(const lbmi_kparam_t * kp, const double * f,

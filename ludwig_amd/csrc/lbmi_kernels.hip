@@ -1970,6 +1970,78 @@ int model_tables(int8_t * cv, double * wv, double * na, double * ma) {
 
 /* ---- C launchers ------------------------------------------------------------ */
 
+/* ---- bounce-back on links (row f4) --------------------------------------------
+ *
+ * wall_bbl_kernel (wall.c:996-1107) without colloids: link n joins the fluid
+ * site i to the solid site j = i + c_p; the post-collision population p at i
+ * comes back as population nvel - p at j (from where lb_propagation pulls it
+ * into i), minus 2 rcs2 w_p rho0 c_p.u_w for a moving wall; both
+ * distributions when ndist = 2. The momentum given to the wall,
+ * (2 f - 2 rcs2 w_p rho0 c_p.u_w - 2 w_p) c_p, is reduced per block
+ * (shuffles + LDS) and added to fnet in block order. */
+
+enum {WALL_BLOCK = 256, WALL_NBLK_MAX = 1024};
+
+__global__ __launch_bounds__(WALL_BLOCK)
+void k_wall_bbl(lbmi_kparam_t kp, lbmi_wall_tab_t tab, double * __restrict__ f,
+		int nlink, const int * __restrict__ linki,
+		const int * __restrict__ linkj, const int * __restrict__ linkp,
+		const int * __restrict__ linku, double * __restrict__ part) {
+
+  const size_t ns = (size_t) kp.nsite;
+  const double rcs2 = 3.0;
+  double fx = 0.0, fy = 0.0, fz = 0.0;
+
+  for (int n = blockIdx.x*WALL_BLOCK + threadIdx.x; n < nlink;
+       n += gridDim.x*WALL_BLOCK) {
+    const int i = linki[n], j = linkj[n];
+    const int ij = linkp[n], ji = tab.nvel - ij, ia = linku[n];
+    const double cx = tab.cv[ij][0], cy = tab.cv[ij][1], cz = tab.cv[ij][2];
+    const double cdotu = cx*tab.uw[ia][0] + cy*tab.uw[ia][1] + cz*tab.uw[ia][2];
+    const double wall = 2.0*rcs2*tab.wv[ij]*tab.rho0*cdotu;
+    double fp = f[ns*ij + i];
+    const double force = 2.0*fp - wall;
+    fx += (force - 2.0*tab.wv[ij])*cx;
+    fy += (force - 2.0*tab.wv[ij])*cy;
+    fz += (force - 2.0*tab.wv[ij])*cz;
+    f[ns*ji + j] = fp - wall;
+    if (tab.ndist > 1) {
+      const size_t off = ns*(size_t) tab.nvel;
+      f[off + ns*ji + j] = f[off + ns*ij + i] - wall;
+    }
+  }
+
+  /* block reduction: 64-lane shuffles, then one LDS slot per wave */
+  for (int d = 32; d > 0; d >>= 1) {
+    fx += shfl_down_d(fx, d);
+    fy += shfl_down_d(fy, d);
+    fz += shfl_down_d(fz, d);
+  }
+  __shared__ double red[WALL_BLOCK/64][3];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[wave][0] = fx; red[wave][1] = fy; red[wave][2] = fz; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int w = 0; w < WALL_BLOCK/64; w++) {
+      s0 += red[w][0]; s1 += red[w][1]; s2 += red[w][2];
+    }
+    part[3*blockIdx.x + 0] = s0;
+    part[3*blockIdx.x + 1] = s1;
+    part[3*blockIdx.x + 2] = s2;
+  }
+}
+
+__global__ void k_wall_fnet(int nblk, const double * __restrict__ part,
+			    double * __restrict__ fnet) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; b++) {
+    s0 += part[3*b]; s1 += part[3*b + 1]; s2 += part[3*b + 2];
+  }
+  fnet[0] += s0; fnet[1] += s1; fnet[2] += s2;
+}
+
 extern "C" int lbmi_k_collide(const lbmi_kparam_t * kp, double * f,
 			      const lbmi_hydro_dev_t * h, void * stream) {
   hipStream_t st = (hipStream_t) stream;
@@ -2364,6 +2436,28 @@ extern "C" int lbmi_k_collide_binary(const lbmi_kparam_t * kp, double * f2,
   if (kp->nvel == 19) return launch_collide_binary<19>(*kp, f2, *h, q, rtau2, phi, grad, delsq, st);
   if (kp->nvel == 27) return launch_collide_binary<27>(*kp, f2, *h, q, rtau2, phi, grad, delsq, st);
   return (int) hipErrorInvalidValue;
+}
+
+extern "C" int lbmi_k_wall_nblk(int nlink) {
+  int nblk = (nlink + WALL_BLOCK - 1)/WALL_BLOCK;
+  if (nblk > WALL_NBLK_MAX) nblk = WALL_NBLK_MAX;
+  if (nblk < 1) nblk = 1;
+  return nblk;
+}
+
+extern "C" int lbmi_k_wall_bbl(const lbmi_kparam_t * kp,
+			       const lbmi_wall_tab_t * tab, double * f,
+			       int nlink, const int * linki,
+			       const int * linkj, const int * linkp,
+			       const int * linku, double * part,
+			       double * fnet, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  int nblk = lbmi_k_wall_nblk(nlink);
+  if (nlink <= 0) return 0;
+  hipLaunchKernelGGL(k_wall_bbl, dim3(nblk), dim3(WALL_BLOCK), 0, st, *kp,
+		     *tab, f, nlink, linki, linkj, linkp, linku, part);
+  hipLaunchKernelGGL(k_wall_fnet, dim3(1), dim3(64), 0, st, nblk, part, fnet);
+  return (int) hipGetLastError();
 }
 
 extern "C" int lbmi_k_moments_nblk(void) { return MOM_NBLK; }

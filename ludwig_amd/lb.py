@@ -340,6 +340,43 @@ class LB:
     def synchronize(self):
         _l.check(self._lib.lbmi_synchronize(self._h))
 
+    # -- walls (wall.c) -----------------------------------------------------
+
+    def wall_map(self, isboundary, status):
+        """wall_init_map: MAP_BOUNDARY into the device map (int8, nall)."""
+        b = (ctypes.c_int * 3)(*[int(x) for x in isboundary])
+        _l.check(self._lib.lbmi_wall_map(self._h, b, _ptr(status)))
+
+    def wall_links_build(self, status, isboundary):
+        """wall_init_boundaries + wall_init_uw; returns the number of links."""
+        b = (ctypes.c_int * 3)(*[int(x) for x in isboundary])
+        n = ctypes.c_int(0)
+        _l.check(self._lib.lbmi_wall_links_build(self._h, _ptr(status), b,
+                                                 ctypes.byref(n)))
+        self.nlink = n.value
+        return n.value
+
+    def wall_links(self):
+        """(linki, linkj, linkp, linku) as the reference holds them."""
+        arr = [np.zeros(max(self.nlink, 1), dtype=np.int32) for _ in range(4)]
+        _l.check(self._lib.lbmi_wall_links(
+            self._h, *[a.ctypes.data_as(ctypes.c_void_p) for a in arr]))
+        return tuple(a[:self.nlink] for a in arr)
+
+    def wall_velocity_set(self, ubot, utop):
+        ub = (ctypes.c_double * 3)(*[float(x) for x in ubot])
+        ut = (ctypes.c_double * 3)(*[float(x) for x in utop])
+        _l.check(self._lib.lbmi_wall_velocity_set(self._h, ub, ut))
+
+    def wall_bbl(self):
+        """wall_bbl: between lb_halo and lb_propagation (EAGER)."""
+        _l.check(self._lib.lbmi_wall_bbl(self._h))
+
+    def wall_momentum(self):
+        out = (ctypes.c_double * 3)()
+        _l.check(self._lib.lbmi_wall_momentum(self._h, out))
+        return np.array(out[:])
+
     def phi_to_field(self, phi):
         """phi_lb_to_field (ndist = 2): phi = sum_p g_p."""
         _l.check(self._lib.lbmi_lb_phi_to_field(self._h, _ptr(phi)))

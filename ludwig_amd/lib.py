@@ -85,6 +85,14 @@ SYMBOLS = [
     ("lbmi_lb_propagation", _i, [_vp]),
     ("lbmi_lb_flush", _i, [_vp]),
     ("lbmi_lb_state", _i, [_vp, ctypes.POINTER(_i)]),
+    ("lbmi_wall_map", _i, [_vp, ctypes.POINTER(_i), _vp]),
+    ("lbmi_wall_links_build", _i, [_vp, _vp, ctypes.POINTER(_i),
+                                   ctypes.POINTER(_i)]),
+    ("lbmi_wall_links", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("lbmi_wall_velocity_set", _i, [_vp, _pd, _pd]),
+    ("lbmi_wall_bbl", _i, [_vp]),
+    ("lbmi_wall_bbl_arrays", _i, [_vp, _i, _vp, _vp, _vp, _vp, _pd, _pd, _vp]),
+    ("lbmi_wall_momentum", _i, [_vp, _pd]),
     ("lbmi_lb_phi_to_field", _i, [_vp, _vp]),
     ("lbmi_lb_collide_binary", _i, [_vp, ctypes.POINTER(HydroPtrs),
                                     ctypes.POINTER(FeSymm)]),

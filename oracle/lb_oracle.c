@@ -545,6 +545,130 @@ int lbo_collide_binary(const lbo_param_t * p, double * f2,
 }
 
 /*
+ * lbo_wall_map, lbo_wall_links, lbo_wall_bbl
+ *
+ * Flat walls and bounce-back on links (row f4).
+ *
+ * lbo_wall_map: wall_init_map (wall.c:1219-1268) on one rank: every site
+ * (halo included) whose coordinate in a wall direction is 0 or ntotal+1
+ * becomes MAP_BOUNDARY (status: nsite chars, other entries untouched).
+ *
+ * lbo_wall_links: wall_init_boundaries (wall.c:381-470) + wall_init_uw
+ * (:864-890): for every interior MAP_FLUID site i, in (ic, jc, kc) order, and
+ * p = 1..nvel-1, a link if i + c_p is MAP_BOUNDARY; linku = 0 (WALL_UZERO),
+ * or with walls in exactly ONE direction iw: 2 (WALL_UWBOT) if c_p[iw] = -1,
+ * 1 (WALL_UWTOP) if c_p[iw] = +1 (wall.c:32-35: WALL_UZERO, WALL_UWTOP, WALL_UWBOT).
+ * Returns the number of links; fills at most maxlink entries.
+ *
+ * lbo_wall_bbl: wall_bbl_kernel (wall.c:996-1107), no colloids, one
+ * distribution: f[j, nvel - p] = f[i, p] - 2 rcs2 w_p rho0 c_p.u_w, and the
+ * momentum transfer (2 f[i,p] - 2 rcs2 w_p rho0 c_p.u_w - 2 w_p) c_p is
+ * ADDED to fnet.
+ */
+
+#define MAP_BOUNDARY_ 1          /* map.h: MAP_FLUID = 0, MAP_BOUNDARY = 1 */
+
+int lbo_wall_map(const lbo_param_t * p, const int isboundary[3],
+		 char * status) {
+  int nall[3];
+  ptrdiff_t str[3];
+  int h = p->nhalo;
+
+  strides(p, nall, str);
+  for (int ic = 1 - h; ic <= p->nlocal[X] + h; ic++) {
+    for (int jc = 1 - h; jc <= p->nlocal[Y] + h; jc++) {
+      for (int kc = 1 - h; kc <= p->nlocal[Z] + h; kc++) {
+	ptrdiff_t index = str[X]*(h + ic - 1) + str[Y]*(h + jc - 1) + (h + kc - 1);
+	if (isboundary[Z] && (kc == 0 || kc == p->nlocal[Z] + 1)) status[index] = MAP_BOUNDARY_;
+	if (isboundary[Y] && (jc == 0 || jc == p->nlocal[Y] + 1)) status[index] = MAP_BOUNDARY_;
+	if (isboundary[X] && (ic == 0 || ic == p->nlocal[X] + 1)) status[index] = MAP_BOUNDARY_;
+      }
+    }
+  }
+  return 0;
+}
+
+int lbo_wall_links(const lbo_param_t * p, const char * status,
+		   const int isboundary[3], int maxlink, int * linki,
+		   int * linkj, int * linkp, int * linku) {
+  int nall[3];
+  ptrdiff_t str[3];
+  int h = p->nhalo;
+  int nlink = 0;
+  int nwall = isboundary[X] + isboundary[Y] + isboundary[Z];
+  int iw = -1;
+  lbo_model_t model;
+
+  if (lbo_model_create(p->nvel, &model) != 0) return -1;
+  strides(p, nall, str);
+  if (nwall == 1) {
+    if (isboundary[X]) iw = X;
+    if (isboundary[Y]) iw = Y;
+    if (isboundary[Z]) iw = Z;
+  }
+
+  for (int ic = 1; ic <= p->nlocal[X]; ic++) {
+    for (int jc = 1; jc <= p->nlocal[Y]; jc++) {
+      for (int kc = 1; kc <= p->nlocal[Z]; kc++) {
+	ptrdiff_t i = str[X]*(h + ic - 1) + str[Y]*(h + jc - 1) + (h + kc - 1);
+	if (status[i] != MAP_FLUID) continue;
+	for (int q = 1; q < p->nvel; q++) {
+	  ptrdiff_t j = i + str[X]*model.cv[q][X] + str[Y]*model.cv[q][Y]
+	    + model.cv[q][Z];
+	  if (status[j] != MAP_BOUNDARY_) continue;
+	  if (nlink < maxlink) {
+	    linki[nlink] = (int) i;
+	    linkj[nlink] = (int) j;
+	    linkp[nlink] = q;
+	    linku[nlink] = 0;
+	    if (iw >= 0 && model.cv[q][iw] == -1) linku[nlink] = 2;
+	    if (iw >= 0 && model.cv[q][iw] == +1) linku[nlink] = 1;
+	  }
+	  nlink += 1;
+	}
+      }
+    }
+  }
+  return nlink;
+}
+
+int lbo_wall_bbl(const lbo_param_t * p, double * f, int nlink,
+		 const int * linki, const int * linkj, const int * linkp,
+		 const int * linku, const double ubot[3],
+		 const double utop[3], double fnet[3]) {
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+  lbo_model_t model;
+  const double rcs2 = 3.0;
+  double uw[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+
+  if (lbo_model_create(p->nvel, &model) != 0) return -1;
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+  for (int ia = 0; ia < 3; ia++) {
+    uw[1][ia] = utop[ia];
+    uw[2][ia] = ubot[ia];
+  }
+
+  for (int n = 0; n < nlink; n++) {
+    int ij = linkp[n];
+    int ji = p->nvel - ij;
+    int ia = linku[n];
+    double cdotu = model.cv[ij][X]*uw[ia][X] + model.cv[ij][Y]*uw[ia][Y]
+      + model.cv[ij][Z]*uw[ia][Z];
+    double fp = f[nsite*ij + linki[n]];
+    double force = 2.0*fp - 2.0*rcs2*model.wv[ij]*p->rho0*cdotu;
+    fnet[X] += (force - 2.0*model.wv[ij])*model.cv[ij][X];
+    fnet[Y] += (force - 2.0*model.wv[ij])*model.cv[ij][Y];
+    fnet[Z] += (force - 2.0*model.wv[ij])*model.cv[ij][Z];
+    fp = fp - 2.0*rcs2*model.wv[ij]*p->rho0*cdotu;
+    f[nsite*ji + linkj[n]] = fp;
+  }
+  return 0;
+}
+
+/*
  * lbo_halo
  *
  * Net effect on one rank with periodic boundaries of lb_halo() with the

@@ -59,6 +59,15 @@ int lbo_collide_binary(const lbo_param_t * p, double * f2,
 		       double mobility, const double * phi,
 		       const double * grad, const double * delsq,
 		       double * u_out);
+int lbo_wall_map(const lbo_param_t * p, const int isboundary[3],
+		 char * status);
+int lbo_wall_links(const lbo_param_t * p, const char * status,
+		   const int isboundary[3], int maxlink, int * linki,
+		   int * linkj, int * linkp, int * linku);
+int lbo_wall_bbl(const lbo_param_t * p, double * f, int nlink,
+		 const int * linki, const int * linkj, const int * linkp,
+		 const int * linku, const double ubot[3],
+		 const double utop[3], double fnet[3]);
 int lbo_halo(const lbo_param_t * p, int nel, double * data);
 int lbo_halo_dirs(const lbo_param_t * p, int nel, double * data, int dirmask);
 int lbo_halo_width(const lbo_param_t * p, int nel, double * data, int dirmask,

@@ -74,6 +74,12 @@ def lib():
         _lib.lbo_collide_binary.argtypes = [pp, dp, dp, ctypes.c_double,
                                             ctypes.c_double, ctypes.c_double,
                                             ctypes.c_double, dp, dp, dp, dp]
+        ip = ctypes.c_void_p
+        _lib.lbo_wall_map.argtypes = [pp, ip, ctypes.c_void_p]
+        _lib.lbo_wall_links.argtypes = [pp, ctypes.c_void_p, ip, ctypes.c_int,
+                                        ip, ip, ip, ip]
+        _lib.lbo_wall_bbl.argtypes = [pp, dp, ctypes.c_int, ip, ip, ip, ip, dp,
+                                      dp, dp]
         _lib.lbo_grad_7pt.argtypes = [pp, dp, dp, dp]
         _lib.lbo_grad_27pt.argtypes = [pp, dp, dp, dp]
         _lib.lbo_cahn_hilliard.argtypes = [pp, ctypes.c_double, ctypes.c_double,
@@ -162,6 +168,41 @@ def field_halo(p, data, nswap):
     width; data shape (nel, nall...) or (nall...)."""
     nel = 1 if data.ndim == 3 else data.shape[0]
     rc = lib().lbo_halo_width(ctypes.byref(p), nel, _ptr(data), 7, nswap)
+    assert rc == 0
+
+
+def wall_map(p, isboundary, status=None):
+    """wall_init_map: MAP_BOUNDARY (1) at the wall sites; int8 (nall)."""
+    if status is None:
+        status = np.zeros(nall(p), dtype=np.int8)
+    b = np.asarray(isboundary, dtype=np.int32)
+    rc = lib().lbo_wall_map(ctypes.byref(p), _ptr(b), _ptr(status))
+    assert rc == 0
+    return status
+
+
+def wall_links(p, status, isboundary):
+    """wall_init_boundaries + wall_init_uw: (linki, linkj, linkp, linku)."""
+    b = np.asarray(isboundary, dtype=np.int32)
+    status = np.ascontiguousarray(status, dtype=np.int8)
+    n = lib().lbo_wall_links(ctypes.byref(p), _ptr(status), _ptr(b), 0, None,
+                             None, None, None)
+    assert n >= 0
+    arr = [np.zeros(max(n, 1), dtype=np.int32) for _ in range(4)]
+    m = lib().lbo_wall_links(ctypes.byref(p), _ptr(status), _ptr(b), n,
+                             *[_ptr(a) for a in arr])
+    assert m == n
+    return tuple(a[:n] for a in arr)
+
+
+def wall_bbl(p, f, links, ubot, utop, fnet):
+    """wall_bbl: bounce-back on links in place; fnet (3) accumulates."""
+    li, lj, lp, lu = [np.ascontiguousarray(a, dtype=np.int32) for a in links]
+    ub = np.asarray(ubot, dtype=np.float64)
+    ut = np.asarray(utop, dtype=np.float64)
+    rc = lib().lbo_wall_bbl(ctypes.byref(p), _ptr(f), len(li), _ptr(li),
+                            _ptr(lj), _ptr(lp), _ptr(lu), _ptr(ub), _ptr(ut),
+                            _ptr(fnet))
     assert rc == 0
 
 

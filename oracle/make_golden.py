@@ -146,6 +146,42 @@ def run_binary_case(case, tmp):
             "u": load("u", (3,)), "f_final": load("f_final", (2 * nvel,))}
 
 
+# name, nvel, (nx, ny, nz), isboundary, ubot_y, utop_y, solid block, nsteps
+WALL_CASES = [
+    ("wall_q19_x", 19, (6, 5, 4), (1, 0, 0), -0.01, 0.02, 0, 4),
+    ("wall_q19_xyz", 19, (5, 6, 4), (1, 1, 1), 0.0, 0.0, 1, 4),
+    ("wall_q27_z", 27, (5, 4, 6), (0, 0, 1), 0.01, -0.03, 0, 4),
+]
+
+
+def run_wall_case(case, tmp):
+    """Flat walls with bounce-back on links: status map, links and f after
+    the first wall_bbl and after nsteps of collide, halo, wall_bbl,
+    propagation; meta["fnet"] = the accumulated wall momentum."""
+    name, nvel, n, bnd, ubot, utop, solid, nsteps = case
+    exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
+    prefix = os.path.join(tmp, name)
+    subprocess.run([exe, "wall", prefix, *map(str, n), *map(str, bnd),
+                    repr(ubot), repr(utop), str(solid), str(nsteps)], check=True)
+    meta = json.load(open(prefix + ".json"))
+    meta["name"] = name
+    meta["scheme_name"] = "m10"
+    nall = tuple(meta["nall"])
+
+    def load(key, lead):
+        return np.fromfile("%s.%s.f64" % (prefix, key), dtype="<f8").reshape(lead + nall)
+
+    def loadi(key):
+        return np.fromfile("%s.%s.i32" % (prefix, key), dtype="<i4")
+
+    return {"meta": np.array(json.dumps(meta)),
+            "status": loadi("status").reshape(nall).astype(np.int8),
+            "linki": loadi("linki"), "linkj": loadi("linkj"),
+            "linkp": loadi("linkp"), "linku": loadi("linku"),
+            "f0": load("f0", (nvel,)), "f_bbl": load("f_bbl", (nvel,)),
+            "f_final": load("f_final", (nvel,))}
+
+
 # name, nvel, (nx, ny, nz), timestep
 IO_CASES = [
     ("io_q19", 19, (6, 5, 4), 7),
@@ -187,6 +223,11 @@ def main():
             print("wrote", fn, os.path.getsize(fn))
         for case in BINARY_CASES:
             out = run_binary_case(case, tmp)
+            fn = os.path.join(GOLD, case[0] + ".npz")
+            np.savez_compressed(fn, **out)
+            print("wrote", fn, os.path.getsize(fn))
+        for case in WALL_CASES:
+            out = run_wall_case(case, tmp)
             fn = os.path.join(GOLD, case[0] + ".npz")
             np.savez_compressed(fn, **out)
             print("wrote", fn, os.path.getsize(fn))

@@ -35,6 +35,8 @@
  *
  *    ref_driver binary <prefix> nx ny nz a b kappa mobility eta zeta fx nsteps
  *               (two-distribution symmetric_lb step, collision.c:610-1027)
+ *    ref_driver wall <prefix> nx ny nz bx by bz uboty utopy solid nsteps
+ *               (flat walls: lb_collide, lb_halo, wall_bbl, lb_propagation)
  *    ref_driver io <dir> nx ny nz timestep      (lb_io_write into <dir>)
  *    ref_driver ioread <dir> nx ny nz timestep  (lb_io_read from <dir>)
  *
@@ -74,6 +76,7 @@
 #include "phi_cahn_hilliard.h"
 #include "advection.h"
 #include "phi_lb_coupler.h"
+#include "wall.h"
 
 #define PI_ 3.14159265358979323846
 
@@ -516,6 +519,164 @@ static int run_binary(int argc, char ** argv) {
 
 /*****************************************************************************
  *
+ *  run_wall
+ *
+ *  "wall" mode: ref_driver wall <prefix> nx ny nz bx by bz uboty utopy \
+ *               solid nsteps
+ *    Flat walls in the directions with b? = 1 (wall_commit: wall_init_map,
+ *    wall_init_boundaries, wall_init_uw, wall.c:166-186, 381-470, 864-890,
+ *    1219-1268) moving with (0, uboty, 0) / (0, utopy, 0), optionally the
+ *    MAP_BOUNDARY block of init_map; the step of ludwig.c:802-860 with
+ *    walls: lb_collide, lb_halo, wall_bbl (wall.c:960-1107), lb_propagation.
+ *    Dumps the status map, the links, f after the first wall_bbl, f_final and
+ *    the accumulated wall momentum.
+ *
+ *****************************************************************************/
+
+static void dump_i32(const char * prefix, const char * name, const int * a,
+		     size_t n) {
+  char fn[1024];
+  FILE * fp = NULL;
+  snprintf(fn, sizeof(fn), "%s.%s.i32", prefix, name);
+  fp = fopen(fn, "wb");
+  if (fp == NULL) { perror(fn); exit(1); }
+  if (n > 0 && fwrite(a, sizeof(int), n, fp) != n) { perror(fn); exit(1); }
+  fclose(fp);
+}
+
+static int run_wall(int argc, char ** argv) {
+
+  const char * prefix = argv[2];
+  case_t c = {0};
+  int periodic[3];
+  wall_param_t wp = {0};
+  int nsteps = atoi(argv[12]);
+
+  pe_t * pe = NULL;
+  cs_t * cs = NULL;
+  physics_t * phys = NULL;
+  lb_t * lb = NULL;
+  hydro_t * hydro = NULL;
+  map_t * map = NULL;
+  noise_t * noise = NULL;
+  wall_t * wall = NULL;
+
+  c.ntotal[X] = atoi(argv[3]);
+  c.ntotal[Y] = atoi(argv[4]);
+  c.ntotal[Z] = atoi(argv[5]);
+  c.nhalo = 1;
+  c.nrelax = LB_RELAXATION_M10;
+  c.eta = 0.1;
+  c.zeta = 0.3;
+  wp.iswall = 1;
+  wp.isboundary[X] = atoi(argv[6]);
+  wp.isboundary[Y] = atoi(argv[7]);
+  wp.isboundary[Z] = atoi(argv[8]);
+  wp.ubot[Y] = atof(argv[9]);
+  wp.utop[Y] = atof(argv[10]);
+  c.solid = atoi(argv[11]);
+  for (int ia = 0; ia < 3; ia++) periodic[ia] = 1 - wp.isboundary[ia];
+
+  MPI_Init(&argc, &argv);
+  pe_create(MPI_COMM_WORLD, PE_QUIET, &pe);
+  cs_create(pe, &cs);
+  cs_ntotal_set(cs, c.ntotal);
+  cs_nhalo_set(cs, c.nhalo);
+  cs_periodicity_set(cs, periodic);
+  cs_init(cs);
+
+  physics_create(pe, &phys);
+  physics_rho0_set(phys, 1.0);
+  physics_eta_shear_set(phys, c.eta);
+  physics_eta_bulk_set(phys, c.zeta);
+
+  {
+    lb_data_options_t opts = lb_data_options_default();
+    opts.ndim = NDIM;
+    opts.nvel = NVEL;
+    opts.ndist = 1;
+    opts.nrelax = c.nrelax;
+    opts.halo = LB_HALO_TARGET;
+    lb_data_create(pe, cs, &opts, &lb);
+  }
+  {
+    hydro_options_t hopts = hydro_options_nhalo(1);
+    hydro_create(pe, cs, NULL, &hopts, &hydro);
+  }
+  map_create(pe, cs, 0, &map);
+  noise_create(pe, cs, &noise);
+  noise_init(noise, 0);
+
+  init_f(cs, lb, &c);
+  init_map(cs, map, &c);
+  wall_create(pe, cs, map, lb, &wall);
+  wall_commit(wall, &wp);
+
+  {
+    size_t nf = (size_t) lb->nsite*lb->model.nvel;
+    size_t ns = (size_t) lb->nsite;
+    int nall[3];
+    double fnet[3] = {0.0, 0.0, 0.0};
+    int * status = (int *) calloc(ns, sizeof(int));
+    char fn[1024];
+    FILE * fp = NULL;
+
+    for (size_t i = 0; i < ns; i++) {
+      int st = 0;
+      map_status(map, (int) i, &st);
+      status[i] = st;
+    }
+    dump_i32(prefix, "status", status, ns);
+    dump_i32(prefix, "linki", wall->linki, wall->nlink);
+    dump_i32(prefix, "linkj", wall->linkj, wall->nlink);
+    dump_i32(prefix, "linkp", wall->linkp, wall->nlink);
+    dump_i32(prefix, "linku", wall->linku, wall->nlink);
+    dump(prefix, "f0", lb->f, nf);
+
+    for (int n = 0; n < nsteps; n++) {
+      lb_collide(lb, hydro, map, noise, NULL, NULL);
+      lb_halo(lb);
+      wall_bbl(wall);
+      if (n == 0) dump(prefix, "f_bbl", lb->f, nf);
+      lb_propagation(lb);
+    }
+    dump(prefix, "f_final", lb->f, nf);
+    wall_momentum(wall, fnet);
+
+    cs_nall(cs, nall);
+    snprintf(fn, sizeof(fn), "%s.json", prefix);
+    fp = fopen(fn, "w");
+    fprintf(fp, "{\"nvel\": %d, \"nlocal\": [%d, %d, %d], \"nhalo\": 1,"
+	    " \"nall\": [%d, %d, %d], \"nsite\": %d, \"scheme\": 0,"
+	    " \"eta\": %.17g, \"zeta\": %.17g, \"rho0\": 1.0,"
+	    " \"fbody\": [0.0, 0.0, 0.0], \"isboundary\": [%d, %d, %d],"
+	    " \"ubot\": [0.0, %.17g, 0.0], \"utop\": [0.0, %.17g, 0.0],"
+	    " \"solid\": %d, \"nlink\": %d, \"nsteps\": %d,"
+	    " \"fnet\": [%.17g, %.17g, %.17g], \"layout\": \"soa\"}\n",
+	    NVEL, c.ntotal[X], c.ntotal[Y], c.ntotal[Z],
+	    nall[X], nall[Y], nall[Z], lb->nsite, c.eta, c.zeta,
+	    wp.isboundary[X], wp.isboundary[Y], wp.isboundary[Z],
+	    wp.ubot[Y], wp.utop[Y], c.solid, wall->nlink, nsteps,
+	    fnet[X], fnet[Y], fnet[Z]);
+    fclose(fp);
+    free(status);
+  }
+
+  wall_free(wall);
+  noise_free(noise);
+  map_free(map);
+  hydro_free(hydro);
+  lb_free(lb);
+  physics_free(phys);
+  cs_free(cs);
+  pe_free(pe);
+  MPI_Finalize();
+
+  return 0;
+}
+
+/*****************************************************************************
+ *
  *  run_io
  *
  *  "io" mode: ref_driver io <dir> nx ny nz timestep
@@ -599,6 +760,9 @@ int main(int argc, char ** argv) {
 
   if ((argc == 10 || argc == 12) && strcmp(argv[1], "fe") == 0) {
     return run_fe(argc, argv);
+  }
+  if (argc == 13 && strcmp(argv[1], "wall") == 0) {
+    return run_wall(argc, argv);
   }
   if (argc == 14 && strcmp(argv[1], "binary") == 0) {
     return run_binary(argc, argv);

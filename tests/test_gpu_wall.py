@@ -1,0 +1,147 @@
+"""Row f4 on the device: flat walls and bounce-back on links (wall.c) through
+the C-ABI against the compiled-reference fixtures and the oracle."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lb_oracle as lbo                                    # noqa: E402
+from tests.common import golden_wall_names, interior, load_golden, relmax  # noqa: E402
+
+
+def _setup(g):
+    import ludwig_amd
+    import torch
+    meta = g["meta"]
+    lb = ludwig_amd.LB(meta["nvel"], tuple(meta["nlocal"]), 1)
+    lb.relaxation_set("m10", meta["eta"], meta["zeta"])
+    st0 = np.zeros(lb.nall, dtype=np.int8)
+    if meta["solid"]:
+        st0[2:4, 2:4, 2:4] = 1
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, status=st0)
+    torch.cuda.synchronize()
+    return lb, hy, meta
+
+
+@pytest.mark.parametrize("name", golden_wall_names())
+def test_wall_map_and_links_exact(name):
+    g = load_golden(name)
+    lb, hy, meta = _setup(g)
+    lb.wall_map(meta["isboundary"], hy.status)
+    lb.synchronize()
+    assert np.array_equal(hy.status.cpu().numpy(), g["status"])
+    n = lb.wall_links_build(hy.status, meta["isboundary"])
+    assert n == meta["nlink"]
+    li, lj, lp, lu = lb.wall_links()
+    assert np.array_equal(li, g["linki"]) and np.array_equal(lj, g["linkj"])
+    assert np.array_equal(lp, g["linkp"]) and np.array_equal(lu, g["linku"])
+    lb.free()
+
+
+@pytest.mark.parametrize("name", golden_wall_names())
+def test_wall_steps_vs_reference(name):
+    g = load_golden(name)
+    lb, hy, meta = _setup(g)
+    lb.wall_map(meta["isboundary"], hy.status)
+    lb.wall_links_build(hy.status, meta["isboundary"])
+    lb.wall_velocity_set(meta["ubot"], meta["utop"])
+    lb.lb_memcpy_h2d(g["f0"])
+    nv = meta["nvel"]
+    for n in range(meta["nsteps"]):
+        lb.lb_collide(hy)
+        lb.lb_halo()
+        lb.wall_bbl()
+        if n == 0:
+            f = lb.lb_memcpy_d2h().reshape(nv, -1)
+            ref = g["f_bbl"].reshape(nv, -1)
+            q = nv - g["linkp"]
+            assert np.max(np.abs(f[q, g["linkj"]] - ref[q, g["linkj"]])) < 1e-15
+        lb.lb_propagation()
+    f = lb.lb_memcpy_d2h()
+    fl = (g["status"] == 0)[1:-1, 1:-1, 1:-1]
+    assert relmax(interior(f, 1)[:, fl], interior(g["f_final"], 1)[:, fl]) < 1e-12
+    fnet = lb.wall_momentum()
+    scale = max(1.0, np.abs(np.array(meta["fnet"])).max())
+    assert np.max(np.abs(fnet - np.array(meta["fnet"]))) < 1e-12 * scale
+    assert np.array_equal(lb.wall_momentum(), np.zeros(3))     # read zeroes it
+    lb.free()
+
+
+def test_couette_between_moving_walls():
+    """Walls at z = 0, Lz+1 moving with -/+ u_w along x: the flow relaxes to
+    the linear Couette profile u_x(z) = u_w (2 z - Lz - 1)/Lz of half-way
+    bounce-back (walls half a site outside the first/last fluid node), and
+    mass is conserved to rounding."""
+    import ludwig_amd
+    import torch
+    n = (4, 4, 16)
+    uw = 0.01
+    lb = ludwig_amd.LB(19, n, 1)
+    lb.relaxation_set("bgk", 1.0 / 6.0, 1.0 / 6.0)      # tau = 1
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, status=np.zeros(lb.nall, dtype=np.int8))
+    torch.cuda.synchronize()
+    lb.wall_map((0, 0, 1), hy.status)
+    assert lb.wall_links_build(hy.status, (0, 0, 1)) == 2 * 4 * 4 * 5
+    lb.wall_velocity_set((-uw, 0, 0), (uw, 0, 0))
+    w = ludwig_amd.model(19)["wv"]
+    f0 = np.zeros((19,) + lb.nall)
+    for p in range(19):
+        interior(f0[p], 1)[...] = w[p]
+    lb.lb_memcpy_h2d(f0)
+    for _ in range(3000):
+        lb.lb_collide(hy)
+        lb.lb_halo()
+        lb.wall_bbl()
+        lb.lb_propagation()
+    lb.lb_collide(hy)
+    lb.synchronize()
+    ux = interior(hy.u.cpu().numpy(), 1)[0].mean(axis=(0, 1))
+    z = np.arange(1, n[2] + 1)
+    exact = uw * (2.0 * z - n[2] - 1.0) / n[2]
+    assert np.max(np.abs(ux - exact)) < 2e-6
+    assert abs(lb.moments()[1] - n[0] * n[1] * n[2]) < 1e-9
+    lb.free()
+
+
+def test_wall_needs_eager_and_links():
+    import ludwig_amd
+    lb = ludwig_amd.LB(19, (4, 4, 4), 1, mode=ludwig_amd.FUSED)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, status=np.zeros(lb.nall, dtype=np.int8))
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.wall_bbl()                                  # no links yet
+    lb.wall_map((1, 0, 0), hy.status)
+    lb.wall_links_build(hy.status, (1, 0, 0))
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.wall_bbl()                                  # FUSED: no such state
+    lb.free()
+
+
+def test_wall_with_two_distributions():
+    """ndist = 2: the order-parameter distribution bounces back on the same
+    links (wall.c:1081-1088)."""
+    import ludwig_amd
+    import torch
+    n = (6, 5, 4)
+    lb = ludwig_amd.LB(19, n, 1, ndist=2)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, status=np.zeros(lb.nall, dtype=np.int8))
+    torch.cuda.synchronize()
+    lb.wall_map((1, 0, 0), hy.status)
+    lb.wall_links_build(hy.status, (1, 0, 0))
+    lb.wall_velocity_set((0, 0.01, 0), (0, -0.02, 0))
+    rng = np.random.default_rng(2)
+    f0 = rng.random((38,) + lb.nall)
+    lb.lb_memcpy_h2d(f0)
+    lb.wall_bbl()
+    f = lb.lb_memcpy_d2h().reshape(2, 19, -1)
+    li, lj, lp, lu = lb.wall_links()
+    m = ludwig_amd.model(19)
+    uw = np.array([[0, 0, 0], [0, -0.02, 0], [0, 0.01, 0]])
+    ref = f0.reshape(2, 19, -1).copy()
+    for k in range(len(li)):
+        cdotu = float(m["cv"][lp[k]] @ uw[lu[k]])
+        for d in range(2):
+            ref[d, 19 - lp[k], lj[k]] = f0.reshape(2, 19, -1)[d, lp[k], li[k]] \
+                - 2.0 * 3.0 * m["wv"][lp[k]] * 1.0 * cdotu
+    assert np.max(np.abs(f - ref)) < 1e-15
+    lb.free()
