@@ -422,17 +422,25 @@ int lbmi_stream(lbmi_t * lb, void ** stream);
  * Ludwig's default-stream kernels, or a torch stream). The handle does not
  * own the stream. Pending work on the previous stream is drained first. */
 int lbmi_set_stream(lbmi_t * lb, void * stream);
-/* Average device time (ms) of the fused kernel launches since the last
- * call, measured with hipEvents on the compute stream (bench.py roofline);
- * enable with lbmi_timing(lb, 1). */
+/* Device time (ms) of the step's kernel launches since the last call,
+ * measured with hipEvents on the compute stream (bench.py roofline).
+ * lbmi_timing(lb, k): k = 0 off, 1 every launch, k > 1 every k-th launch (an
+ * event record costs the stream a few microseconds between two kernels, so
+ * a timed production loop samples). lbmi_timing_read returns the summed
+ * time and the number of launches that were timed. */
 int lbmi_timing(lbmi_t * lb, int on);
 int lbmi_timing_read(lbmi_t * lb, double * ms_total, int * nlaunch);
 
-/* Launch tuning of the fused kernel; results do not depend on it.
- * "xcd_group": blocks per XCD interleave group (0 = one chunk per XCD);
- * "lds_cap": dynamic LDS bytes per block, caps resident blocks per CU;
- * "x_packed": 1 = RCCL X exchange through packed staging buffers (one
- * message per direction) instead of the default zero-copy plane sends. */
+/* Launch tuning of the fused step; results do not depend on it.
+ * "xcd_group": blocks per XCD interleave group (0 = one chunk per XCD; 16);
+ * "lds_cap": dynamic LDS bytes per block, caps resident blocks per CU (65536);
+ * "blocked": 1 = on one GPU keep the deferred FUSED state in the blocked
+ *            order [site/256][p][site%256] (default 1), 0 = SoA throughout;
+ * "x_packed": 1 = RCCL X exchange through packed staging buffers, one message
+ *            per direction (default), 0 = zero-copy sends of the planes;
+ * "x_concurrent": 1 = slabs: the two boundary planes run on a third stream
+ *            beside the interior launch once the halo has arrived (default),
+ *            0 = after it on the compute stream. */
 int lbmi_tune(lbmi_t * lb, const char * key, int value);
 
 /* ---- multi-GPU: 1-d slab decomposition along X over RCCL ---------------- */

@@ -43,6 +43,9 @@ struct lbmi_s {
   hipStream_t stream;                /* compute (own_stream, or the caller's) */
   hipStream_t own_stream;
   hipStream_t comm_stream;           /* halo exchange (multi-GPU overlap) */
+  hipStream_t bnd_stream;            /* boundary planes of a slab (FUSED) */
+  hipEvent_t ev_bnd;                 /* boundary planes of fprime written */
+  int x_concurrent;                  /* 1: boundary planes beside the interior */
   hipEvent_t ev_ready;               /* boundary planes of f written */
   hipEvent_t ev_halo;                /* x halo planes of f filled */
 
@@ -86,7 +89,9 @@ struct lbmi_s {
   double rho0;
 
   /* kernel timing */
-  int timing;
+  int timing;                        /* 0 off, k: every k-th launch */
+  int timing_count;
+  int timing_now;
   int nev;
   hipEvent_t ev0[LBMI_NEVENT];
   hipEvent_t ev1[LBMI_NEVENT];
@@ -317,6 +322,7 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   lb->kp.xcd_group = 16;
   lb->kp.lds_cap = 65536;
   lb->x_packed = 1;
+  lb->x_concurrent = 1;
   lb->use_blocked = 1;               /* profiles/r01_blocked_order.txt */
   lb->grad_npt = 7;
   lb->adv_order = 1;
@@ -327,6 +333,8 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   /* lbmi_free() releases whatever exists so far (members start as NULL) */
   if (hipStreamCreateWithFlags(&lb->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&lb->comm_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&lb->bnd_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&lb->ev_bnd, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&lb->ev_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&lb->ev_halo, hipEventDisableTiming) != hipSuccess) {
     lbmi_free(lb);
@@ -361,6 +369,7 @@ int lbmi_free(lbmi_t * lb) {
   hipSetDevice(lb->device);
   if (lb->own_stream) hipStreamSynchronize(lb->stream);
   if (lb->comm_stream) hipStreamSynchronize(lb->comm_stream);
+  if (lb->bnd_stream) hipStreamSynchronize(lb->bnd_stream);
 
   lbmi_comm_free(lb);
 
@@ -380,6 +389,8 @@ int lbmi_free(lbmi_t * lb) {
   if (lb->ev_ready) hipEventDestroy(lb->ev_ready);
   if (lb->ev_halo) hipEventDestroy(lb->ev_halo);
   if (lb->comm_stream) hipStreamDestroy(lb->comm_stream);
+  if (lb->ev_bnd) hipEventDestroy(lb->ev_bnd);
+  if (lb->bnd_stream) hipStreamDestroy(lb->bnd_stream);
   if (lb->own_stream) hipStreamDestroy(lb->own_stream);
   free(lb);
 
@@ -494,7 +505,12 @@ static lbmi_hydro_dev_t lbmi_hydro_dev(const lbmi_hydro_t * hydro) {
 /* Event-pair timing of a kernel launch on the compute stream */
 
 static int lbmi_time_begin(lbmi_t * lb) {
+  lb->timing_now = 0;
   if (!lb->timing) return 0;
+  /* every timing-th launch: an event record costs the stream a few
+   * microseconds between kernels */
+  if ((lb->timing_count++ % lb->timing) != 0) return 0;
+  lb->timing_now = 1;
   if (!lb->ev_created) {
     lb->ev_created = 1;               /* lbmi_free destroys the non-NULL ones */
     for (int n = 0; n < LBMI_NEVENT; n++) {
@@ -513,7 +529,8 @@ static int lbmi_time_begin(lbmi_t * lb) {
 }
 
 static int lbmi_time_end(lbmi_t * lb) {
-  if (!lb->timing) return 0;
+  if (!lb->timing_now) return 0;
+  lb->timing_now = 0;
   HIPCHECK(hipEventRecord(lb->ev1[lb->nev], lb->stream));
   lb->nev += 1;
   return 0;
@@ -521,7 +538,9 @@ static int lbmi_time_end(lbmi_t * lb) {
 
 int lbmi_timing(lbmi_t * lb, int on) {
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
-  lb->timing = (on != 0);
+  lb->timing = (on > 0) ? on : 0;
+  lb->timing_count = 0;
+  lb->timing_now = 0;
   lb->nev = 0;
   lb->ms_accum = 0.0;
   lb->launches_accum = 0;
@@ -559,6 +578,10 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
   }
   if (strcmp(key, "x_packed") == 0) {
     lb->x_packed = (value != 0);
+    return 0;
+  }
+  if (strcmp(key, "x_concurrent") == 0) {
+    lb->x_concurrent = (value != 0);
     return 0;
   }
   if (strcmp(key, "blocked") == 0) {
@@ -948,11 +971,28 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
     if (ifail) return ifail;
     HIPCHECK(hipEventRecord(lb->ev_halo, lb->comm_stream));
 
-    /* both boundary planes in one launch, after the halo has arrived */
-    HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_halo, 0));
-    KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				    0, xlo, xlo, xhi, (xhi > xlo) ? xhi : xhi - 1,
-				    lb->stream));
+    if (lb->x_concurrent) {
+      /* The two boundary planes depend on the state of the previous step
+       * (complete at ev_ready) and on the halo, not on the interior launch
+       * of THIS step (they write other planes of fprime): run them on a
+       * third stream beside it, so that a step costs the interior kernel,
+       * not interior + boundary + two stream hand-overs. The compute stream
+       * joins at the end: whatever follows sees the whole of fprime. */
+      HIPCHECK(hipStreamWaitEvent(lb->bnd_stream, lb->ev_ready, 0));
+      HIPCHECK(hipStreamWaitEvent(lb->bnd_stream, lb->ev_halo, 0));
+      KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
+				      0, xlo, xlo, xhi, (xhi > xlo) ? xhi : xhi - 1,
+				      lb->bnd_stream));
+      HIPCHECK(hipEventRecord(lb->ev_bnd, lb->bnd_stream));
+      HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_bnd, 0));
+    }
+    else {
+      /* both boundary planes in one launch, after the halo has arrived */
+      HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_halo, 0));
+      KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
+				      0, xlo, xlo, xhi, (xhi > xlo) ? xhi : xhi - 1,
+				      lb->stream));
+    }
   }
 
   ifail = lbmi_time_end(lb);
@@ -1906,6 +1946,7 @@ int lbmi_synchronize(lbmi_t * lb) {
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   HIPCHECK(hipSetDevice(lb->device));
   HIPCHECK(hipStreamSynchronize(lb->comm_stream));
+  HIPCHECK(hipStreamSynchronize(lb->bnd_stream));
   HIPCHECK(hipStreamSynchronize(lb->stream));
   return 0;
 }

@@ -418,7 +418,8 @@ class LB:
         _l.check(self._lib.lbmi_tune(self._h, key.encode(), int(value)))
 
     def timing(self, on=True):
-        _l.check(self._lib.lbmi_timing(self._h, 1 if on else 0))
+        """on: False/0 off, True/1 every launch, k every k-th launch."""
+        _l.check(self._lib.lbmi_timing(self._h, int(on)))
 
     def timing_read(self):
         ms = ctypes.c_double()
