@@ -337,7 +337,7 @@ def main():
             # passes): quote the committed measurement of the same kernel
             # on the same workload, if this run is that workload
             pmc = os.path.join(ROOT, "profiles",
-                               "r01_blocked_pmc_hbm_traffic.json"
+                               "r01_default_pmc_hbm_traffic.json"
                                if order.startswith("blocked")
                                else "r01_pmc_hbm_traffic.json")
             same = (args.nvel == 19 and tuple(args.size) == (256, 256, 256)

@@ -432,10 +432,12 @@ int lbmi_timing(lbmi_t * lb, int on);
 int lbmi_timing_read(lbmi_t * lb, double * ms_total, int * nlaunch);
 
 /* Launch tuning of the fused step; results do not depend on it.
- * "xcd_group": blocks per XCD interleave group (0 = one chunk per XCD; 16);
+ * "xcd_group": blocks per XCD interleave group (0 = one chunk per XCD; 32);
  * "lds_cap": dynamic LDS bytes per block, caps resident blocks per CU (65536);
  * "blocked": 1 = on one GPU keep the deferred FUSED state in the blocked
  *            order [site/256][p][site%256] (default 1), 0 = SoA throughout;
+ * "nt_store": bit 0 = nontemporal stores of the blocked deferred state
+ *            (default 1), bit 1 = of hydro->rho, u (default 0);
  * "x_packed": 1 = RCCL X exchange through packed staging buffers, one message
  *            per direction (default), 0 = zero-copy sends of the planes;
  * "x_concurrent": 1 = slabs: the two boundary planes run on a third stream

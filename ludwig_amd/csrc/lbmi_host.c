@@ -319,11 +319,12 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
    * are resident per CU: with more waves in flight the streamed lines of
    * the 2 x nvel arrays overflow the 4 MiB L2 of an XCD before the
    * neighbouring wave has used its share of them. */
-  lb->kp.xcd_group = 16;
+  lb->kp.xcd_group = 32;
   lb->kp.lds_cap = 65536;
   lb->x_packed = 1;
   lb->x_concurrent = 1;
   lb->use_blocked = 1;               /* profiles/r01_blocked_order.txt */
+  lb->kp.nt_store = 1;               /* idem: nontemporal stores, blocked order */
   lb->grad_npt = 7;
   lb->adv_order = 1;
 
@@ -578,6 +579,10 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
   }
   if (strcmp(key, "x_packed") == 0) {
     lb->x_packed = (value != 0);
+    return 0;
+  }
+  if (strcmp(key, "nt_store") == 0) {
+    lb->kp.nt_store = value & 3;      /* bit 0: f, bit 1: rho and u */
     return 0;
   }
   if (strcmp(key, "x_concurrent") == 0) {

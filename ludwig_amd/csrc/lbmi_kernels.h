@@ -37,6 +37,7 @@ typedef struct lbmi_kparam_s {
   /* launch tuning of the fused kernel (lbmi_tune) */
   int xcd_group;           /* blocks per XCD interleave group; 0: chunked */
   int lds_cap;             /* dynamic LDS bytes per block: occupancy cap */
+  int nt_store;            /* blocked order: nontemporal stores of f */
 } lbmi_kparam_t;
 
 typedef struct lbmi_hydro_dev_s {

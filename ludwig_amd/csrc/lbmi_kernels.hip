@@ -626,7 +626,7 @@ void pc_pull(const lbmi_kparam_t & kp, const double * __restrict__ f,
 }
 
 /* phase 2: collide (interior fluid sites) and store site i */
-template <int NVEL, int SCHEME, bool WB>
+template <int NVEL, int SCHEME, bool WB, bool NTS>
 __device__ __forceinline__
 void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
 		      const lbmi_hydro_dev_t & h, int i,
@@ -649,20 +649,37 @@ void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
     Relax rx = {kp.rtau_shear, kp.rtau_bulk, kp.rtau_even, kp.rtau_odd};
     double rho, u[3];
     collide_site<NVEL, SCHEME>(ps.fl, frc, rx, rho, u);
-    if (h.rho) h.rho[i] = rho;
-    if (h.u) {
-      h.u[i] = u[0];
-      h.u[ns + i] = u[1];
-      h.u[2*ns + i] = u[2];
+    if (kp.nt_store & 2) {
+      /* rho and u are written once and not read again by this kernel */
+      if (h.rho) __builtin_nontemporal_store(rho, &h.rho[i]);
+      if (h.u) {
+	__builtin_nontemporal_store(u[0], &h.u[i]);
+	__builtin_nontemporal_store(u[1], &h.u[ns + i]);
+	__builtin_nontemporal_store(u[2], &h.u[2*ns + i]);
+      }
+    }
+    else {
+      if (h.rho) h.rho[i] = rho;
+      if (h.u) {
+	h.u[i] = u[0];
+	h.u[ns + i] = u[1];
+	h.u[2*ns + i] = u[2];
+      }
     }
   }
 
   static_for<0, NVEL>([&](auto P) {
-    stf(&fp[faddr<NVEL, WB>(ns, P, i)], ps.fl[P]);
+    if constexpr (NTS) {
+      __builtin_nontemporal_store(ps.fl[P], &fp[faddr<NVEL, WB>(ns, P, i)]);
+    }
+    else {
+      stf(&fp[faddr<NVEL, WB>(ns, P, i)], ps.fl[P]);
+    }
   });
 }
 
-/* LAY: 0 SoA -> SoA, 1 SoA -> blocked, 2 blocked -> blocked */
+/* LAY & 3: 0 SoA -> SoA, 1 SoA -> blocked, 2 blocked -> blocked;
+ * LAY & 4: nontemporal stores of fprime */
 
 template <int NVEL, int SCHEME, bool WRAP, int LAY>
 __global__ __launch_bounds__(BLOCK, LBMI_WAVES)
@@ -689,19 +706,20 @@ void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
   /* blocks start at multiples of LBMI_ALIGN sites so that every store of a
    * wave covers whole 64-byte sectors of every population array (nsite*8
    * is a multiple of 64 for the sizes of interest); lanes before i0 idle */
-  constexpr int ALIGNV = (LAY == 0) ? LBMI_ALIGN : LBW;
+  constexpr int ORD = LAY & 3;
+  constexpr int ALIGNV = (ORD == 0) ? LBMI_ALIGN : LBW;
   const int i0a = (i0/ALIGNV)*ALIGNV;
   static_for<0, SPT>([&](auto K) {
     constexpr int k = K;
     i[k] = i0a + (int) (lb*(BLOCK*SPT) + k*BLOCK + threadIdx.x);
     if (i[k] >= i0 && i[k] < i1) {
-      pc_pull<NVEL, WRAP, LAY == 2>(kp, f, wrapmask, i[k], ps[k]);
+      pc_pull<NVEL, WRAP, ORD == 2>(kp, f, wrapmask, i[k], ps[k]);
     }
   });
   static_for<0, SPT>([&](auto K) {
     constexpr int k = K;
     if (i[k] >= i0 && i[k] < i1) {
-      pc_collide_store<NVEL, SCHEME, LAY != 0>(kp, fp, h, i[k], ps[k]);
+      pc_collide_store<NVEL, SCHEME, ORD != 0, (LAY & 4) != 0>(kp, fp, h, i[k], ps[k]);
     }
   });
 }
@@ -1813,8 +1831,8 @@ template <int NVEL, bool WRAP, int LAY>
 int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
 	      const lbmi_hydro_dev_t & h, int wrapmask, int i0, int i1,
 	      int j0, int j1, hipStream_t st) {
-  constexpr int ALIGNV = (LAY == 0) ? LBMI_ALIGN : LBW;
-  static_assert(LAY == 0 || BLOCK*SPT == LBW, "blocked order: one thread block per layout block");
+  constexpr int ALIGNV = ((LAY & 3) == 0) ? LBMI_ALIGN : LBW;
+  static_assert((LAY & 3) == 0 || BLOCK*SPT == LBW, "blocked order: one thread block per layout block");
   const int i0a = (i0/ALIGNV)*ALIGNV;
   const int j0a = (j0/ALIGNV)*ALIGNV;
   unsigned nblk_first = (unsigned) ((i1 - i0a + BLOCK*SPT - 1)/(BLOCK*SPT));
@@ -1876,6 +1894,10 @@ int launch_pc_any(const lbmi_kparam_t & kp, const double * f, double * fp,
   }
   if (lay == 0) return launch_pc<NVEL, true, 0>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
 #if LBMI_BLOCK*LBMI_SPT == 256
+  if (kp.nt_store & 1) {
+    if (lay == 1) return launch_pc<NVEL, true, 5>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
+    if (lay == 2) return launch_pc<NVEL, true, 6>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
+  }
   if (lay == 1) return launch_pc<NVEL, true, 1>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
   if (lay == 2) return launch_pc<NVEL, true, 2>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
 #endif

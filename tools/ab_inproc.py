@@ -31,7 +31,12 @@ def main():
              "inplace": ludwig_amd.INPLACE}
     lbs = []
     for nm in names:
-        lb = ludwig_amd.LB(args.nvel, tuple(args.size), 1, mode=modes[nm])
+        # "fused+key=value+..." applies lbmi_tune settings to that handle
+        base, *tunes = nm.split("+")
+        lb = ludwig_amd.LB(args.nvel, tuple(args.size), 1, mode=modes[base])
+        for kv in tunes:
+            k, v = kv.split("=")
+            lb.tune(k, int(v))
         lb.relaxation_set("m10", 0.1, 0.3)
         m = ludwig_amd.model(args.nvel)
         synthetic.fill_device(lb, m["cv"], m["wv"], tuple(args.size))
