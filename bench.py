@@ -285,8 +285,13 @@ def main():
     torch.cuda.synchronize()
     lb.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    if fe is None:
+        # the three calls of every step issued by the C loop of the library
+        # (lbmi_lb_run), as ludwig.c issues them, not one by one from Python
+        lb.run(hydro, args.steps)
+    else:
+        for _ in range(args.steps):
+            one_step()
     lb.synchronize()
     torch.cuda.synchronize()
     barrier()

@@ -222,6 +222,10 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro);  /* lb_collide */
 int lbmi_lb_halo(lbmi_t * lb);                                 /* lb_halo    */
 int lbmi_lb_propagation(lbmi_t * lb);                          /* lb_propagation */
 int lbmi_lb_flush(lbmi_t * lb);
+/* nsteps x (lbmi_lb_collide, lbmi_lb_halo, lbmi_lb_propagation): the LB part
+ * of the reference's main loop for callers that have nothing to do in
+ * between (a host language with expensive foreign calls, a benchmark). */
+int lbmi_lb_run(lbmi_t * lb, const lbmi_hydro_t * hydro, int nsteps);
 
 /* ndist = 2, free_energy symmetric_lb (LBMI_MODE_EAGER, one rank): the
  * second distribution carries the order parameter. f holds both,
@@ -436,8 +440,9 @@ int lbmi_timing_read(lbmi_t * lb, double * ms_total, int * nlaunch);
  * "lds_cap": dynamic LDS bytes per block, caps resident blocks per CU (65536);
  * "blocked": 1 = on one GPU keep the deferred FUSED state in the blocked
  *            order [site/256][p][site%256] (default 1), 0 = SoA throughout;
- * "nt_store": bit 0 = nontemporal stores of the blocked deferred state
- *            (default 1), bit 1 = of hydro->rho, u (default 0);
+ * "nt_store": bit 0 = nontemporal stores of the blocked deferred state, bit 1
+ *            = of hydro->rho, u; -1 (default) = bit 0 exactly when f and
+ *            fprime together exceed the 256 MiB Infinity Cache;
  * "x_packed": 1 = RCCL X exchange through packed staging buffers, one message
  *            per direction (default), 0 = zero-copy sends of the planes;
  * "x_concurrent": 1 = slabs: the two boundary planes run on a third stream

@@ -198,6 +198,12 @@ class LB:
         self.lb_halo()
         self.lb_propagation()
 
+    def run(self, hydro=None, nsteps=1):
+        """nsteps x (lb_collide, lb_halo, lb_propagation) in one foreign call."""
+        h = hydro.ptrs() if hydro is not None else None
+        _l.check(self._lib.lbmi_lb_run(
+            self._h, ctypes.byref(h) if h is not None else None, int(nsteps)))
+
     def moments(self, status=None):
         """Volume, sum rho, sum rho^2, min, max, g_x, g_y, g_z, 0 (interior,
         fluid sites; this rank)."""

@@ -84,6 +84,7 @@ SYMBOLS = [
     ("lbmi_lb_halo", _i, [_vp]),
     ("lbmi_lb_propagation", _i, [_vp]),
     ("lbmi_lb_flush", _i, [_vp]),
+    ("lbmi_lb_run", _i, [_vp, ctypes.POINTER(HydroPtrs), _i]),
     ("lbmi_lb_state", _i, [_vp, ctypes.POINTER(_i)]),
     ("lbmi_wall_map", _i, [_vp, ctypes.POINTER(_i), _vp]),
     ("lbmi_wall_links_build", _i, [_vp, _vp, ctypes.POINTER(_i),

@@ -168,3 +168,48 @@ def test_hydro_field_set():
     assert np.all(un[0] == 0.5) and np.all(un[1] == -1.5) and np.all(un[2] == 2.5)
     assert np.all(rho.cpu().numpy() == 1.0)
     lb.free()
+
+
+def test_lb_run_equals_steps():
+    """lbmi_lb_run(n) = n x (collide, halo, propagation), every mode."""
+    import ludwig_amd
+    from oracle import lb_oracle as lbo
+    nlocal = (20, 12, 16)
+    p = lbo.make_param(19, nlocal, 1, "m10", 0.1, 0.3)
+    f0 = lbo.init_synthetic(p)
+    for mode in (ludwig_amd.EAGER, ludwig_amd.FUSED, ludwig_amd.INPLACE):
+        out = []
+        for use_run in (False, True):
+            lb = ludwig_amd.LB(19, nlocal, 1, mode=mode)
+            lb.relaxation_set("m10", 0.1, 0.3)
+            hy = ludwig_amd.Hydro(lb.nall, lb.device)
+            lb.lb_memcpy_h2d(f0)
+            if use_run:
+                lb.run(hy, 5)
+            else:
+                for _ in range(5):
+                    lb.step(hy)
+            out.append(lb.lb_memcpy_d2h()[:, 1:-1, 1:-1, 1:-1].copy())
+            lb.free()
+        assert np.array_equal(out[0], out[1])
+
+
+def test_nt_store_auto_and_explicit_agree():
+    import ludwig_amd
+    from oracle import lb_oracle as lbo
+    nlocal = (24, 10, 18)
+    p = lbo.make_param(19, nlocal, 1, "bgk", 0.1, 0.1)
+    f0 = lbo.init_synthetic(p)
+    out = []
+    for nt in (-1, 0, 1, 3):
+        lb = ludwig_amd.LB(19, nlocal, 1, mode=ludwig_amd.FUSED)
+        lb.tune("nt_store", nt)
+        lb.relaxation_set("bgk", 0.1, 0.1)
+        hy = ludwig_amd.Hydro(lb.nall, lb.device)
+        lb.lb_memcpy_h2d(f0)
+        lb.run(hy, 4)
+        out.append((lb.lb_memcpy_d2h()[:, 1:-1, 1:-1, 1:-1].copy(),
+                    hy.u.cpu().numpy()))
+        lb.free()
+    for o in out[1:]:
+        assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
