@@ -325,6 +325,7 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   lb->x_packed = 1;
   lb->x_concurrent = 1;
   lb->use_blocked = 1;               /* profiles/r01_blocked_order.txt */
+  lb->kp.fe_tiled = 1;
   lb->nt_store_mode = -1;            /* idem: nontemporal stores when f, fprime
 					exceed the Infinity Cache */
   lb->grad_npt = 7;
@@ -585,6 +586,10 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
   }
   if (strcmp(key, "nt_store") == 0) {
     lb->nt_store_mode = (value < 0) ? -1 : (value & 3);   /* bit 0: f, bit 1: rho, u */
+    return 0;
+  }
+  if (strcmp(key, "fe_tiled") == 0) {
+    lb->kp.fe_tiled = (value != 0);
     return 0;
   }
   if (strcmp(key, "x_concurrent") == 0) {

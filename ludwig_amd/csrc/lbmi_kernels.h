@@ -38,6 +38,7 @@ typedef struct lbmi_kparam_s {
   int xcd_group;           /* blocks per XCD interleave group; 0: chunked */
   int lds_cap;             /* dynamic LDS bytes per block: occupancy cap */
   int nt_store;            /* blocked order: nontemporal stores of f */
+  int fe_tiled;            /* free-energy pass: phi through an LDS tile */
 } lbmi_kparam_t;
 
 typedef struct lbmi_hydro_dev_s {

@@ -1412,39 +1412,35 @@ void k_cahn_hilliard(lbmi_kparam_t kp, Symm q, double mobility, int order,
  * does not depend on u and the update of phi does not depend on the force,
  * so the two results are exactly those of the separate kernels. */
 
-template <bool ACCUMULATE, int NPT>
-__global__ __launch_bounds__(BLOCK)
-void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility, int order,
-		    const double * __restrict__ phi,
-		    const double * __restrict__ grad,
-		    const double * __restrict__ delsq,
-		    const double * __restrict__ u,
-		    double * __restrict__ force,
-		    double * __restrict__ phi_out, int i0, int i1,
-		    unsigned nblk) {
+/* One site of the fused pass. phi may be the global array (ip = i, strides
+ * of the lattice) or an LDS tile (ip = index in the tile, its strides);
+ * grad, delsq (NPT = 0 only), u, force, phi_out are global, indexed by i. */
 
-  unsigned lb;
-  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
-  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
-  if (i < i0 || i >= i1) return;
-  Site s = decode(kp, i);
-  if (!s.interior) return;
+template <bool ACCUMULATE, int NPT>
+__device__ __forceinline__
+void fe_step_site(const lbmi_kparam_t & kp, const Symm & q, double mobility,
+		  int order, const double * __restrict__ phi, int ip, int psx,
+		  int psy, const double * __restrict__ grad,
+		  const double * __restrict__ delsq,
+		  const double * __restrict__ u, double * __restrict__ force,
+		  double * __restrict__ phi_out, int i) {
 
   const size_t ns = (size_t) kp.nsite;
   const int str[3] = {kp.strx, kp.stry, 1};
+  const int pstr[3] = {psx, psy, 1};
 
   /* stress and chemical potential at a site: from phi alone (NPT = 7, 27)
    * or from the gradient arrays (NPT = 0) */
-  auto at = [&](size_t j, double (&st)[3][3], double & mu, double & ph) {
+  auto at = [&](int jp, size_t j, double (&st)[3][3], double & mu, double & ph) {
     double g[3], d2;
     if constexpr (NPT == 0) {
       g[0] = grad[j]; g[1] = grad[ns + j]; g[2] = grad[2*ns + j];
       d2 = delsq[j];
     }
     else {
-      grad_at<NPT>(phi, j, kp.strx, kp.stry, g, d2);
+      grad_at<NPT>(phi, (size_t) jp, psx, psy, g, d2);
     }
-    ph = phi[j];
+    ph = phi[jp];
     symm_stress(q, ph, g, d2, st);
     mu = q.a*ph + q.b*ph*ph*ph - q.kappa*d2;
   };
@@ -1453,20 +1449,20 @@ void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility, int order,
   double mu0, mu1, phi0, phi1;
   double f[3] = {0.0, 0.0, 0.0};
   double fhi[3], flo[3];
-  at((size_t) i, pth0, mu0, phi0);
+  at(ip, (size_t) i, pth0, mu0, phi0);
 
   static_for<0, 3>([&](auto D) {
     constexpr int id = D;
     const double ud0 = u[ns*id + i];
     double pm2 = 0.0, pp2 = 0.0;
     if (order > 2) {
-      pm2 = phi[i - 2*str[id]];
-      pp2 = phi[i + 2*str[id]];
+      pm2 = phi[ip - 2*pstr[id]];
+      pp2 = phi[ip + 2*pstr[id]];
     }
-    const double pm1 = phi[i - str[id]], pp1 = phi[i + str[id]];
+    const double pm1 = phi[ip - pstr[id]], pp1 = phi[ip + pstr[id]];
     {
       size_t j = (size_t) (i + str[id]);
-      at(j, pth1, mu1, phi1);
+      at(ip + pstr[id], j, pth1, mu1, phi1);
       for (int ia = 0; ia < 3; ia++) f[ia] -= 0.5*(pth1[ia][id] + pth0[ia][id]);
       double uf = 0.5*(ud0 + u[ns*id + j]);
       double fl = adv_flux(order, false, uf, pm1, phi0, pp1, pp2);
@@ -1475,7 +1471,7 @@ void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility, int order,
     }
     {
       size_t j = (size_t) (i - str[id]);
-      at(j, pth1, mu1, phi1);
+      at(ip - pstr[id], j, pth1, mu1, phi1);
       for (int ia = 0; ia < 3; ia++) f[ia] += 0.5*(pth1[ia][id] + pth0[ia][id]);
       double uf = 0.5*(ud0 + u[ns*id + j]);
       double fl = adv_flux(order, id == 0, uf, pm2, pm1, phi0, pp1);
@@ -1500,6 +1496,84 @@ void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility, int order,
   const double wz = (kp.nlocal[2] == 1) ? 0.0 : 1.0;
   phi_out[i] = phi0 - (+ fhi[0] - flo[0] + fhi[1] - flo[1]
 		       + wz*fhi[2] - wz*flo[2]);
+}
+
+template <bool ACCUMULATE, int NPT>
+__global__ __launch_bounds__(BLOCK)
+void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility, int order,
+		    const double * __restrict__ phi,
+		    const double * __restrict__ grad,
+		    const double * __restrict__ delsq,
+		    const double * __restrict__ u,
+		    double * __restrict__ force,
+		    double * __restrict__ phi_out, int i0, int i1,
+		    unsigned nblk) {
+
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+  Site s = decode(kp, i);
+  if (!s.interior) return;
+
+  fe_step_site<ACCUMULATE, NPT>(kp, q, mobility, order, phi, i, kp.strx,
+				kp.stry, grad, delsq, u, force, phi_out, i);
+}
+
+/* The same pass with phi staged through LDS: a block of 256 threads owns a
+ * tile of FT_X x FT_Y x FT_Z sites, loads phi for the tile and the two
+ * layers around it once (the stencil of the pass: gradients at the site and
+ * its six neighbours, advection up to two sites away), and every thread
+ * then works FT_X sites from the tile. The 49 (7-point) phi reads per site
+ * become LDS reads; HBM and L2 see phi ~3.4 times per site instead of being
+ * asked 25 distinct addresses per site. u, force and phi_out stay global. */
+
+enum {FT_X = 4, FT_Y = 8, FT_Z = 32, FT_H = 2,
+      FT_LX = FT_X + 2*FT_H, FT_LY = FT_Y + 2*FT_H, FT_LZ = FT_Z + 2*FT_H};
+
+template <bool ACCUMULATE, int NPT>
+__global__ __launch_bounds__(FT_Y*FT_Z)
+void k_symm_fe_step_tiled(lbmi_kparam_t kp, Symm q, double mobility, int order,
+			  const double * __restrict__ phi,
+			  const double * __restrict__ u,
+			  double * __restrict__ force,
+			  double * __restrict__ phi_out, int nty, int ntz,
+			  unsigned nblk) {
+
+  __shared__ double tile[FT_LX*FT_LY*FT_LZ];
+
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  const int bz = (int) (lb % (unsigned) ntz);
+  const int by = (int) ((lb / (unsigned) ntz) % (unsigned) nty);
+  const int bx = (int) (lb / (unsigned) (ntz*nty));
+  const int nh = kp.nhalo;
+  const int x0 = nh + bx*FT_X, y0 = nh + by*FT_Y, z0 = nh + bz*FT_Z;
+
+  for (int l = (int) threadIdx.x; l < FT_LX*FT_LY*FT_LZ; l += FT_Y*FT_Z) {
+    const int lz = l % FT_LZ, ly = (l / FT_LZ) % FT_LY, lx = l / (FT_LZ*FT_LY);
+    const int gx = x0 - FT_H + lx, gy = y0 - FT_H + ly, gz = z0 - FT_H + lz;
+    double v = 0.0;
+    if (gx < kp.nall[0] && gy < kp.nall[1] && gz < kp.nall[2]) {
+      v = phi[(size_t) gx*kp.strx + (size_t) gy*kp.stry + gz];
+    }
+    tile[l] = v;
+  }
+  __syncthreads();
+
+  const int tz = (int) threadIdx.x % FT_Z, ty = (int) threadIdx.x / FT_Z;
+  const int gy = y0 + ty, gz = z0 + tz;
+  if (gy >= nh + kp.nlocal[1] || gz >= nh + kp.nlocal[2]) return;
+
+  for (int tx = 0; tx < FT_X; tx++) {
+    const int gx = x0 + tx;
+    if (gx >= nh + kp.nlocal[0]) break;
+    const int i = gx*kp.strx + gy*kp.stry + gz;
+    const int ip = ((tx + FT_H)*FT_LY + (ty + FT_H))*FT_LZ + (tz + FT_H);
+    fe_step_site<ACCUMULATE, NPT>(kp, q, mobility, order, tile, ip,
+				  FT_LY*FT_LZ, FT_LZ, nullptr, nullptr, u,
+				  force, phi_out, i);
+  }
 }
 
 /* ---- two distributions: the symmetric_lb step (row f4) ------------------------
@@ -2359,6 +2433,25 @@ static void launch_fe_step(const lbmi_kparam_t * kp, int npt, int order,
 			   const double * grad, const double * delsq,
 			   const double * u, double * force, double * phi_out,
 			   hipStream_t st) {
+  if (npt != 0 && kp->fe_tiled) {
+    /* phi through an LDS tile */
+    const int ntx = (kp->nlocal[0] + FT_X - 1)/FT_X;
+    const int nty = (kp->nlocal[1] + FT_Y - 1)/FT_Y;
+    const int ntz = (kp->nlocal[2] + FT_Z - 1)/FT_Z;
+    const unsigned nblk = (unsigned) ntx*(unsigned) nty*(unsigned) ntz;
+    dim3 tgrid(grid_for(nblk, (unsigned) kp->xcd_group)), tblock(FT_Y*FT_Z);
+    if (npt == 27) {
+      hipLaunchKernelGGL((k_symm_fe_step_tiled<ACCUMULATE, 27>), tgrid, tblock,
+			 0, st, *kp, q, mobility, order, phi, u, force, phi_out,
+			 nty, ntz, nblk);
+    }
+    else {
+      hipLaunchKernelGGL((k_symm_fe_step_tiled<ACCUMULATE, 7>), tgrid, tblock,
+			 0, st, *kp, q, mobility, order, phi, u, force, phi_out,
+			 nty, ntz, nblk);
+    }
+    return;
+  }
   Range1D r = interior_range(*kp);
   dim3 grid(r.grid), block(BLOCK);
   if (npt == 0) {
