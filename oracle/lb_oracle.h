@@ -8,9 +8,11 @@
  *
  * Parity status: PINNED. Checked against golden vectors produced by the
  * compiled reference itself (oracle/_ref, built by oracle/Makefile; fixtures
- * in tests/golden/, generator oracle/make_golden.py) and against the
- * conserved quantities in the reference's own regression logs
- * (tests/regression/d3q19-short/serial-dist-*.log).
+ * in tests/golden/, generator oracle/make_golden.py: the LB step, the
+ * symmetric free-energy chain, the two-distribution step, walls, the
+ * distribution files) and against the quantities printed in the reference's
+ * own regression logs (tests/regression/d3q19-short/serial-dist-*.log,
+ * serial-symm-dr1.log, d3q19-io/iodrop-mpi1-io1.log).
  *
  * Storage is the reference's SoA ("reverse") order, memory.h:187-188:
  *   f[(n*nvel + p)*nsite + index]
