@@ -669,7 +669,7 @@ int lbmi_propagate_collide(lbmi_t * lb, const double * f, double * fprime,
  *****************************************************************************/
 
 static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
-			   double * data, hipStream_t st) {
+			   double * data, int blocked, hipStream_t st) {
 
   size_t psz = (size_t) lb->kp.strx;
   size_t ns = (size_t) lb->kp.nsite;
@@ -682,7 +682,7 @@ static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
 		     "not been called", lb->opts.cartsz);
   }
 
-  if (!lb->x_packed) {
+  if (!lb->x_packed && !blocked) {
     /* Zero-copy: X is the slowest index, so the boundary plane of ONE
      * component is a contiguous run of strx doubles. Every component goes
      * straight from the interior plane of this rank into the halo plane of
@@ -720,7 +720,7 @@ static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
 
     /* sendlo: first interior plane, components sel->hi -> prev's high halo
      * sendhi: last interior plane, components sel->lo  -> next's low halo */
-    KCHECK(lbmi_k_halo_pack_x(&lb->kp, sel, data, lb->sendlo, lb->sendhi, st));
+    KCHECK(lbmi_k_halo_pack_x(&lb->kp, sel, data, lb->sendlo, lb->sendhi, blocked, st));
 
     NCCLCHECK(ncclGroupStart());
     NCCLCHECK(ncclSend(lb->sendhi, nlo, ncclDouble, next, lb->comm, st));
@@ -729,7 +729,7 @@ static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
     NCCLCHECK(ncclRecv(lb->recvhi, nhi, ncclDouble, next, lb->comm, st));
     NCCLCHECK(ncclGroupEnd());
 
-    KCHECK(lbmi_k_halo_unpack_x(&lb->kp, sel, data, lb->recvlo, lb->recvhi, st));
+    KCHECK(lbmi_k_halo_unpack_x(&lb->kp, sel, data, lb->recvlo, lb->recvhi, blocked, st));
   }
 
   return 0;
@@ -739,7 +739,7 @@ static int lbmi_halo_generic(lbmi_t * lb, const lbmi_halo_sel_t sel[3],
 			     double * data, hipStream_t st) {
   int ifail;
   if (lb->opts.cartsz > 1 || lb->have_comm) {
-    ifail = lbmi_x_exchange(lb, &sel[X], data, st);
+    ifail = lbmi_x_exchange(lb, &sel[X], data, 0, st);
     if (ifail) return ifail;
   }
   else {
@@ -787,7 +787,7 @@ int lbmi_halo_x_pack(lbmi_t * lb, const double * f, int scheme,
   sel = lbmi_sel(lb, scheme);
   if (sel == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
   HIPCHECK(hipSetDevice(lb->device));
-  KCHECK(lbmi_k_halo_pack_x(&lb->kp, &sel[X], f, sendlo, sendhi, lb->stream));
+  KCHECK(lbmi_k_halo_pack_x(&lb->kp, &sel[X], f, sendlo, sendhi, 0, lb->stream));
   return 0;
 }
 
@@ -798,7 +798,7 @@ int lbmi_halo_x_unpack(lbmi_t * lb, double * f, int scheme,
   sel = lbmi_sel(lb, scheme);
   if (sel == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
   HIPCHECK(hipSetDevice(lb->device));
-  KCHECK(lbmi_k_halo_unpack_x(&lb->kp, &sel[X], f, recvlo, recvhi, lb->stream));
+  KCHECK(lbmi_k_halo_unpack_x(&lb->kp, &sel[X], f, recvlo, recvhi, 0, lb->stream));
   return 0;
 }
 
@@ -927,10 +927,18 @@ static int lbmi_deferred(const lbmi_t * lb) {
  * inside the whole blocks of the array */
 
 static int lbmi_blocked_ok(const lbmi_t * lb) {
-  int last = (lb->kp.nhalo + lb->kp.nlocal[X])*lb->kp.strx;
-  return (lb->use_blocked && lb->opts.mode == LBMI_MODE_FUSED &&
-	  lb->opts.cartsz == 1 && !lb->have_comm &&
-	  last <= lbmi_k_blocked_sites(&lb->kp));
+  int nfull = lbmi_k_blocked_sites(&lb->kp);
+  if (!lb->use_blocked || lb->opts.mode != LBMI_MODE_FUSED) return 0;
+  if (lb->opts.cartsz == 1 && !lb->have_comm) {
+    /* every pull is wrapped by index: nothing beyond the interior planes */
+    int last = (lb->kp.nhalo + lb->kp.nlocal[X])*lb->kp.strx;
+    return (last <= nfull);
+  }
+  /* Slabs pull from the x halo planes as well. Of the high one, the last
+   * nhalo rows in y (and the z halo of the row before) are never pulled from
+   * (y and z wrap by index): the sites past the last whole block must lie
+   * in there. */
+  return (lb->kp.nsite - nfull <= lb->kp.nhalo*lb->kp.stry + lb->kp.nhalo);
 }
 
 /* Back to the reference's SoA order (same state, other addresses) */
@@ -983,13 +991,28 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
      * compute stream never idles while the host is busy enqueueing the
      * exchange (an RCCL group costs ~15 us of host time). ev_ready marks
      * "previous step complete", i.e. the boundary planes of f are final. */
+    /* lay: 0 SoA -> SoA; 1 SoA -> blocked; 2 blocked -> blocked. Both
+     * launches of a step and the exchange see f in ONE order. */
+    int lay = lbmi_blocked_ok(lb) ? (lb->blocked ? 2 : 1) : 0;
+    if (lay == 0 && lb->blocked) {
+      ifail = lbmi_unblock(lb);
+      if (ifail) return ifail;
+    }
+    if (lb->nt_store_mode >= 0) {
+      lb->kp.nt_store = lb->nt_store_mode;
+    }
+    else {
+      size_t bytes = 2*sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel;
+      lb->kp.nt_store = (bytes > ((size_t) 256 << 20)) ? 1 : 0;
+    }
     HIPCHECK(hipEventRecord(lb->ev_ready, lb->stream));
     KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				    0, xlo + 1, xhi - 1, 0, -1, lb->stream));
+				    lay, xlo + 1, xhi - 1, 0, -1, lb->stream));
 
     /* comm stream: exchange the boundary planes into the x halo planes */
     HIPCHECK(hipStreamWaitEvent(lb->comm_stream, lb->ev_ready, 0));
-    ifail = lbmi_x_exchange(lb, &lb->sel_reduced[X], lb->f, lb->comm_stream);
+    ifail = lbmi_x_exchange(lb, &lb->sel_reduced[X], lb->f, lb->blocked,
+			    lb->comm_stream);
     if (ifail) return ifail;
     HIPCHECK(hipEventRecord(lb->ev_halo, lb->comm_stream));
 
@@ -1003,7 +1026,7 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
       HIPCHECK(hipStreamWaitEvent(lb->bnd_stream, lb->ev_ready, 0));
       HIPCHECK(hipStreamWaitEvent(lb->bnd_stream, lb->ev_halo, 0));
       KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				      0, xlo, xlo, xhi, (xhi > xlo) ? xhi : xhi - 1,
+				      lay, xlo, xlo, xhi, (xhi > xlo) ? xhi : xhi - 1,
 				      lb->bnd_stream));
       HIPCHECK(hipEventRecord(lb->ev_bnd, lb->bnd_stream));
       HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_bnd, 0));
@@ -1012,9 +1035,10 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
       /* both boundary planes in one launch, after the halo has arrived */
       HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_halo, 0));
       KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				      0, xlo, xlo, xhi, (xhi > xlo) ? xhi : xhi - 1,
+				      lay, xlo, xlo, xhi, (xhi > xlo) ? xhi : xhi - 1,
 				      lb->stream));
     }
+    lb->blocked = (lay != 0);
   }
 
   ifail = lbmi_time_end(lb);

@@ -1012,10 +1012,21 @@ void k_halo_copy(lbmi_kparam_t kp, int dir, lbmi_halo_sel_t sel,
  * high halo: components sel.hi), buf_hi the LAST interior plane
  * (components sel.lo). */
 
+/* address of component p of site i in an nvel-component array: SoA, or the
+ * blocked order of a deferred distribution state (faddr above) */
+__device__ __forceinline__
+size_t xaddr(const lbmi_kparam_t & kp, int blocked, int p, size_t i) {
+  if (blocked) {
+    return (i >> 8)*(size_t) (kp.nvel*LBW) + (size_t) (p*LBW) + (i & (size_t) (LBW - 1));
+  }
+  return (size_t) kp.nsite*p + i;
+}
+
 __global__ __launch_bounds__(BLOCK)
 void k_halo_pack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
 		   const double * __restrict__ data,
-		   double * __restrict__ buf_lo, double * __restrict__ buf_hi) {
+		   double * __restrict__ buf_lo, double * __restrict__ buf_hi,
+		   int blocked) {
 
   int j = blockIdx.x*BLOCK + threadIdx.x;
   int psz = kp.strx;
@@ -1023,13 +1034,13 @@ void k_halo_pack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
   int k = blockIdx.y;
   const int nh = kp.nhalo;
   if (k < sel.nhi) {
-    const double * d = data + (size_t) kp.nsite*sel.hi[k];
-    buf_lo[(size_t) k*psz + j] = d[(size_t) nh*kp.strx + j];
+    size_t i = (size_t) nh*kp.strx + j;
+    buf_lo[(size_t) k*psz + j] = data[xaddr(kp, blocked, sel.hi[k], i)];
   }
   else {
     int kk = k - sel.nhi;
-    const double * d = data + (size_t) kp.nsite*sel.lo[kk];
-    buf_hi[(size_t) kk*psz + j] = d[(size_t) (nh + kp.nlocal[0] - 1)*kp.strx + j];
+    size_t i = (size_t) (nh + kp.nlocal[0] - 1)*kp.strx + j;
+    buf_hi[(size_t) kk*psz + j] = data[xaddr(kp, blocked, sel.lo[kk], i)];
   }
 }
 
@@ -1041,21 +1052,24 @@ __global__ __launch_bounds__(BLOCK)
 void k_halo_unpack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
 		     double * __restrict__ data,
 		     const double * __restrict__ buf_lo,
-		     const double * __restrict__ buf_hi) {
+		     const double * __restrict__ buf_hi, int blocked) {
 
   int j = blockIdx.x*BLOCK + threadIdx.x;
   int psz = kp.strx;
   if (j >= psz) return;
   int k = blockIdx.y;
   const int nh = kp.nhalo;
+  /* blocked order: the sites past the last whole block (the very end of the
+   * high halo plane, y/z halo rows nobody pulls from) do not exist */
+  const size_t nfull = blocked ? ((size_t) kp.nsite/LBW)*LBW : (size_t) kp.nsite;
   if (k < sel.nlo) {
-    double * d = data + (size_t) kp.nsite*sel.lo[k];
-    d[(size_t) (nh - 1)*kp.strx + j] = buf_lo[(size_t) k*psz + j];
+    size_t i = (size_t) (nh - 1)*kp.strx + j;
+    if (i < nfull) data[xaddr(kp, blocked, sel.lo[k], i)] = buf_lo[(size_t) k*psz + j];
   }
   else {
     int kk = k - sel.nlo;
-    double * d = data + (size_t) kp.nsite*sel.hi[kk];
-    d[(size_t) (nh + kp.nlocal[0])*kp.strx + j] = buf_hi[(size_t) kk*psz + j];
+    size_t i = (size_t) (nh + kp.nlocal[0])*kp.strx + j;
+    if (i < nfull) data[xaddr(kp, blocked, sel.hi[kk], i)] = buf_hi[(size_t) kk*psz + j];
   }
 }
 
@@ -2302,26 +2316,28 @@ extern "C" int lbmi_k_halo_copy(const lbmi_kparam_t * kp, int dir,
 extern "C" int lbmi_k_halo_pack_x(const lbmi_kparam_t * kp,
 				  const lbmi_halo_sel_t * sel,
 				  const double * data, double * buf_lo,
-				  double * buf_hi, void * stream) {
+				  double * buf_hi, int blocked,
+				  void * stream) {
   hipStream_t st = (hipStream_t) stream;
   int ncomp = sel->nlo + sel->nhi;
   if (ncomp == 0) return 0;
   dim3 grid((kp->strx + BLOCK - 1)/BLOCK, ncomp), block(BLOCK);
   hipLaunchKernelGGL(k_halo_pack_x, grid, block, 0, st, *kp, *sel, data,
-		     buf_lo, buf_hi);
+		     buf_lo, buf_hi, blocked);
   return (int) hipGetLastError();
 }
 
 extern "C" int lbmi_k_halo_unpack_x(const lbmi_kparam_t * kp,
 				    const lbmi_halo_sel_t * sel,
 				    double * data, const double * buf_lo,
-				    const double * buf_hi, void * stream) {
+				    const double * buf_hi, int blocked,
+				    void * stream) {
   hipStream_t st = (hipStream_t) stream;
   int ncomp = sel->nlo + sel->nhi;
   if (ncomp == 0) return 0;
   dim3 grid((kp->strx + BLOCK - 1)/BLOCK, ncomp), block(BLOCK);
   hipLaunchKernelGGL(k_halo_unpack_x, grid, block, 0, st, *kp, *sel, data,
-		     buf_lo, buf_hi);
+		     buf_lo, buf_hi, blocked);
   return (int) hipGetLastError();
 }
 
