@@ -201,6 +201,8 @@ static void lbmi_halo_selections(lbmi_t * lb) {
 
 int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
 
+  int prio_low = 0, prio_high = 0;
+
   lbmi_t * lb = NULL;
   int ndevice = 0;
   hipDeviceProp_t prop;
@@ -335,9 +337,15 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   lbmi_set_relaxation(lb, LBMI_RELAXATION_M10, 1.0, 1.0/6.0, 1.0/6.0);
 
   /* lbmi_free() releases whatever exists so far (members start as NULL) */
+  /* the exchange and the boundary planes sit on the critical path of a slab
+   * step while the long interior launch fills the chip: highest priority */
+  if (hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) {
+    prio_low = 0;
+    prio_high = 0;
+  }
   if (hipStreamCreateWithFlags(&lb->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&lb->comm_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&lb->bnd_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithPriority(&lb->comm_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
+      hipStreamCreateWithPriority(&lb->bnd_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
       hipEventCreateWithFlags(&lb->ev_bnd, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&lb->ev_ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&lb->ev_halo, hipEventDisableTiming) != hipSuccess) {
