@@ -157,7 +157,12 @@ def main():
 
     if world > 1:
         # control plane only (barrier, max-reduction, id broadcast); the
-        # data path is the library's own RCCL communicator
+        # data path is the library's own RCCL communicator. All ranks share
+        # one node: rendezvous and bootstrap over loopback, whatever the
+        # host name resolves to (or does not).
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
@@ -180,22 +185,12 @@ def main():
         k, v = kv.split("=")
         lb.tune(k, int(v))
 
-    # RCCL prints a version banner on stdout when a communicator is created;
-    # the contract is ONE JSON line on stdout, so park fd 1 on stderr meanwhile
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
-    try:
-        if world > 1:
-            ids = [ludwig_amd.LB.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            lb.comm_init(ids[0])
-        elif args.selfring:
-            lb.comm_init(ludwig_amd.LB.comm_unique_id())
-    finally:
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        os.close(saved_stdout)
+    if world > 1:
+        ids = [ludwig_amd.LB.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        lb.comm_init(ids[0])
+    elif args.selfring:
+        lb.comm_init(ludwig_amd.LB.comm_unique_id())
 
     m = ludwig_amd.lb.model(args.nvel)
     synthetic.fill_device(lb, m["cv"], m["wv"], ntotal,
@@ -399,12 +394,28 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        result = json.dumps(out)
 
     lb.free()
     if world > 1:
         dist.destroy_process_group()
+    return result if rank == 0 else None
 
 
 if __name__ == "__main__":
-    main()
+    # The contract is ONE JSON line on stdout. Gloo ("[Gloo] Rank 0 is
+    # connected ...") and RCCL (its version banner) write to fd 1 from
+    # native code: park fd 1 on stderr for the whole run and give it back
+    # only for the line itself.
+    sys.stdout.flush()
+    _saved = os.dup(1)
+    os.dup2(2, 1)
+    _line = None
+    try:
+        _line = main()
+    finally:
+        sys.stdout.flush()
+        os.dup2(_saved, 1)
+        os.close(_saved)
+    if _line is not None:
+        print(_line, flush=True)
