@@ -27,3 +27,17 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_libraries():
+    """A fresh checkout has no binaries (they are git-ignored): build the
+    product library (hipcc cross-compiles without a GPU) and the oracle once
+    per session. The product itself never builds on demand -- it fails
+    loudly when liblbmi.so is missing."""
+    from ludwig_amd import lib as L
+    if not os.path.exists(L.LIB_PATH):
+        L.build()
+    from oracle import lb_oracle as lbo
+    lbo.lib()
+    yield
