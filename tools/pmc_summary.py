@@ -50,6 +50,16 @@ def main():
     nf, fetch = counter_avg(tag, "fetch", "FETCH_SIZE", kernel)
     nw, write = counter_avg(tag, "write", "WRITE_SIZE", kernel)
     rl = bench["roofline"]
+    # the stats pass prints its own bench line: HIP events and rocprofv3 of
+    # ONE process (separate processes differ by a few per cent through the
+    # physical placement of their arrays)
+    same = None
+    try:
+        log = open(os.path.join(ROOT, "gpurun_out", tag + "_stats.log")).read()
+        line = [x for x in log.splitlines() if x.startswith("{")][-1]
+        same = json.loads(line)["roofline"]["avg_launch_ms"]
+    except Exception:
+        pass
     algo = rl["bytes_per_lup"] * rl["lups_per_launch"]
     traffic = 2.0 * fetch * 1024.0 + write * 1024.0
     out = {
@@ -67,6 +77,7 @@ def main():
             "rocprofv3_avg_kernel_ms": kavg[0] if kavg else None,
             "rocprofv3_calls": kavg[1] if kavg else None,
             "bench_hip_event_avg_kernel_ms": rl["avg_launch_ms"],
+            "hip_event_avg_kernel_ms_in_the_rocprofv3_stats_process": same,
             "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), "
                     "same command and same box as the stats pass and the bench "
                     "line; FETCH_SIZE doubled (gfx950); stores include the "
