@@ -202,11 +202,12 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
   assert(lb);
   assert(map);
 
-  /* Not covered by liblbmi: fluctuations, free-energy stress relaxation,
-   * viscosity models; two distributions only with the symmetric free energy
-   * (as the reference, collision.c:160) */
-  if (!shim_supported(lb) || noise->on[NOISE_RHO] ||
-      (fe && fe->use_stress_relaxation) || visc != NULL ||
+  /* Not covered by liblbmi: fluctuations, viscosity models, stress
+   * relaxation with a free energy other than the symmetric one; two
+   * distributions only with the symmetric free energy (as the reference,
+   * collision.c:160) */
+  if (!shim_supported(lb) || noise->on[NOISE_RHO] || visc != NULL ||
+      (fe && fe->use_stress_relaxation && fe->id != FE_SYMMETRIC) ||
       (lb->ndist == 2 && (fe == NULL || fe->id != FE_SYMMETRIC))) {
     if (shim_.h && shim_.lb == lb) {
       SHIM_CHECK(lb, lbmi_lb_flush(shim_.h));
@@ -252,8 +253,9 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
     hy.rho    = shim_field_data(hydro->rho);
     hy.u      = shim_field_data(hydro->u);
 
-    if (lb->ndist == 2) {
-      /* lb_collision_binary (collision.c:610-1027) */
+    if (lb->ndist == 2 || (fe && fe->use_stress_relaxation)) {
+      /* lb_collision_binary (collision.c:610-1027), or the single-fluid
+       * collision with the symmetric stress relaxed (:413-429) */
       fe_symm_t * fs = (fe_symm_t *) fe;
       fe_symm_param_t param;
       lbmi_fe_symm_t bin;
@@ -267,7 +269,12 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
 			  tdpMemcpyDeviceToHost));
       tdpAssert(tdpMemcpy(&bin.delsq, &fs->dphi->target->delsq,
 			  sizeof(double *), tdpMemcpyDeviceToHost));
-      SHIM_CHECK(lb, lbmi_lb_collide_binary(h, &hy, &bin));
+      if (lb->ndist == 2) {
+	SHIM_CHECK(lb, lbmi_lb_collide_binary(h, &hy, &bin));
+      }
+      else {
+	SHIM_CHECK(lb, lbmi_lb_collide_fe(h, &hy, &bin));
+      }
     }
     else {
       SHIM_CHECK(lb, lbmi_lb_collide(h, &hy));

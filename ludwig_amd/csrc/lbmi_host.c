@@ -1389,6 +1389,34 @@ int lbmi_wall_momentum(lbmi_t * lb, double fnet[3]) {
  *
  *****************************************************************************/
 
+/* lb_collide with fe->use_stress_relaxation (collision.c:413-429,
+ * FE_FORCE_METHOD_RELAXATION_SYMM) for the symmetric free energy and ONE
+ * distribution. Always an in-place collision on the canonical state: a
+ * deferred halo swap and propagation are materialised first. */
+
+int lbmi_lb_collide_fe(lbmi_t * lb, const lbmi_hydro_t * hydro,
+		       const lbmi_fe_symm_t * fe) {
+  lbmi_hydro_dev_t h = lbmi_hydro_dev(hydro);
+  int ifail;
+  if (lb == NULL || fe == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+  if (lb->opts.ndist != 1) return lbmi_fail(LBMI_ERR_STATE, "needs ndist = 1");
+  if (!fe->phi || !fe->grad || !fe->delsq) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_lb_collide_fe: phi, grad and "
+		     "delsq are required");
+  }
+  if (hydro == NULL) return 0;                       /* collision.c:149 */
+  if (lbmi_deferred(lb) && lb->pending_halo && !lb->pending_prop) {
+    return lbmi_fail(LBMI_ERR_STATE, "lb_collide after lb_halo without "
+		     "lb_propagation");
+  }
+  ifail = lbmi_lb_flush(lb);
+  if (ifail) return ifail;
+  KCHECK(lbmi_k_collide_fe(&lb->kp, lb->f, &h, fe->a, fe->b, fe->kappa,
+			   fe->phi, fe->grad, fe->delsq, lb->stream));
+  return 0;
+}
+
 int lbmi_lb_phi_to_field(lbmi_t * lb, double * phi) {
   if (lb == NULL || phi == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");

@@ -140,6 +140,12 @@ int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, int npt, int order,
 			const double * delsq, const double * u, double * force,
 			double * phi_out, int accumulate, void * stream);
 
+/* k_collide with fe->use_stress_relaxation for the symmetric free energy */
+int lbmi_k_collide_fe(const lbmi_kparam_t * kp, double * f,
+		      const lbmi_hydro_dev_t * h, double a, double b,
+		      double kappa, const double * phi, const double * grad,
+		      const double * delsq, void * stream);
+
 /* Two distributions (symmetric_lb): f2[(n*nvel + p)*nsite + i] */
 int lbmi_k_phi_from_g(const lbmi_kparam_t * kp, const double * f2,
 		      double * phi, void * stream);

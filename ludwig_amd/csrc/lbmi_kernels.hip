@@ -499,6 +499,64 @@ void k_collide(lbmi_kparam_t kp, double * __restrict__ f,
   }
 }
 
+/* k_collide_fe: the same with fe->use_stress_relaxation (collision.c:413-
+ * 429) for the symmetric free energy: its stress at the site, from phi and
+ * the field_grad_compute arrays, joins the equilibrium stress. */
+
+template <int NVEL, int SCHEME>
+__global__ __launch_bounds__(BLOCK)
+void k_collide_fe(lbmi_kparam_t kp, double * __restrict__ f,
+		  lbmi_hydro_dev_t h, double qa, double qb, double qkappa,
+		  const double * __restrict__ phi,
+		  const double * __restrict__ grad,
+		  const double * __restrict__ delsq, int i0, int i1,
+		  unsigned nblk) {
+
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+
+  Site s = decode(kp, i);
+  if (!s.interior) return;
+  if (h.status && h.status[i] != 0) return;      /* collision.c:299-304 */
+
+  const size_t ns = (size_t) kp.nsite;
+  double fl[NVEL];
+  static_for<0, NVEL>([&](auto P) { fl[P] = f[ns*P + i]; });
+
+  double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
+  if (h.force) {
+    frc[0] += h.force[i];
+    frc[1] += h.force[ns + i];
+    frc[2] += h.force[2*ns + i];
+  }
+
+  Relax rx = {kp.rtau_shear, kp.rtau_bulk, kp.rtau_even, kp.rtau_odd};
+  double rho, u[3];
+  double sth[6];
+  {
+    /* P_ab = p0 delta_ab + kappa d_a phi d_b phi (symmetric.c:371-420) */
+    const double ph = phi[i], d2 = delsq[i];
+    const double g0 = grad[i], g1 = grad[ns + i], g2 = grad[2*ns + i];
+    const double p0 = 0.5*qa*ph*ph + 0.75*qb*ph*ph*ph*ph - qkappa*ph*d2
+      - 0.5*qkappa*(g0*g0 + g1*g1 + g2*g2);
+    sth[0] = p0 + qkappa*g0*g0; sth[1] = qkappa*g0*g1; sth[2] = qkappa*g0*g2;
+    sth[3] = p0 + qkappa*g1*g1; sth[4] = qkappa*g1*g2;
+    sth[5] = p0 + qkappa*g2*g2;
+  }
+  const double (&sthr)[6] = sth;
+  collide_site_impl<NVEL, SCHEME, true>(fl, frc, rx, sthr, rho, u);
+
+  static_for<0, NVEL>([&](auto P) { f[ns*P + i] = fl[P]; });
+  if (h.rho) h.rho[i] = rho;
+  if (h.u) {
+    h.u[i] = u[0];
+    h.u[ns + i] = u[1];
+    h.u[2*ns + i] = u[2];
+  }
+}
+
 /* ---- k_propagate: pull streaming ------------------------------------------ */
 
 template <int NVEL>
@@ -2157,6 +2215,48 @@ extern "C" int lbmi_k_collide(const lbmi_kparam_t * kp, double * f,
   hipStream_t st = (hipStream_t) stream;
   if (kp->nvel == 19) return launch_collide<19>(*kp, f, *h, st);
   if (kp->nvel == 27) return launch_collide<27>(*kp, f, *h, st);
+  return (int) hipErrorInvalidValue;
+}
+
+template <int NVEL>
+static int launch_collide_fe(const lbmi_kparam_t & kp, double * f,
+			     const lbmi_hydro_dev_t & h, double a, double b,
+			     double kappa, const double * phi,
+			     const double * grad, const double * delsq,
+			     hipStream_t st) {
+  Range1D r = interior_range(kp);
+  dim3 grid(r.grid), block(BLOCK);
+  switch (kp.scheme) {
+  case LBMI_M10:
+    hipLaunchKernelGGL((k_collide_fe<NVEL, LBMI_M10>), grid, block, 0, st, kp,
+		       f, h, a, b, kappa, phi, grad, delsq, r.i0, r.i1, r.nblk);
+    break;
+  case LBMI_BGK:
+    hipLaunchKernelGGL((k_collide_fe<NVEL, LBMI_BGK>), grid, block, 0, st, kp,
+		       f, h, a, b, kappa, phi, grad, delsq, r.i0, r.i1, r.nblk);
+    break;
+  case LBMI_TRT:
+    if constexpr (NVEL == 19) {
+      hipLaunchKernelGGL((k_collide_fe<NVEL, LBMI_TRT>), grid, block, 0, st,
+			 kp, f, h, a, b, kappa, phi, grad, delsq, r.i0, r.i1,
+			 r.nblk);
+      break;
+    }
+    return (int) hipErrorInvalidValue;
+  default:
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_collide_fe(const lbmi_kparam_t * kp, double * f,
+				 const lbmi_hydro_dev_t * h, double a,
+				 double b, double kappa, const double * phi,
+				 const double * grad, const double * delsq,
+				 void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  if (kp->nvel == 19) return launch_collide_fe<19>(*kp, f, *h, a, b, kappa, phi, grad, delsq, st);
+  if (kp->nvel == 27) return launch_collide_fe<27>(*kp, f, *h, a, b, kappa, phi, grad, delsq, st);
   return (int) hipErrorInvalidValue;
 }
 

@@ -400,6 +400,15 @@ class LB:
             _l.check(self._lib.lbmi_lb_collide_binary(self._h, ctypes.byref(h),
                                                       ctypes.byref(fe)))
 
+    def lb_collide_fe(self, hydro, a, b, kappa, phi, grad, delsq):
+        """lb_collide with fe->use_stress_relaxation (symmetric free energy)."""
+        fe = _l.FeSymm()
+        fe.a, fe.b, fe.kappa, fe.mobility = a, b, kappa, 0.0
+        fe.phi, fe.grad, fe.delsq = _ptr(phi), _ptr(grad), _ptr(delsq)
+        h = hydro.ptrs()
+        _l.check(self._lib.lbmi_lb_collide_fe(self._h, ctypes.byref(h),
+                                              ctypes.byref(fe)))
+
     def lb_io_write(self, directory, timestep, ntotal_x=None, offset_x=0):
         """lb_io_write (model.c:1568): dist-metadata.001-001 and
         dist-<timestep>.001-001 in `directory` (MPI-IO mode, one file)."""

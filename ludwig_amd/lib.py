@@ -97,6 +97,8 @@ SYMBOLS = [
     ("lbmi_lb_phi_to_field", _i, [_vp, _vp]),
     ("lbmi_lb_collide_binary", _i, [_vp, ctypes.POINTER(HydroPtrs),
                                     ctypes.POINTER(FeSymm)]),
+    ("lbmi_lb_collide_fe", _i, [_vp, ctypes.POINTER(HydroPtrs),
+                                ctypes.POINTER(FeSymm)]),
     ("lbmi_lb_memcpy_h2d", _i, [_vp, _vp]),
     ("lbmi_lb_memcpy_d2h", _i, [_vp, _vp]),
     ("lbmi_lb_moments", _i, [_vp, _vp, _pd]),

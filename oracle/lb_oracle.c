@@ -228,8 +228,40 @@ static int relaxation_rates(const lbo_param_t * p, double * rtau_shear,
  * reproduced here.
  */
 
+static void symm_stress(double a, double b, double kappa, double phi,
+			const double g[3], double delsq, double s[3][3]);
+
+/* fe != NULL: fe->use_stress_relaxation (collision.c:413-429) with the
+ * symmetric free energy: its stress (fe_symm_str_v, symmetric.c:371-420) is
+ * added to the equilibrium stress. fe = {a, b, kappa}; phi, grad, delsq as
+ * field_grad_compute left them. */
+
+static int collide_impl(const lbo_param_t * p, double * f,
+			const double * force, const char * status,
+			const double * fe, const double * phi,
+			const double * grad, const double * delsq,
+			double * rho_out, double * u_out);
+
 int lbo_collide(const lbo_param_t * p, double * f, const double * force,
 		const char * status, double * rho_out, double * u_out) {
+  return collide_impl(p, f, force, status, NULL, NULL, NULL, NULL, rho_out,
+		      u_out);
+}
+
+int lbo_collide_fe(const lbo_param_t * p, double * f, const double * force,
+		   const char * status, double a, double b, double kappa,
+		   const double * phi, const double * grad,
+		   const double * delsq, double * rho_out, double * u_out) {
+  const double fe[3] = {a, b, kappa};
+  return collide_impl(p, f, force, status, fe, phi, grad, delsq, rho_out,
+		      u_out);
+}
+
+static int collide_impl(const lbo_param_t * p, double * f,
+			const double * force, const char * status,
+			const double * fe, const double * phi,
+			const double * grad, const double * delsq,
+			double * rho_out, double * u_out) {
 
   int nall[3];
   ptrdiff_t str[3];
@@ -304,6 +336,16 @@ int lbo_collide(const lbo_param_t * p, double * f, const double * force,
 	tr_s = 0.0; tr_seq = 0.0;
 	for (int ia = 0; ia < 3; ia++) {
 	  for (int ib = 0; ib < 3; ib++) seq[ia][ib] = rho*u[ia]*u[ib];
+	}
+	if (fe) {
+	  double sth[3][3], gr[3];
+	  for (int ia = 0; ia < 3; ia++) gr[ia] = grad[nsite*ia + index];
+	  symm_stress(fe[0], fe[1], fe[2], phi[index], gr, delsq[index], sth);
+	  for (int ia = 0; ia < 3; ia++) {
+	    for (int ib = 0; ib < 3; ib++) seq[ia][ib] += sth[ia][ib];
+	  }
+	}
+	for (int ia = 0; ia < 3; ia++) {
 	  tr_s   += s[ia][ia];
 	  tr_seq += seq[ia][ia];
 	}

@@ -71,6 +71,9 @@ def lib():
         _lib.lbo_halo_width.argtypes = [pp, ctypes.c_int, dp, ctypes.c_int,
                                         ctypes.c_int]
         _lib.lbo_phi_from_g.argtypes = [pp, dp, dp]
+        _lib.lbo_collide_fe.argtypes = [pp, dp, dp, dp, ctypes.c_double,
+                                        ctypes.c_double, ctypes.c_double,
+                                        dp, dp, dp, dp, dp]
         _lib.lbo_collide_binary.argtypes = [pp, dp, dp, ctypes.c_double,
                                             ctypes.c_double, ctypes.c_double,
                                             ctypes.c_double, dp, dp, dp, dp]
@@ -203,6 +206,15 @@ def wall_bbl(p, f, links, ubot, utop, fnet):
     rc = lib().lbo_wall_bbl(ctypes.byref(p), _ptr(f), len(li), _ptr(li),
                             _ptr(lj), _ptr(lp), _ptr(lu), _ptr(ub), _ptr(ut),
                             _ptr(fnet))
+    assert rc == 0
+
+
+def collide_fe(p, f, force, status, a, b, kappa, phi, grad, delsq, rho=None,
+               u=None):
+    """lb_collide with fe->use_stress_relaxation (symmetric free energy)."""
+    rc = lib().lbo_collide_fe(ctypes.byref(p), _ptr(f), _ptr(force), _ptr(status),
+                              a, b, kappa, _ptr(phi), _ptr(grad), _ptr(delsq),
+                              _ptr(rho), _ptr(u))
     assert rc == 0
 
 

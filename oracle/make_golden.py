@@ -122,6 +122,36 @@ BINARY_CASES = [
 ]
 
 
+# fe->use_stress_relaxation with ONE distribution (same arguments)
+RELAX_CASES = [
+    ("relax_q19_a", 19, (6, 5, 4), -0.0625, 0.0625, 0.04, 0.15, 0.1, 0.1, 1e-5, 4),
+    ("relax_q27_a", 27, (5, 6, 4), -0.00625, 0.00625, 0.004, 1.25, 0.1, 0.3, 0.0, 4),
+]
+
+
+def run_relax_case(case, tmp):
+    """lb_collide with fe->use_stress_relaxation = 1 (collision.c:413-429):
+    the symmetric stress of a fixed phi in the equilibrium stress."""
+    name, nvel, n, a, b, kappa, mob, eta, zeta, fx, nsteps = case
+    exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
+    prefix = os.path.join(tmp, name)
+    subprocess.run([exe, "relax", prefix, *map(str, n), repr(a), repr(b),
+                    repr(kappa), repr(mob), repr(eta), repr(zeta), repr(fx),
+                    str(nsteps)], check=True)
+    meta = json.load(open(prefix + ".json"))
+    meta["name"] = name
+    nall = tuple(meta["nall"])
+
+    def load(key, lead):
+        return np.fromfile("%s.%s.f64" % (prefix, key), dtype="<f8").reshape(lead + nall)
+
+    return {"meta": np.array(json.dumps(meta)), "f0": load("f0", (nvel,)),
+            "phi": load("phi", ()), "grad": load("grad", (3,)),
+            "delsq": load("delsq", ()), "f_collide": load("f_collide", (nvel,)),
+            "rho": load("rho", ()), "u": load("u", (3,)),
+            "f_final": load("f_final", (nvel,))}
+
+
 def run_binary_case(case, tmp):
     """The two-distribution (symmetric_lb) step: lb_collision_binary with
     27-point gradients, lb_halo and lb_propagation of both distributions.
@@ -223,6 +253,11 @@ def main():
             print("wrote", fn, os.path.getsize(fn))
         for case in BINARY_CASES:
             out = run_binary_case(case, tmp)
+            fn = os.path.join(GOLD, case[0] + ".npz")
+            np.savez_compressed(fn, **out)
+            print("wrote", fn, os.path.getsize(fn))
+        for case in RELAX_CASES:
+            out = run_relax_case(case, tmp)
             fn = os.path.join(GOLD, case[0] + ".npz")
             np.savez_compressed(fn, **out)
             print("wrote", fn, os.path.getsize(fn))

@@ -35,6 +35,8 @@
  *
  *    ref_driver binary <prefix> nx ny nz a b kappa mobility eta zeta fx nsteps
  *               (two-distribution symmetric_lb step, collision.c:610-1027)
+ *    ref_driver relax <prefix> nx ny nz a b kappa mobility eta zeta fx nsteps
+ *               (ONE distribution, fe->use_stress_relaxation: collision.c:413)
  *    ref_driver wall <prefix> nx ny nz bx by bz uboty utopy solid nsteps
  *               (flat walls: lb_collide, lb_halo, wall_bbl, lb_propagation)
  *    ref_driver io <dir> nx ny nz timestep      (lb_io_write into <dir>)
@@ -362,6 +364,11 @@ static int run_fe(int argc, char ** argv) {
 
 static int run_binary(int argc, char ** argv) {
 
+  /* "relax": ONE distribution and fe->use_stress_relaxation = 1, i.e. the
+   * single-fluid collision with the symmetric stress in the equilibrium
+   * stress (collision.c:413-429, FE_FORCE_METHOD_RELAXATION_SYMM,
+   * ludwig.c:1235-1237); phi is a fixed analytic field */
+  const int relax = (strcmp(argv[1], "relax") == 0);
   const char * prefix = argv[2];
   case_t c = {0};
   fe_symm_param_t param = {0};
@@ -417,7 +424,7 @@ static int run_binary(int argc, char ** argv) {
     lb_data_options_t opts = lb_data_options_default();
     opts.ndim = NDIM;
     opts.nvel = NVEL;
-    opts.ndist = 2;
+    opts.ndist = relax ? 1 : 2;
     opts.nrelax = LB_RELAXATION_M10;
     opts.halo = LB_HALO_TARGET;
     lb_data_create(pe, cs, &opts, &lb);
@@ -430,6 +437,7 @@ static int run_binary(int argc, char ** argv) {
   field_grad_set(dphi, grad_3d_27pt_fluid_d2, NULL);
   fe_symm_create(pe, cs, phi, dphi, &fe);
   fe_symm_param_set(fe, param);
+  if (relax) fe->super.use_stress_relaxation = 1;
   {
     hydro_options_t hopts = hydro_options_nhalo(1);
     hydro_create(pe, cs, le, &hopts, &hydro);
@@ -451,6 +459,10 @@ static int run_binary(int argc, char ** argv) {
 	double y = (jc - 1.0)/c.ntotal[Y];
 	double z = (kc - 1.0)/c.ntotal[Z];
 	double phi0 = 0.4*sin(2.0*PI_*x)*cos(2.0*PI_*y) + 0.3*sin(2.0*PI_*z + 1.0);
+	if (relax) {
+	  field_scalar_set(phi, index, phi0 + 0.02*(lcg_uniform() - 0.5));
+	  continue;
+	}
 	for (int p = 0; p < lb->model.nvel; p++) {
 	  double r = lcg_uniform();
 	  lb_f_set(lb, index, p, LB_PHI,
@@ -461,7 +473,7 @@ static int run_binary(int argc, char ** argv) {
   }
 
   {
-    size_t nf = (size_t) lb->nsite*lb->model.nvel*2;
+    size_t nf = (size_t) lb->nsite*lb->model.nvel*(relax ? 1 : 2);
     size_t ns = (size_t) lb->nsite;
     int nall[3];
     char fn[1024];
@@ -469,7 +481,7 @@ static int run_binary(int argc, char ** argv) {
 
     dump(prefix, "f0", lb->f, nf);
     for (int n = 0; n < nsteps; n++) {
-      phi_lb_to_field(phi, lb);
+      if (!relax) phi_lb_to_field(phi, lb);
       field_halo(phi);
       field_grad_compute(dphi);
       hydro_u_zero(hydro, fzero);
@@ -480,6 +492,7 @@ static int run_binary(int argc, char ** argv) {
 	dump(prefix, "delsq", dphi->delsq, ns);
 	dump(prefix, "f_collide", lb->f, nf);
 	dump(prefix, "u", hydro->u->data, 3*ns);
+	dump(prefix, "rho", hydro->rho->data, ns);
       }
       lb_halo(lb);
       lb_propagation(lb);
@@ -489,13 +502,13 @@ static int run_binary(int argc, char ** argv) {
     cs_nall(cs, nall);
     snprintf(fn, sizeof(fn), "%s.json", prefix);
     fp = fopen(fn, "w");
-    fprintf(fp, "{\"nvel\": %d, \"ndist\": 2, \"nlocal\": [%d, %d, %d],"
+    fprintf(fp, "{\"nvel\": %d, \"ndist\": %d, \"nlocal\": [%d, %d, %d],"
 	    " \"nhalo\": 1, \"nall\": [%d, %d, %d], \"nsite\": %d,"
 	    " \"a\": %.17g, \"b\": %.17g, \"kappa\": %.17g,"
 	    " \"mobility\": %.17g, \"eta\": %.17g, \"zeta\": %.17g,"
 	    " \"fbody\": [%.17g, 0.0, 0.0], \"nsteps\": %d,"
 	    " \"layout\": \"soa\"}\n",
-	    NVEL, c.ntotal[X], c.ntotal[Y], c.ntotal[Z],
+	    NVEL, relax ? 1 : 2, c.ntotal[X], c.ntotal[Y], c.ntotal[Z],
 	    nall[X], nall[Y], nall[Z], lb->nsite, param.a, param.b,
 	    param.kappa, mobility, c.eta, c.zeta, c.fbody[X], nsteps);
     fclose(fp);
@@ -764,7 +777,8 @@ int main(int argc, char ** argv) {
   if (argc == 13 && strcmp(argv[1], "wall") == 0) {
     return run_wall(argc, argv);
   }
-  if (argc == 14 && strcmp(argv[1], "binary") == 0) {
+  if (argc == 14 && (strcmp(argv[1], "binary") == 0 ||
+		     strcmp(argv[1], "relax") == 0)) {
     return run_binary(argc, argv);
   }
   if (argc == 7 && (strcmp(argv[1], "io") == 0 ||

@@ -152,3 +152,33 @@ def test_binary_rejections():
     with pytest.raises(ludwig_amd.LbmiError):
         lb.phi_to_field(hy.rho)                # needs ndist = 2
     lb.free()
+
+
+# --- one distribution, fe->use_stress_relaxation -----------------------------
+
+from tests.common import golden_relax_names  # noqa: E402
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["eager", "fused"])
+@pytest.mark.parametrize("name", golden_relax_names())
+def test_stress_relaxation_vs_reference(name, mode):
+    import ludwig_amd
+    g = load_golden(name)
+    meta = g["meta"]
+    lb = ludwig_amd.LB(meta["nvel"], tuple(meta["nlocal"]), 1, mode=mode)
+    lb.relaxation_set("m10", meta["eta"], meta["zeta"])
+    lb.body_force_set(meta["fbody"])
+    hy = ludwig_amd.Hydro(lb.nall, lb.device)
+    phi, grad, delsq = _dev(lb, g["phi"]), _dev(lb, g["grad"]), _dev(lb, g["delsq"])
+    lb.lb_memcpy_h2d(g["f0"])
+    lb.lb_collide_fe(hy, meta["a"], meta["b"], meta["kappa"], phi, grad, delsq)
+    assert relmax(interior(lb.lb_memcpy_d2h(), 1), interior(g["f_collide"], 1)) < 1e-12
+    assert relmax(interior(_host(lb, hy.rho), 1), interior(g["rho"], 1)) < 1e-12
+    assert relmax(interior(_host(lb, hy.u), 1), interior(g["u"], 1)) < 1e-12
+    lb.lb_memcpy_h2d(g["f0"])
+    for _ in range(meta["nsteps"]):
+        lb.lb_collide_fe(hy, meta["a"], meta["b"], meta["kappa"], phi, grad, delsq)
+        lb.lb_halo()
+        lb.lb_propagation()
+    assert relmax(interior(lb.lb_memcpy_d2h(), 1), interior(g["f_final"], 1)) < 1e-12
+    lb.free()

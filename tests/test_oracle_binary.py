@@ -63,3 +63,40 @@ def test_binary_steps(name):
     for sl in (slice(0, nv), slice(nv, 2 * nv)):
         m0 = interior(g["f0"][sl], 1).sum()
         assert abs(interior(f2[sl], 1).sum() - m0) < 1e-12 * max(1.0, abs(m0))
+
+
+# --- one distribution, fe->use_stress_relaxation (collision.c:413-429) -------
+
+from tests.common import golden_relax_names  # noqa: E402
+
+
+@pytest.mark.parametrize("name", golden_relax_names())
+def test_stress_relaxation_collision_and_steps(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    p = param(meta)
+    phi = np.ascontiguousarray(g["phi"])
+    grad = np.ascontiguousarray(g["grad"])
+    delsq = np.ascontiguousarray(g["delsq"])
+    f = np.ascontiguousarray(g["f0"]).copy()
+    rho = np.zeros(f.shape[1:])
+    u = np.zeros((3,) + f.shape[1:])
+    lbo.collide_fe(p, f, None, None, meta["a"], meta["b"], meta["kappa"], phi,
+                   grad, delsq, rho, u)
+    assert relmax(interior(f, 1), interior(g["f_collide"], 1)) < 5e-15
+    assert relmax(interior(rho, 1), interior(g["rho"], 1)) < 5e-15
+    assert relmax(interior(u, 1), interior(g["u"], 1)) < 5e-15
+    # the stress changes the result: this is not the plain collision
+    f1 = np.ascontiguousarray(g["f0"]).copy()
+    lbo.collide(p, f1)
+    assert relmax(interior(f1, 1), interior(g["f_collide"], 1)) > 1e-6
+    # whole steps with phi fixed
+    f = np.ascontiguousarray(g["f0"]).copy()
+    fp = np.zeros_like(f)
+    for _ in range(meta["nsteps"]):
+        lbo.collide_fe(p, f, None, None, meta["a"], meta["b"], meta["kappa"],
+                       phi, grad, delsq)
+        lbo.halo(p, f)
+        lbo.propagate(p, f, fp)
+        f, fp = fp, f
+    assert relmax(interior(f, 1), interior(g["f_final"], 1)) < 1e-13
