@@ -127,12 +127,18 @@ typedef struct lbmi_options_s {
 /* Borrowed per-call fields of lb_collide(): hydro_t and map_t device arrays
  * (collision.c:200-202, 329-333, 571-579). Any pointer may be NULL:
  * force == NULL is a zero force field; status == NULL is all MAP_FLUID;
- * rho/u == NULL are not written. */
+ * rho/u == NULL are not written; eta == NULL is the constant viscosity.
+ * Zero-initialise the struct: members may be added at its end. */
 typedef struct lbmi_hydro_s {
   const double * force;     /* hydro->force->data, 3*nsite                   */
   const char   * status;    /* map->status, nsite bytes, 0 = MAP_FLUID       */
   double       * rho;       /* hydro->rho->data, nsite                       */
   double       * u;         /* hydro->u->data, 3*nsite                       */
+  const double * eta;       /* hydro->eta->data, nsite: the local shear
+			       viscosity of a viscosity model (lb_collide
+			       with visc != NULL, collision.c:386-404; the
+			       bulk viscosity keeps the ratio of
+			       lbmi_set_relaxation); NULL = constant         */
 } lbmi_hydro_t;
 
 /* ---- life cycle: lb_data_create / lb_free (model.c:56-213) -------------- */

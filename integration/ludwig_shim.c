@@ -202,11 +202,12 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
   assert(lb);
   assert(map);
 
-  /* Not covered by liblbmi: fluctuations, viscosity models, stress
-   * relaxation with a free energy other than the symmetric one; two
+  /* Not covered by liblbmi: fluctuations, stress relaxation with a free
+   * energy other than the symmetric one; two
    * distributions only with the symmetric free energy (as the reference,
    * collision.c:160) */
-  if (!shim_supported(lb) || noise->on[NOISE_RHO] || visc != NULL ||
+  if (!shim_supported(lb) || noise->on[NOISE_RHO] ||
+      (visc != NULL && lb->ndist != 1) ||
       (fe && fe->use_stress_relaxation && fe->id != FE_SYMMETRIC) ||
       (lb->ndist == 2 && (fe == NULL || fe->id != FE_SYMMETRIC))) {
     if (shim_.h && shim_.lb == lb) {
@@ -252,6 +253,9 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
     hy.status = status;
     hy.rho    = shim_field_data(hydro->rho);
     hy.u      = shim_field_data(hydro->u);
+    /* a viscosity model has left the local viscosity in hydro->eta
+     * (collision.c:386-404, 1947) */
+    hy.eta    = visc ? shim_field_data(hydro->eta) : NULL;
 
     if (lb->ndist == 2 || (fe && fe->use_stress_relaxation)) {
       /* lb_collision_binary (collision.c:610-1027), or the single-fluid

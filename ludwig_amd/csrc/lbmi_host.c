@@ -443,6 +443,8 @@ int lbmi_set_relaxation(lbmi_t * lb, int scheme, double rho0,
   rtau = 1.0/(0.5 + eta_shear/(rho0*cs2));
   rtau_bulk = 1.0/(0.5 + eta_bulk/(rho0*cs2));
   lb->rho0 = rho0;
+  lb->kp.rho0 = rho0;
+  lb->kp.bulk_ratio = eta_bulk/eta_shear;
 
   switch (scheme) {
   case LBMI_RELAXATION_M10:
@@ -504,12 +506,13 @@ int lbmi_relaxation_rates(const lbmi_t * lb, double rtau[4]) {
  *****************************************************************************/
 
 static lbmi_hydro_dev_t lbmi_hydro_dev(const lbmi_hydro_t * hydro) {
-  lbmi_hydro_dev_t h = {NULL, NULL, NULL, NULL};
+  lbmi_hydro_dev_t h = {NULL, NULL, NULL, NULL, NULL};
   if (hydro) {
     h.force = hydro->force;
     h.status = hydro->status;
     h.rho = hydro->rho;
     h.u = hydro->u;
+    h.eta = hydro->eta;
   }
   return h;
 }
@@ -1441,6 +1444,7 @@ int lbmi_lb_collide_binary(lbmi_t * lb, const lbmi_hydro_t * hydro,
   if (hydro == NULL) return 0;
   h.rho = NULL;
   h.status = NULL;
+  h.eta = NULL;                    /* fixed rates, collision.c:862-876 */
   HIPCHECK(hipSetDevice(lb->device));
   /* (1/tau_2) = 2/(2M + 1), collision.c:1965-1968 */
   KCHECK(lbmi_k_collide_binary(&lb->kp, lb->f, &h, fe->a, fe->b, fe->kappa,

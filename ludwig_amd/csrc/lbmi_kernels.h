@@ -33,6 +33,8 @@ typedef struct lbmi_kparam_s {
   double rtau_bulk;
   double rtau_even;        /* ghost modes 10, 14, 18 (d3q19); all for d3q27 */
   double rtau_odd;         /* ghost modes 11-13, 15-17 (d3q19) */
+  double rho0;             /* for local relaxation times (hydro eta) */
+  double bulk_ratio;       /* eta_bulk/eta_shear of lbmi_set_relaxation */
   double fbody[3];
   /* launch tuning of the fused kernel (lbmi_tune) */
   int xcd_group;           /* blocks per XCD interleave group; 0: chunked */
@@ -46,6 +48,7 @@ typedef struct lbmi_hydro_dev_s {
   const char   * status;
   double       * rho;
   double       * u;
+  const double * eta;       /* local shear viscosity, or NULL */
 } lbmi_hydro_dev_t;
 
 /* Halo pass description: components (populations) to copy to the low-side

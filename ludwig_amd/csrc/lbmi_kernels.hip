@@ -397,6 +397,39 @@ void collide_site_impl(double (&f)[NVEL], const double (&frc)[3],
   });
 }
 
+/* Relaxation rates of a site: the constants of lbmi_set_relaxation, or,
+ * with a viscosity model, those of the local shear viscosity hydro->eta
+ * (collision.c:386-404 with lb_relaxation_time_shear_v, _bulk_v, _ghosts_v,
+ * :1287-1538; the bulk viscosity keeps the Newtonian ratio) */
+
+template <int SCHEME>
+__device__ __forceinline__
+Relax site_relax(const lbmi_kparam_t & kp, const lbmi_hydro_dev_t & h, int i) {
+  Relax rx = {kp.rtau_shear, kp.rtau_bulk, kp.rtau_even, kp.rtau_odd};
+  if (h.eta) {
+    const double cs2 = (1.0/3.0);
+    const double eta = h.eta[i];
+    const double rtau = 1.0/(0.5 + eta/(kp.rho0*cs2));
+    rx.rtau_s = rtau;
+    if constexpr (SCHEME == LBMI_BGK) {
+      rx.rtau_b = rtau;
+      rx.rtau_e = rtau;
+      rx.rtau_o = rtau;
+    }
+    else {
+      rx.rtau_b = 1.0/(0.5 + (kp.bulk_ratio*eta)/(kp.rho0*cs2));
+      if constexpr (SCHEME == LBMI_TRT) {
+	const double tau = eta/(kp.rho0*cs2);
+	double rodd = 0.5 + 2.0*tau/(tau + 3.0/8.0);
+	if (rodd > 2.0) rodd = 2.0;
+	rx.rtau_e = rtau;
+	rx.rtau_o = rodd;
+      }
+    }
+  }
+  return rx;
+}
+
 template <int NVEL, int SCHEME>
 __device__ __forceinline__
 void collide_site(double (&f)[NVEL], const double (&frc)[3], const Relax & rx,
@@ -486,7 +519,7 @@ void k_collide(lbmi_kparam_t kp, double * __restrict__ f,
     frc[2] += h.force[2*ns + i];
   }
 
-  Relax rx = {kp.rtau_shear, kp.rtau_bulk, kp.rtau_even, kp.rtau_odd};
+  Relax rx = site_relax<SCHEME>(kp, h, i);
   double rho, u[3];
   collide_site<NVEL, SCHEME>(fl, frc, rx, rho, u);
 
@@ -532,7 +565,7 @@ void k_collide_fe(lbmi_kparam_t kp, double * __restrict__ f,
     frc[2] += h.force[2*ns + i];
   }
 
-  Relax rx = {kp.rtau_shear, kp.rtau_bulk, kp.rtau_even, kp.rtau_odd};
+  Relax rx = site_relax<SCHEME>(kp, h, i);
   double rho, u[3];
   double sth[6];
   {
@@ -704,7 +737,7 @@ void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
       frc[1] += h.force[ns + i];
       frc[2] += h.force[2*ns + i];
     }
-    Relax rx = {kp.rtau_shear, kp.rtau_bulk, kp.rtau_even, kp.rtau_odd};
+    Relax rx = site_relax<SCHEME>(kp, h, i);
     double rho, u[3];
     collide_site<NVEL, SCHEME>(ps.fl, frc, rx, rho, u);
     if (kp.nt_store & 2) {
@@ -855,7 +888,7 @@ void site_collide_hydro(const lbmi_kparam_t & kp, const lbmi_hydro_dev_t & h,
     frc[1] += h.force[ns + i];
     frc[2] += h.force[2*ns + i];
   }
-  Relax rx = {kp.rtau_shear, kp.rtau_bulk, kp.rtau_even, kp.rtau_odd};
+  Relax rx = site_relax<SCHEME>(kp, h, i);
   double rho, u[3];
   collide_site<NVEL, SCHEME>(fl, frc, rx, rho, u);
   if (h.rho) h.rho[i] = rho;

@@ -42,7 +42,8 @@ def _ptr(t):
 class Hydro:
     """Device arrays of hydro_t (+ map_t status) that lb_collide borrows."""
 
-    def __init__(self, nall, device, force=None, status=None, with_rho_u=True):
+    def __init__(self, nall, device, force=None, status=None, with_rho_u=True,
+                 eta=None):
         torch = _torch()
         self.nall = tuple(nall)
         self.device = device
@@ -50,6 +51,12 @@ class Hydro:
         self.status = None
         self.rho = None
         self.u = None
+        self.eta = None
+        if eta is not None:
+            # hydro->eta of a viscosity model: local shear viscosity
+            self.eta = torch.from_numpy(np.ascontiguousarray(
+                eta, dtype=np.float64)).to(device)
+            assert tuple(self.eta.shape) == self.nall
         if force is not None:
             self.force = torch.from_numpy(np.ascontiguousarray(
                 force, dtype=np.float64)).to(device)
@@ -72,6 +79,7 @@ class Hydro:
         h.status = _ptr(self.status)
         h.rho = _ptr(self.rho)
         h.u = _ptr(self.u)
+        h.eta = _ptr(self.eta)
         return h
 
 

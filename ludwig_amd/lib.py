@@ -35,6 +35,7 @@ class HydroPtrs(ctypes.Structure):
         ("status", ctypes.c_void_p),
         ("rho", ctypes.c_void_p),
         ("u", ctypes.c_void_p),
+        ("eta", ctypes.c_void_p),
     ]
 
 

@@ -173,10 +173,25 @@ static void strides(const lbo_param_t * p, int nall[3], ptrdiff_t str[3]) {
  * (shear), :1339-1373 (bulk), :1443-1538 (ghosts; scheme-driven).
  */
 
+static int relaxation_rates_eta(const lbo_param_t * p, double eta,
+				double eta_bulk, double * rtau_shear,
+				double * rtau_bulk,
+				double rtau_ghost[LBO_NVEL_MAX]);
+
 static int relaxation_rates(const lbo_param_t * p, double * rtau_shear,
 			    double * rtau_bulk, double rtau_ghost[LBO_NVEL_MAX]) {
+  return relaxation_rates_eta(p, p->eta_shear, p->eta_bulk, rtau_shear,
+			      rtau_bulk, rtau_ghost);
+}
 
-  double eta = p->eta_shear;
+/* lb_relaxation_time_shear_v, _bulk_v, _ghosts_v (collision.c:1287-1538) for
+ * a given (possibly local) shear viscosity eta and bulk viscosity eta_bulk */
+
+static int relaxation_rates_eta(const lbo_param_t * p, double eta,
+				double eta_bulk, double * rtau_shear,
+				double * rtau_bulk,
+				double rtau_ghost[LBO_NVEL_MAX]) {
+
   double rtau = 1.0/(0.5 + eta/(p->rho0*cs2));
 
   *rtau_shear = rtau;
@@ -185,7 +200,7 @@ static int relaxation_rates(const lbo_param_t * p, double * rtau_shear,
 
   switch (p->scheme) {
   case LBO_M10:
-    *rtau_bulk = 1.0/(0.5 + p->eta_bulk/(p->rho0*cs2));
+    *rtau_bulk = 1.0/(0.5 + eta_bulk/(p->rho0*cs2));
     for (int m = NHYDRO; m < p->nvel; m++) rtau_ghost[m] = 1.0;
     break;
   case LBO_BGK:
@@ -200,7 +215,7 @@ static int relaxation_rates(const lbo_param_t * p, double * rtau_shear,
       double rtau_odd = 0.5 + 2.0*tau/(tau + 3.0/8.0);
       if (rtau_odd > 2.0) rtau_odd = 2.0;
       if (p->nvel != 19) return -1;
-      *rtau_bulk = 1.0/(0.5 + p->eta_bulk/(p->rho0*cs2));
+      *rtau_bulk = 1.0/(0.5 + eta_bulk/(p->rho0*cs2));
       rtau_ghost[10] = rtau; rtau_ghost[14] = rtau; rtau_ghost[18] = rtau;
       rtau_ghost[11] = rtau_odd; rtau_ghost[12] = rtau_odd;
       rtau_ghost[13] = rtau_odd; rtau_ghost[15] = rtau_odd;
@@ -240,12 +255,24 @@ static int collide_impl(const lbo_param_t * p, double * f,
 			const double * force, const char * status,
 			const double * fe, const double * phi,
 			const double * grad, const double * delsq,
+			const double * eta_site,
 			double * rho_out, double * u_out);
 
 int lbo_collide(const lbo_param_t * p, double * f, const double * force,
 		const char * status, double * rho_out, double * u_out) {
-  return collide_impl(p, f, force, status, NULL, NULL, NULL, NULL, rho_out,
-		      u_out);
+  return collide_impl(p, f, force, status, NULL, NULL, NULL, NULL, NULL,
+		      rho_out, u_out);
+}
+
+/* With a viscosity model (visc != NULL in lb_collide): the local shear
+ * viscosity comes from hydro->eta and the bulk viscosity keeps the
+ * Newtonian ratio, (eta_bulk/eta_shear) eta (collision.c:386-404). */
+
+int lbo_collide_visc(const lbo_param_t * p, double * f, const double * force,
+		     const char * status, const double * eta,
+		     double * rho_out, double * u_out) {
+  return collide_impl(p, f, force, status, NULL, NULL, NULL, NULL, eta,
+		      rho_out, u_out);
 }
 
 int lbo_collide_fe(const lbo_param_t * p, double * f, const double * force,
@@ -253,14 +280,15 @@ int lbo_collide_fe(const lbo_param_t * p, double * f, const double * force,
 		   const double * phi, const double * grad,
 		   const double * delsq, double * rho_out, double * u_out) {
   const double fe[3] = {a, b, kappa};
-  return collide_impl(p, f, force, status, fe, phi, grad, delsq, rho_out,
-		      u_out);
+  return collide_impl(p, f, force, status, fe, phi, grad, delsq, NULL,
+		      rho_out, u_out);
 }
 
 static int collide_impl(const lbo_param_t * p, double * f,
 			const double * force, const char * status,
 			const double * fe, const double * phi,
 			const double * grad, const double * delsq,
+			const double * eta_site,
 			double * rho_out, double * u_out) {
 
   int nall[3];
@@ -300,7 +328,11 @@ static int collide_impl(const lbo_param_t * p, double * f,
 	double frc[3], u[3];
 	double s[3][3], seq[3][3];
 	double rho, rrho, tr_s, tr_seq;
+	double srtau = rtau, srtau_bulk = rtau_bulk;   /* this site's rates */
+	double srtau_ghost[LBO_NVEL_MAX];
 	int m;
+
+	for (m = 0; m < LBO_NVEL_MAX; m++) srtau_ghost[m] = rtau_ghost[m];
 
 	if (status && status[index] != MAP_FLUID) continue;
 
@@ -332,6 +364,13 @@ static int collide_impl(const lbo_param_t * p, double * f,
 	rrho = 1.0/rho;
 	for (int ia = 0; ia < 3; ia++) u[ia] = rrho*(mode[1+ia] + 0.5*frc[ia]);
 
+	if (eta_site) {
+	  /* local relaxation times (collision.c:386-404) */
+	  double eta = eta_site[index];
+	  relaxation_rates_eta(p, eta, (p->eta_bulk/p->eta_shear)*eta,
+			       &srtau, &srtau_bulk, srtau_ghost);
+	}
+
 	/* stress relaxation (collision.c:408-474) */
 	tr_s = 0.0; tr_seq = 0.0;
 	for (int ia = 0; ia < 3; ia++) {
@@ -353,14 +392,14 @@ static int collide_impl(const lbo_param_t * p, double * f,
 	  s[ia][ia]   -= rdim*tr_s;
 	  seq[ia][ia] -= rdim*tr_seq;
 	}
-	tr_s = tr_s - rtau_bulk*(tr_s - tr_seq);
+	tr_s = tr_s - srtau_bulk*(tr_s - tr_seq);
 
 	for (int ia = 0; ia < 3; ia++) {
 	  for (int ib = 0; ib < 3; ib++) {
 	    double dab = (ia == ib);
-	    s[ia][ib] -= rtau*(s[ia][ib] - seq[ia][ib]);
+	    s[ia][ib] -= srtau*(s[ia][ib] - seq[ia][ib]);
 	    s[ia][ib] += dab*rdim*tr_s;
-	    s[ia][ib] += (2.0 - rtau)*(u[ia]*frc[ib] + frc[ia]*u[ib]);
+	    s[ia][ib] += (2.0 - srtau)*(u[ia]*frc[ib] + frc[ia]*u[ib]);
 	  }
 	}
 
@@ -374,7 +413,7 @@ static int collide_impl(const lbo_param_t * p, double * f,
 	  }
 	}
 	for (m = NHYDRO; m < nvel; m++) {
-	  mode[m] = mode[m] - rtau_ghost[m]*(mode[m] - 0.0);
+	  mode[m] = mode[m] - srtau_ghost[m]*(mode[m] - 0.0);
 	}
 
 	/* modes -> f (collision.c:548-559) */

@@ -70,6 +70,9 @@ int lbo_wall_bbl(const lbo_param_t * p, double * f, int nlink,
 		 const int * linki, const int * linkj, const int * linkp,
 		 const int * linku, const double ubot[3],
 		 const double utop[3], double fnet[3]);
+int lbo_collide_visc(const lbo_param_t * p, double * f, const double * force,
+		     const char * status, const double * eta,
+		     double * rho_out, double * u_out);
 int lbo_collide_fe(const lbo_param_t * p, double * f, const double * force,
 		   const char * status, double a, double b, double kappa,
 		   const double * phi, const double * grad,

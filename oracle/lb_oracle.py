@@ -71,6 +71,7 @@ def lib():
         _lib.lbo_halo_width.argtypes = [pp, ctypes.c_int, dp, ctypes.c_int,
                                         ctypes.c_int]
         _lib.lbo_phi_from_g.argtypes = [pp, dp, dp]
+        _lib.lbo_collide_visc.argtypes = [pp, dp, dp, dp, dp, dp, dp]
         _lib.lbo_collide_fe.argtypes = [pp, dp, dp, dp, ctypes.c_double,
                                         ctypes.c_double, ctypes.c_double,
                                         dp, dp, dp, dp, dp]
@@ -206,6 +207,13 @@ def wall_bbl(p, f, links, ubot, utop, fnet):
     rc = lib().lbo_wall_bbl(ctypes.byref(p), _ptr(f), len(li), _ptr(li),
                             _ptr(lj), _ptr(lp), _ptr(lu), _ptr(ub), _ptr(ut),
                             _ptr(fnet))
+    assert rc == 0
+
+
+def collide_visc(p, f, force, status, eta, rho=None, u=None):
+    """lb_collide with a viscosity model: local eta from hydro->eta."""
+    rc = lib().lbo_collide_visc(ctypes.byref(p), _ptr(f), _ptr(force),
+                                _ptr(status), _ptr(eta), _ptr(rho), _ptr(u))
     assert rc == 0
 
 

@@ -46,8 +46,16 @@ CASES = [
     ("q27_bgk_nh2",     27, (5, 4, 6), 2, "bgk", 0.15, 0.15, (0, 0, 1e-5), 0, 0, 5, False),
 ]
 
+# the same tuple; lb_collide is given a viscosity model, i.e. the local shear
+# viscosity comes from hydro->eta (key "eta" in the fixture)
+VISC_CASES = [
+    ("visc_q19_m10", 19, (6, 5, 4), 1, "m10", 0.1, 0.3, (1e-5, 0, 0), 0, 0, 4, False),
+    ("visc_q19_trt", 19, (6, 5, 4), 1, "trt", 0.05, 0.2, (0, 0, 0), 1, 0, 4, False),
+    ("visc_q27_bgk", 27, (5, 4, 6), 1, "bgk", 0.15, 0.15, (0, 0, 1e-5), 0, 0, 4, False),
+]
 
-def run_case(case, tmp):
+
+def run_case(case, tmp, visc=0):
     (name, nvel, n, nhalo, scheme, eta, zeta, fb, ff, solid, nsteps,
      keep_halo) = case
     exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
@@ -55,6 +63,8 @@ def run_case(case, tmp):
     args = [exe, "dump", prefix, *map(str, n), str(nhalo), scheme,
             repr(eta), repr(zeta), *[repr(float(x)) for x in fb],
             str(ff), str(solid), str(nsteps)]
+    if visc:
+        args.append("1")
     subprocess.run(args, check=True)
     meta = json.load(open(prefix + ".json"))
     meta["name"] = name
@@ -77,6 +87,8 @@ def run_case(case, tmp):
         out["records"] = rec.reshape(tuple(meta["nlocal"]) + (nvel,))
     out["f_prop"] = load("f_prop", (nvel,))
     out["f_final"] = load("f_final", (nvel,))
+    if visc:
+        out["eta"] = load("eta", ())
     return out
 
 
@@ -243,6 +255,11 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         for case in CASES:
             out = run_case(case, tmp)
+            fn = os.path.join(GOLD, case[0] + ".npz")
+            np.savez_compressed(fn, **out)
+            print("wrote", fn, os.path.getsize(fn))
+        for case in VISC_CASES:
+            out = run_case(case, tmp, visc=1)
             fn = os.path.join(GOLD, case[0] + ".npz")
             np.savez_compressed(fn, **out)
             print("wrote", fn, os.path.getsize(fn))

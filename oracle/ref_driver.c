@@ -25,7 +25,7 @@
  *
  *  Usage:
  *    ref_driver dump <prefix> nx ny nz nhalo scheme eta zeta fx fy fz \
- *               fieldforce solid nsteps
+ *               fieldforce solid nsteps [visc]
  *    ref_driver time nx ny nz scheme eta zeta nsteps
  *    ref_driver fe <prefix> nx ny nz a b kappa mobility [gradnpt advorder]
  *               (symmetric free energy: field_halo, field_grad_compute with
@@ -91,6 +91,7 @@ typedef struct {
   int fieldforce;       /* per-site force field on/off */
   int solid;            /* a block of MAP_BOUNDARY sites on/off */
   int nsteps;
+  int visc;             /* viscosity model: local eta from hydro->eta */
 } case_t;
 
 static uint32_t lcg_state = 12345u;
@@ -786,7 +787,7 @@ int main(int argc, char ** argv) {
     return run_io(argc, argv);
   }
 
-  if (argc >= 2 && strcmp(argv[1], "dump") == 0 && argc == 16) {
+  if (argc >= 2 && strcmp(argv[1], "dump") == 0 && (argc == 16 || argc == 17)) {
     int a = 2;
     strncpy(prefix, argv[a++], sizeof(prefix) - 1);
     c.ntotal[X] = atoi(argv[a++]);
@@ -802,6 +803,7 @@ int main(int argc, char ** argv) {
     c.fieldforce = atoi(argv[a++]);
     c.solid = atoi(argv[a++]);
     c.nsteps = atoi(argv[a++]);
+    if (argc == 17) c.visc = atoi(argv[a++]);
   }
   else if (argc >= 2 && strcmp(argv[1], "time") == 0 && argc == 9) {
     int a = 2;
@@ -856,17 +858,37 @@ int main(int argc, char ** argv) {
   init_force(cs, hydro, &c);
   init_map(cs, map, &c);
 
+  if (c.visc) {
+    /* what a viscosity model (visc_t::update) would leave in hydro->eta;
+     * lb_collide only tests the visc pointer (collision.c:1947) */
+    int nlocal[3];
+    cs_nlocal(cs, nlocal);
+    for (int ic = 1; ic <= nlocal[X]; ic++) {
+      for (int jc = 1; jc <= nlocal[Y]; jc++) {
+	for (int kc = 1; kc <= nlocal[Z]; kc++) {
+	  double x = (ic - 1.0)/c.ntotal[X];
+	  double z = (kc - 1.0)/c.ntotal[Z];
+	  double eta = c.eta*(1.0 + 0.5*sin(2.0*PI_*x)*cos(2.0*PI_*z))
+	    + 0.01*c.eta*(lcg_uniform() - 0.5);
+	  hydro->eta->data[addr_rank0(hydro->nsite, cs_index(cs, ic, jc, kc))] = eta;
+	}
+      }
+    }
+  }
+
   {
     size_t nf = (size_t) lb->nsite*lb->model.nvel;
     size_t ns = (size_t) lb->nsite;
+    visc_t * visc = c.visc ? (visc_t *) hydro : NULL;   /* non-NULL flag */
 
     if (timing == 0) {
 
       dump(prefix, "f0", lb->f, nf);
       dump(prefix, "force", hydro->force->data, 3*ns);
+      if (c.visc) dump(prefix, "eta", hydro->eta->data, ns);
 
       for (int n = 0; n < c.nsteps; n++) {
-	lb_collide(lb, hydro, map, noise, NULL, NULL);
+	lb_collide(lb, hydro, map, noise, NULL, visc);
 	if (n == 0) {
 	  dump(prefix, "f_collide", lb->f, nf);
 	  dump(prefix, "rho", hydro->rho->data, ns);
@@ -913,11 +935,12 @@ int main(int argc, char ** argv) {
 		" \"nall\": [%d, %d, %d], \"nsite\": %d, \"scheme\": %d,"
 		" \"eta\": %.17g, \"zeta\": %.17g, \"rho0\": 1.0,"
 		" \"fbody\": [%.17g, %.17g, %.17g], \"fieldforce\": %d,"
-		" \"solid\": %d, \"nsteps\": %d, \"layout\": \"soa\"}\n",
+		" \"solid\": %d, \"nsteps\": %d, \"visc\": %d,"
+		" \"layout\": \"soa\"}\n",
 		NVEL, c.ntotal[X], c.ntotal[Y], c.ntotal[Z], c.nhalo,
 		nall[X], nall[Y], nall[Z], lb->nsite, (int) c.nrelax,
 		c.eta, c.zeta, c.fbody[X], c.fbody[Y], c.fbody[Z],
-		c.fieldforce, c.solid, c.nsteps);
+		c.fieldforce, c.solid, c.nsteps, c.visc);
 	fclose(fp);
       }
     }

@@ -98,6 +98,7 @@ static int run_mode(int mode, const char * name) {
   CHECK(lbmi_lb_bind(lb, f, fprime));
   CHECK(lbmi_lb_memcpy_h2d(lb, fh));
 
+  memset(&hydro, 0, sizeof(hydro));
   hydro.force = force; hydro.status = NULL; hydro.rho = rho; hydro.u = u;
 
   for (int n = 0; n < NSTEPS; n++) {

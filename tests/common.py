@@ -33,6 +33,12 @@ def golden_binary_names():
                   for f in glob.glob(os.path.join(GOLDEN_DIR, "bin_*.npz")))
 
 
+def golden_visc_names():
+    """Fixtures of lb_collide with a viscosity model (visc_*)."""
+    return sorted(os.path.basename(f)[:-4]
+                  for f in glob.glob(os.path.join(GOLDEN_DIR, "visc_*.npz")))
+
+
 def golden_relax_names():
     """Fixtures of lb_collide with fe->use_stress_relaxation (relax_*)."""
     return sorted(os.path.basename(f)[:-4]

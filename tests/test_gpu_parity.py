@@ -618,3 +618,56 @@ def test_rccl_self_ring_blocked_slab(nvel, nlocal, concurrent):
     for _ in range(5):
         f, fp = lbo.step(p, f, fp)
     assert relmax(res[1][1], interior(f, 1)) < RTOL_F
+
+
+# --- viscosity model: local relaxation times from hydro->eta ------------------
+
+from tests.common import golden_visc_names  # noqa: E402
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "fused_soa"])
+@pytest.mark.parametrize("name", golden_visc_names())
+def test_local_viscosity_vs_reference(name, mode):
+    """lb_collide with visc != NULL (collision.c:386-404): the rates of every
+    site from hydro->eta, bulk viscosity in the Newtonian ratio."""
+    import ludwig_amd
+    g = load_golden(name)
+    meta = g["meta"]
+    h = meta["nhalo"]
+    lb = make_lb(meta, mode=mode)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, force=g["force"], eta=g["eta"])
+    lb.lb_memcpy_h2d(g["f0"])
+    lb.lb_collide(hy)
+    assert relmax(interior(lb.lb_memcpy_d2h(), h), interior(g["f_collide"], h)) < RTOL_F
+    assert relmax(interior(host(lb, hy.u), h), interior(g["u"], h)) < RTOL_F
+    lb.lb_memcpy_h2d(g["f0"])
+    for _ in range(meta["nsteps"]):
+        lb.step(hy)
+    assert relmax(interior(lb.lb_memcpy_d2h(), h), interior(g["f_final"], h)) < RTOL_F
+    lb.free()
+
+
+def test_local_viscosity_seeded_blocked():
+    """A lattice of whole blocks: the fused blocked kernel with hydro->eta,
+    against the oracle."""
+    import ludwig_amd
+    nlocal = (10, 14, 14)
+    p = lbo.make_param(19, nlocal, 1, "trt", 0.1, 0.25)
+    f0 = lbo.init_synthetic(p)
+    rng = np.random.default_rng(4)
+    eta = 0.1 * (1.0 + 0.4 * rng.random(lbo.nall(p)))
+    f = f0.copy()
+    fp = np.zeros_like(f)
+    for _ in range(4):
+        lbo.collide_visc(p, f, None, None, eta)
+        lbo.halo(p, f)
+        lbo.propagate(p, f, fp)
+        f, fp = fp, f
+    lb = ludwig_amd.LB(19, nlocal, 1, mode=ludwig_amd.FUSED)
+    lb.relaxation_set("trt", 0.1, 0.25)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, eta=eta)
+    lb.lb_memcpy_h2d(f0)
+    lb.run(hy, 4)
+    assert lb.state()[2] == 1
+    assert relmax(interior(lb.lb_memcpy_d2h(), 1), interior(f, 1)) < RTOL_F
+    lb.free()

@@ -137,3 +137,38 @@ def test_record_stream(name):
     assert np.array_equal(interior(f2, h), interior(f, h))
     # halo sites untouched
     assert np.count_nonzero(f2) == np.count_nonzero(interior(f2, h))
+
+
+# --- viscosity model: local relaxation times from hydro->eta ------------------
+
+from tests.common import golden_visc_names  # noqa: E402
+
+
+@pytest.mark.parametrize("name", golden_visc_names())
+def test_collision_with_local_viscosity(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    p = lbo.make_param(meta["nvel"], meta["nlocal"], meta["nhalo"],
+                       meta["scheme_name"], meta["eta"], meta["zeta"],
+                       meta["rho0"], meta["fbody"])
+    eta = np.ascontiguousarray(g["eta"])
+    force = np.ascontiguousarray(g["force"])
+    f = np.ascontiguousarray(g["f0"]).copy()
+    rho = np.zeros(f.shape[1:])
+    u = np.zeros((3,) + f.shape[1:])
+    lbo.collide_visc(p, f, force, None, eta, rho, u)
+    h = meta["nhalo"]
+    assert relmax(interior(f, h), interior(g["f_collide"], h)) < 5e-15
+    assert relmax(interior(u, h), interior(g["u"], h)) < 5e-15
+    # it is not the constant-viscosity collision
+    f1 = np.ascontiguousarray(g["f0"]).copy()
+    lbo.collide(p, f1, force)
+    assert relmax(interior(f1, h), interior(g["f_collide"], h)) > 1e-7
+    f = np.ascontiguousarray(g["f0"]).copy()
+    fp = np.zeros_like(f)
+    for _ in range(meta["nsteps"]):
+        lbo.collide_visc(p, f, force, None, eta)
+        lbo.halo(p, f)
+        lbo.propagate(p, f, fp)
+        f, fp = fp, f
+    assert relmax(interior(f, h), interior(g["f_final"], h)) < 1e-13
