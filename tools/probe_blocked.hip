@@ -62,6 +62,56 @@ void k_pull(const double * __restrict__ f, double * __restrict__ fp,
   for (int p = 0; p < NS; p++) fp[addr<WB, BW>(nsite, p, i)] = v[p]*1.0000001;
 }
 
+static double time_it(hipStream_t st, int reps, const std::function<void()> & launch);
+
+// Two consecutive sites per thread, 16-byte accesses (global_load_dwordx4
+// with 8-byte alignment for the z-shifted pulls). Blocked order, BW sites per
+// block of BW/2 threads.
+struct __attribute__((packed, aligned(8))) d2 { double a, b; };
+
+template <int BW>
+__global__ __launch_bounds__(BW/2)
+void k_pull2(const double * __restrict__ f, double * __restrict__ fp,
+	     size_t nsite, long long i0, long long i1, unsigned nblk, unsigned group) {
+  extern __shared__ int lds_unused[];
+  unsigned lb;
+  if (!lblock(nblk, group, lb)) return;
+  long long i = i0 + (long long) lb*BW + 2*threadIdx.x;
+  if (i >= i1) return;
+  d2 v[NS];
+#pragma unroll
+  for (int p = 0; p < NS; p++) {
+    long long j = i - c_shift[p];
+    // both sites of the pair lie in one block row unless j is the last site of a row
+    if ((j % BW) != BW - 1) {
+      v[p] = *reinterpret_cast<const d2 *>(&f[addr<1, BW>(nsite, p, j)]);
+    } else {
+      v[p].a = f[addr<1, BW>(nsite, p, j)];
+      v[p].b = f[addr<1, BW>(nsite, p, j + 1)];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NS; p++) {
+    d2 w = {v[p].a*1.0000001, v[p].b*1.0000001};
+    *reinterpret_cast<d2 *>(&fp[addr<1, BW>(nsite, p, i)]) = w;
+  }
+}
+
+template <int BW>
+void run2(hipStream_t st, const double * a, double * b, size_t nsite, unsigned lds,
+	  unsigned group) {
+  const long long strx = 258*258;
+  const long long i0 = ((2*strx + 1023)/1024)*1024, i1 = ((255LL*strx)/1024)*1024;
+  unsigned nblk = (unsigned) ((i1 - i0 + BW - 1)/BW);
+  unsigned q = 8u*group;
+  unsigned grid = ((nblk + q - 1)/q)*q;
+  auto kern = k_pull2<BW>;
+  double ms = time_it(st, 10, [&]{ hipLaunchKernelGGL(kern, dim3(grid), dim3(BW/2), lds, st, a, b, nsite, i0, i1, nblk, group); });
+  double gb = 2.0*NS*8.0*(double) (i1 - i0)*1e-9;
+  printf("pull2 (16 B/lane) blk->blk BW=%4d bs=%4d lds=%6u g=%3u  %7.3f ms %8.1f GB/s\n",
+	 BW, BW/2, lds, group, ms, gb/ms*1e3);
+}
+
 static double time_it(hipStream_t st, int reps, const std::function<void()> & launch) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -127,6 +177,11 @@ int main() {
     run<1, 1, 256, 256>(st, a, b, nsite, 0, 4);
     run<1, 1, 256, 256>(st, a, b, nsite, 0, 64);
     run<1, 1, 256, 256>(st, a, b, nsite, 32768, 16);
+    for (unsigned lds : {0u, 32768u, 65536u}) {
+      run2<256>(st, a, b, nsite, lds, 16);
+      run2<512>(st, a, b, nsite, lds, 16);
+      run2<512>(st, a, b, nsite, lds, 32);
+    }
   }
   return 0;
 }
