@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--nvel", type=int, default=19)
     ap.add_argument("--scheme", default="m10", choices=["m10", "bgk", "trt"])
     ap.add_argument("--mode", default="fused",
-                    choices=["fused", "eager", "inplace", "fused_soa"],
+                    choices=["fused", "eager", "inplace", "fused_soa", "fused_halo"],
                     help="fused (default): on one GPU the deferred state is "
                     "kept in the block-contiguous order; fused_soa: in the "
                     "reference's SoA order")
@@ -175,7 +175,8 @@ def main():
     dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, nhalo=args.nhalo)
     mode = {"fused": ludwig_amd.FUSED, "eager": ludwig_amd.EAGER,
             "inplace": ludwig_amd.INPLACE,
-            "fused_soa": ludwig_amd.FUSED_SOA}[args.mode]
+            "fused_soa": ludwig_amd.FUSED_SOA,
+            "fused_halo": ludwig_amd.FUSED_HALO}[args.mode]
     lb = ludwig_amd.LB(args.nvel, dec.nlocal, args.nhalo, mode=mode,
                        halo_scheme=ludwig_amd.HALO_REDUCED, device=local_rank,
                        cartsz=world, cartrank=rank)
@@ -315,7 +316,7 @@ def main():
         algo_bytes = pop_bytes + (56 if args.hydro else 0)
         local_sites = dec.nlocal[0] * dec.nlocal[1] * dec.nlocal[2]
         roofline = None
-        if nlaunch > 0 and args.mode in ("fused", "inplace", "fused_soa"):
+        if nlaunch > 0 and args.mode in ("fused", "inplace", "fused_soa", "fused_halo"):
             t_launch = 1e-3 * kms / nlaunch
             achieved = 1e-9 * algo_bytes * local_sites / t_launch
             roofline = {

@@ -104,11 +104,20 @@ typedef enum lbmi_halo_e {
  *        lbmi_lb_flush). The second kernel performs the propagation of its
  *        own step early, so the lb_halo / lb_propagation calls that follow
  *        it only acknowledge. Same legality conditions as FUSED, and
- *        cartsz == 1 (with slabs it falls back to FUSED). */
+ *        cartsz == 1 (with slabs it falls back to FUSED).
+ * FUSED_HALO: lb_collide and lb_halo are as observable as in EAGER -- after
+ *        them f is the reference's post-collision state with its halo, in the
+ *        reference's order, so link bounce-back (wall_bbl,
+ *        bounce_back_on_links) and open boundaries may modify it -- and only
+ *        lb_propagation is deferred: the next lb_collide pulls straight from
+ *        that array, halo sites included (no index wrap). Two passes over f
+ *        per step instead of EAGER's three; the mode for walls and colloids.
+ *        Readers of f AFTER lb_propagation need lbmi_lb_flush. */
 typedef enum lbmi_mode_e {
   LBMI_MODE_EAGER = 0,
   LBMI_MODE_FUSED = 1,
-  LBMI_MODE_INPLACE = 2
+  LBMI_MODE_INPLACE = 2,
+  LBMI_MODE_FUSED_HALO = 3
 } lbmi_mode_t;
 
 typedef struct lbmi_options_s {
@@ -246,7 +255,8 @@ int lbmi_lb_run(lbmi_t * lb, const lbmi_hydro_t * hydro, int nsteps);
  *                          the field and its field_grad_compute arrays at
  *                          the interior sites; mobility M gives the
  *                          relaxation rate 2/(1 + 2M) of the phi flux. */
-/* Flat walls and solid sites with bounce-back on links (wall.c), EAGER mode.
+/* Flat walls and solid sites with bounce-back on links (wall.c), EAGER or
+ * FUSED_HALO mode.
  * The step with walls is lb_collide, lb_halo, wall_bbl, lb_propagation
  * (ludwig.c:802-860): "no halo updates between bounce back and propagation".
  *   lbmi_wall_map        wall_init_map (wall.c:1219-1268): MAP_BOUNDARY (1)

@@ -74,10 +74,10 @@ int phi_lb_to_field_ref(field_t * phi, lb_t * lb);
 typedef struct shim_s {
   lb_t * lb;
   lbmi_t * h;
-  int fused;                      /* LBMI_MODE_FUSED in use */
+  int mode;                       /* lbmi_mode_t in use */
 } shim_t;
 
-static shim_t shim_ = {NULL, NULL, 0};
+static shim_t shim_ = {NULL, NULL, LBMI_MODE_EAGER};
 
 #define SHIM_CHECK(lb, call)						\
   do {									\
@@ -145,7 +145,12 @@ static lbmi_t * shim_handle(lb_t * lb) {
     int cartsz[3], coords[3];
     double * f = NULL;
     double * fprime = NULL;
-    const char * mode = getenv("LBMI_MODE");     /* "fused" or "eager" */
+    /* LBMI_MODE = eager (default: f as the reference after every call),
+     * halo (collision and halo as observable as in eager, propagation
+     * deferred: walls and colloids are fine) or fused (halo swap and
+     * propagation deferred: nothing may touch f between lb_collide and
+     * lb_propagation) */
+    const char * mode = getenv("LBMI_MODE");
 
     lbmi_options_default(&opts);
     opts.nvel = lb->model.nvel;
@@ -160,6 +165,7 @@ static lbmi_t * shim_handle(lb_t * lb) {
     opts.halo_scheme = LBMI_HALO_FULL;           /* halo_swap_packed semantics */
     opts.mode = LBMI_MODE_EAGER;
     if (mode && mode[0] == 'f' && lb->ndist == 1) opts.mode = LBMI_MODE_FUSED;
+    if (mode && mode[0] == 'h' && lb->ndist == 1) opts.mode = LBMI_MODE_FUSED_HALO;
 
     SHIM_CHECK(lb, lbmi_create(&opts, &shim_.h));
     /* Ludwig launches all its kernels on the default stream
@@ -167,7 +173,7 @@ static lbmi_t * shim_handle(lb_t * lb) {
      * kernels on either side of each call are ordered without extra syncs */
     SHIM_CHECK(lb, lbmi_set_stream(shim_.h, NULL));
     shim_.lb = lb;
-    shim_.fused = (opts.mode == LBMI_MODE_FUSED);
+    shim_.mode = opts.mode;
 
     shim_device_f(lb, &f, &fprime);
     SHIM_CHECK(lb, lbmi_lb_bind(shim_.h, f, fprime));
@@ -326,9 +332,10 @@ int wall_bbl(wall_t * wall) {
   if (wall->param->slip.active || !shim_supported(wall->lb)) {
     return wall_bbl_ref(wall);
   }
-  if (shim_.fused) {
+  if (shim_.mode == LBMI_MODE_FUSED) {
     pe_fatal(wall->pe, "liblbmi: LBMI_MODE=fused cannot be used with walls "
-	     "(bounce-back acts between lb_halo and lb_propagation)\n");
+	     "(bounce-back acts between lb_halo and lb_propagation): use "
+	     "LBMI_MODE=halo\n");
   }
 
   {

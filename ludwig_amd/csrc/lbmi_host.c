@@ -58,6 +58,7 @@ struct lbmi_s {
   int layout_swapped;                /* INPLACE: population p lives in slot opp(p) */
   int early_prop;                    /* INPLACE: k_aa_odd already propagated this step */
   int halo_seen;                     /* INPLACE: lb_halo called while early_prop */
+  int halo_done;                     /* FUSED_HALO: the pending halo is in f already */
   int nt_store_mode;                 /* -1 auto, else the lbmi_tune value */
   int use_blocked;                   /* FUSED, 1 GPU: keep the deferred state in
 					the blocked order (lbmi_tune "blocked") */
@@ -235,7 +236,7 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
 		     opts->cartsz, opts->cartrank);
   }
   if (opts->mode != LBMI_MODE_EAGER && opts->mode != LBMI_MODE_FUSED &&
-      opts->mode != LBMI_MODE_INPLACE) {
+      opts->mode != LBMI_MODE_INPLACE && opts->mode != LBMI_MODE_FUSED_HALO) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "mode = %d", opts->mode);
   }
   if (opts->halo_scheme != LBMI_HALO_FULL &&
@@ -884,6 +885,7 @@ int lbmi_lb_bind(lbmi_t * lb, double * f, double * fprime) {
   lb->layout_swapped = 0;
   lb->early_prop = 0;
   lb->halo_seen = 0;
+  lb->halo_done = 0;
   lb->blocked = 0;
 
   if (f == NULL) {
@@ -930,7 +932,8 @@ static int lbmi_inplace(const lbmi_t * lb) {
 
 static int lbmi_deferred(const lbmi_t * lb) {
   return (lb->opts.mode == LBMI_MODE_FUSED ||
-	  lb->opts.mode == LBMI_MODE_INPLACE);
+	  lb->opts.mode == LBMI_MODE_INPLACE ||
+	  lb->opts.mode == LBMI_MODE_FUSED_HALO);
 }
 
 /* The blocked order of a deferred state (lbmi_kernels.hip, faddr): single
@@ -976,7 +979,13 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
   ifail = lbmi_time_begin(lb);
   if (ifail) return ifail;
 
-  if (lb->opts.cartsz == 1 && !lb->have_comm) {
+  if (lb->opts.mode == LBMI_MODE_FUSED_HALO) {
+    /* the halo swap has been done (and anything may have bounced back into
+     * it): pull from the array as it is, halo sites included */
+    KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, 0, 0,
+				    xlo, xhi, 0, -1, lb->stream));
+  }
+  else if (lb->opts.cartsz == 1 && !lb->have_comm) {
     /* lay: 0 SoA -> SoA; 1 SoA -> blocked; 2 blocked -> blocked */
     int lay = lbmi_blocked_ok(lb) ? (lb->blocked ? 2 : 1) : 0;
     if (lay == 0 && lb->blocked) {
@@ -1127,6 +1136,7 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
     }
     lb->pending_prop = 0;
     lb->pending_halo = 0;
+    lb->halo_done = 0;
     return lbmi_fused_step(lb, &h);
   }
 
@@ -1329,10 +1339,12 @@ int lbmi_wall_bbl_arrays(lbmi_t * lb, int nlink, const int * linki,
   double ma[LBMI_NVEL_MAX*LBMI_NVEL_MAX];
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
-  if (lb->opts.mode != LBMI_MODE_EAGER) {
+  if (lb->opts.mode != LBMI_MODE_EAGER &&
+      !(lb->opts.mode == LBMI_MODE_FUSED_HALO && !lb->pending_prop)) {
     /* bounce-back acts on the post-collision state between lb_halo and
      * lb_propagation: that state must exist (ludwig.c:836-858) */
-    return lbmi_fail(LBMI_ERR_STATE, "walls need LBMI_MODE_EAGER");
+    return lbmi_fail(LBMI_ERR_STATE, "walls need LBMI_MODE_EAGER or "
+		     "LBMI_MODE_FUSED_HALO (before lb_propagation)");
   }
   if (nlink == 0) return 0;                          /* wall.c:967 */
   if (nlink < 0 || !linki || !linkj || !linkp || !linku || !ubot || !utop || !fnet) {
@@ -1472,6 +1484,12 @@ int lbmi_lb_halo(lbmi_t * lb) {
     if (lb->pending_prop) {
       return lbmi_fail(LBMI_ERR_STATE, "lb_halo while a propagation is pending");
     }
+    if (lb->opts.mode == LBMI_MODE_FUSED_HALO) {
+      /* eager: f gets its halo now; only the propagation will be deferred */
+      int ifail = lbmi_halo(lb, lb->f, lb->opts.halo_scheme);
+      if (ifail) return ifail;
+      lb->halo_done = 1;
+    }
     lb->pending_halo = 1;
     return 0;
   }
@@ -1575,9 +1593,12 @@ int lbmi_lb_flush(lbmi_t * lb) {
   }
 
   if (lb->pending_halo) {
-    int ifail = lbmi_halo(lb, lb->f, lb->opts.halo_scheme);
-    if (ifail) return ifail;
+    if (!lb->halo_done) {
+      int ifail = lbmi_halo(lb, lb->f, lb->opts.halo_scheme);
+      if (ifail) return ifail;
+    }
     lb->pending_halo = 0;
+    lb->halo_done = 0;
   }
   if (lb->pending_prop) {
     KCHECK(lbmi_k_propagate(&lb->kp, lb->f, lb->fprime, lb->stream));
@@ -1606,7 +1627,7 @@ int lbmi_lb_run(lbmi_t * lb, const lbmi_hydro_t * hydro, int nsteps) {
 
 int lbmi_lb_state(lbmi_t * lb, int state[3]) {
   if (lb == NULL || state == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
-  state[0] = (lb->pending_halo || lb->halo_seen);
+  state[0] = ((lb->pending_halo && !lb->halo_done) || lb->halo_seen);
   state[1] = (lb->pending_prop || lb->early_prop);
   state[2] = lb->blocked ? 1 : (lb->layout_swapped ? 2 : 0);
   return 0;
@@ -1630,6 +1651,7 @@ int lbmi_lb_memcpy_h2d(lbmi_t * lb, const double * f_host) {
   lb->layout_swapped = 0;
   lb->early_prop = 0;
   lb->halo_seen = 0;
+  lb->halo_done = 0;
   lb->blocked = 0;
   HIPCHECK(hipMemcpyAsync(lb->f, f_host, sz, hipMemcpyHostToDevice, lb->stream));
   HIPCHECK(hipStreamSynchronize(lb->stream));
@@ -1852,6 +1874,7 @@ int lbmi_lb_records_unpack(lbmi_t * lb, const double * records) {
   lb->pending_prop = 0;
   lb->early_prop = 0;
   lb->halo_seen = 0;
+  lb->halo_done = 0;
   lb->blocked = 0;
   if (lb->layout_swapped) {
     lb->layout_swapped = 0;

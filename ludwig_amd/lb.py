@@ -20,10 +20,10 @@ import numpy as np
 from . import lib as _l
 
 M10, BGK, TRT = 0, 1, 2                    # lb_relaxation_enum_t
-EAGER, FUSED, INPLACE = 0, 1, 2            # lbmi_mode_t
+EAGER, FUSED, INPLACE, FUSED_HALO = 0, 1, 2, 3   # lbmi_mode_t
 # Python-side shorthand: FUSED with the deferred state kept in the reference's
 # SoA order (lbmi_tune "blocked" = 0) instead of the default blocked order
-FUSED_SOA = 3
+FUSED_SOA = 101
 HALO_FULL, HALO_REDUCED = 0, 2             # lbmi_halo_t
 _SCHEMES = {"m10": M10, "bgk": BGK, "trt": TRT}
 

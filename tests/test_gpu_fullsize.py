@@ -86,7 +86,7 @@ def test_modes_agree_256():
     nsteps = 4
     res = []
     for mode in (ludwig_amd.EAGER, ludwig_amd.FUSED, ludwig_amd.INPLACE,
-                 ludwig_amd.FUSED_SOA):
+                 ludwig_amd.FUSED_SOA, ludwig_amd.FUSED_HALO):
         lb = _setup(mode, (1e-6, 0.0, 0.0))
         hy = ludwig_amd.Hydro(lb.nall, lb.device)
         for _ in range(nsteps):
@@ -95,7 +95,7 @@ def test_modes_agree_256():
         lb.synchronize()
         res.append((lb.f[:, 1:-1, 1:-1, 1:-1].clone(), hy.u.clone()))
         lb.free()
-    for k in (1, 2, 3):
+    for k in (1, 2, 3, 4):
         d = float((res[k][0] - res[0][0]).abs().max() / res[0][0].abs().max())
         assert d < 1e-14
         assert float((res[k][1][:, 1:-1, 1:-1, 1:-1]

@@ -128,7 +128,7 @@ def test_reduced_halo_same_interior(name):
 
 # --- whole time steps: EAGER and FUSED against the reference -----------------
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "fused_soa"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 101, 3], ids=["eager", "fused", "inplace", "fused_soa", "fused_halo"])
 @pytest.mark.parametrize("halo_scheme", [0, 2], ids=["full", "reduced"])
 @pytest.mark.parametrize("name", golden_names())
 def test_steps_vs_reference(name, mode, halo_scheme):
@@ -165,7 +165,7 @@ def test_fused_equals_eager_bitwise_inputs(name):
     meta = g["meta"]
     h = meta["nhalo"]
     out = []
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 1, 2, 101, 3):
         lb = make_lb(meta, mode=mode)
         hy = make_hydro(lb, g, meta)
         lb.lb_memcpy_h2d(g["f0"])
@@ -176,9 +176,10 @@ def test_fused_equals_eager_bitwise_inputs(name):
     assert relmax(out[1], out[0]) < 1e-14
     assert relmax(out[2], out[0]) < 1e-14
     assert np.array_equal(out[3], out[1])       # blocked / SoA order: same arithmetic
+    assert relmax(out[4], out[0]) < 1e-14       # FUSED_HALO
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3], ids=["fused", "inplace", "fused_soa"])
+@pytest.mark.parametrize("mode", [1, 2, 101, 3], ids=["fused", "inplace", "fused_soa", "fused_halo"])
 @pytest.mark.parametrize("name", ["q19_bgk_ffield", "q27_m10_ffield", "q19_m10_solid"])
 def test_flush_at_every_call_point(name, mode):
     """A device-to-host copy (which flushes) placed after ANY call of ANY
@@ -291,7 +292,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "fused_soa"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 101, 3], ids=["eager", "fused", "inplace", "fused_soa", "fused_halo"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "q%d-%s-%s" % (c[0], "x".join(map(str, c[1])), c[3]))
 def test_seeded_vs_oracle(case, mode):
     import ludwig_amd
@@ -356,7 +357,7 @@ def test_field_halo(nhalo):
 
 # --- reference regression log on the device ---------------------------------
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "fused_soa"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 101, 3], ids=["eager", "fused", "inplace", "fused_soa", "fused_halo"])
 def test_regression_log_1dp(mode):
     import ludwig_amd
     case = load_expected()["serial-dist-1dp"]
@@ -539,7 +540,7 @@ def test_blocked_order_is_invisible(nvel, nlocal, nhalo):
         lb.free()
         return seen, final, u, orders
 
-    _, ref_final, ref_u, ref_orders = run(3, None)     # FUSED, SoA order
+    _, ref_final, ref_u, ref_orders = run(101, None)   # FUSED, SoA order
     _, final, u, orders = run(1, None)                 # FUSED, default
     assert 1 not in ref_orders
     assert 1 in orders, "the blocked order was never used"
@@ -625,7 +626,7 @@ def test_rccl_self_ring_blocked_slab(nvel, nlocal, concurrent):
 from tests.common import golden_visc_names  # noqa: E402
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "fused_soa"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 101, 3], ids=["eager", "fused", "inplace", "fused_soa", "fused_halo"])
 @pytest.mark.parametrize("name", golden_visc_names())
 def test_local_viscosity_vs_reference(name, mode):
     """lb_collide with visc != NULL (collision.c:386-404): the rates of every

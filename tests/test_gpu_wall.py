@@ -10,11 +10,11 @@ from oracle import lb_oracle as lbo                                    # noqa: E
 from tests.common import golden_wall_names, interior, load_golden, relmax  # noqa: E402
 
 
-def _setup(g):
+def _setup(g, mode=0):
     import ludwig_amd
     import torch
     meta = g["meta"]
-    lb = ludwig_amd.LB(meta["nvel"], tuple(meta["nlocal"]), 1)
+    lb = ludwig_amd.LB(meta["nvel"], tuple(meta["nlocal"]), 1, mode=mode)
     lb.relaxation_set("m10", meta["eta"], meta["zeta"])
     st0 = np.zeros(lb.nall, dtype=np.int8)
     if meta["solid"]:
@@ -39,10 +39,14 @@ def test_wall_map_and_links_exact(name):
     lb.free()
 
 
+@pytest.mark.parametrize("mode", [0, 3], ids=["eager", "fused_halo"])
 @pytest.mark.parametrize("name", golden_wall_names())
-def test_wall_steps_vs_reference(name):
+def test_wall_steps_vs_reference(name, mode):
+    """EAGER: three stages. FUSED_HALO: lb_collide and lb_halo leave the
+    reference's state for the bounce-back; only the propagation is deferred
+    into the next collision."""
     g = load_golden(name)
-    lb, hy, meta = _setup(g)
+    lb, hy, meta = _setup(g, mode)
     lb.wall_map(meta["isboundary"], hy.status)
     lb.wall_links_build(hy.status, meta["isboundary"])
     lb.wall_velocity_set(meta["ubot"], meta["utop"])
@@ -68,7 +72,8 @@ def test_wall_steps_vs_reference(name):
     lb.free()
 
 
-def test_couette_between_moving_walls():
+@pytest.mark.parametrize("mode", [0, 3], ids=["eager", "fused_halo"])
+def test_couette_between_moving_walls(mode):
     """Walls at z = 0, Lz+1 moving with -/+ u_w along x: the flow relaxes to
     the linear Couette profile u_x(z) = u_w (2 z - Lz - 1)/Lz of half-way
     bounce-back (walls half a site outside the first/last fluid node), and
@@ -77,7 +82,7 @@ def test_couette_between_moving_walls():
     import torch
     n = (4, 4, 16)
     uw = 0.01
-    lb = ludwig_amd.LB(19, n, 1)
+    lb = ludwig_amd.LB(19, n, 1, mode=mode)
     lb.relaxation_set("bgk", 1.0 / 6.0, 1.0 / 6.0)      # tau = 1
     hy = ludwig_amd.Hydro(lb.nall, lb.device, status=np.zeros(lb.nall, dtype=np.int8))
     torch.cuda.synchronize()
@@ -114,6 +119,17 @@ def test_wall_needs_eager_and_links():
     lb.wall_links_build(hy.status, (1, 0, 0))
     with pytest.raises(ludwig_amd.LbmiError):
         lb.wall_bbl()                                  # FUSED: no such state
+    lb.free()
+    lb = ludwig_amd.LB(19, (4, 4, 4), 1, mode=ludwig_amd.FUSED_HALO)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, status=np.zeros(lb.nall, dtype=np.int8))
+    lb.wall_map((1, 0, 0), hy.status)
+    lb.wall_links_build(hy.status, (1, 0, 0))
+    lb.lb_collide(hy)
+    lb.lb_halo()
+    lb.wall_bbl()                                      # the state exists
+    lb.lb_propagation()
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.wall_bbl()                                  # too late: deferred
     lb.free()
 
 
