@@ -4,9 +4,9 @@
  *
  * Builds a uniform-flow D3Q19 state (the reference's lb_init_uniform,
  * distribution_rt.c:504-533, i.e. the regression case serial-dist-3du),
- * runs N steps of lb_collide / lb_halo / lb_propagation in EAGER, FUSED and
- * INPLACE mode and checks the conserved quantities the reference prints for
- * that case (tests/regression/d3q19-short/serial-dist-3du.log):
+ * runs N steps of lb_collide / lb_halo / lb_propagation in EAGER, FUSED,
+ * INPLACE and FUSED_HALO mode and checks the conserved quantities the
+ * reference prints for that case (tests/regression/d3q19-short/serial-dist-3du.log):
  *   [rho] 32768.00 1.00000000000 ...   momentum 6.5536e+01 9.8304e+01 1.31072e+02
  *
  * Build + run (on a MI355X): see tests/test_gpu_c_abi.py.
@@ -142,6 +142,7 @@ int main(void) {
   if (run_mode(LBMI_MODE_EAGER, "eager")) return 1;
   if (run_mode(LBMI_MODE_FUSED, "fused")) return 1;
   if (run_mode(LBMI_MODE_INPLACE, "inplace")) return 1;
+  if (run_mode(LBMI_MODE_FUSED_HALO, "fused_halo")) return 1;
   printf("C-ABI test passed\n");
   return 0;
 }
