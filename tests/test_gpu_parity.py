@@ -388,7 +388,7 @@ def test_regression_log_1dp(mode):
 # --- RCCL ring on one GPU: rank 0 is its own neighbour ----------------------
 
 @pytest.mark.parametrize("packed", [0, 1], ids=["zerocopy", "packed"])
-@pytest.mark.parametrize("mode", [0, 1], ids=["eager", "fused"])
+@pytest.mark.parametrize("mode", [0, 1, 3], ids=["eager", "fused", "fused_halo"])
 def test_rccl_self_ring(mode, packed):
     """With a 1-rank communicator the X halo goes through pack ->
     ncclSend/ncclRecv (to self) -> unpack instead of the device-side copy;
