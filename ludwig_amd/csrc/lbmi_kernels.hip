@@ -854,8 +854,11 @@ void k_relayout(lbmi_kparam_t kp, const double * __restrict__ src,
  * tests/unit/test_lb_model.c:103-140). Periodic directions are wrapped by
  * index arithmetic on both the pull and the push; y/z halo lanes idle (their
  * lines are resident from the neighbouring lanes' loads, so the gaps in the
- * store streams cost nothing here). SWAPPED_IN = false lets k_aa_odd start
- * from the normal layout (after a flush).
+ * store streams cost nothing here). Pulling from the NORMAL order instead
+ * (template argument SWAPPED_IN = false) is not race-free in place -- a thread
+ * would push into locations its neighbours still have to pull from -- and is
+ * never launched: after a flush the launcher swaps the slots first
+ * (k_aa_unswap, a per-site involution).
  */
 
 template <int NVEL> __host__ __device__ constexpr int opp(int p) {
@@ -2376,18 +2379,24 @@ extern "C" int lbmi_k_aa_even(const lbmi_kparam_t * kp, double * f,
   return (int) hipErrorInvalidValue;
 }
 
+extern "C" int lbmi_k_aa_unswap(const lbmi_kparam_t * kp, double * f,
+				void * stream);
+
 extern "C" int lbmi_k_aa_odd(const lbmi_kparam_t * kp, double * f,
 			     const lbmi_hydro_dev_t * h, int wrapmask,
 			     int swapped_in, void * stream) {
   hipStream_t st = (hipStream_t) stream;
-  if (kp->nvel == 19) {
-    return swapped_in ? launch_aa_odd<19, true>(*kp, f, *h, wrapmask, st)
-      : launch_aa_odd<19, false>(*kp, f, *h, wrapmask, st);
+  if (!swapped_in) {
+    /* The pull-collide-push is race-free only from the slot-swapped order
+     * (every thread then reads and writes the SAME addresses): from the
+     * normal order a thread would push into locations its neighbours still
+     * have to pull from. After a flush, swap the slots first (a per-site
+     * permutation, in place). */
+    int ifail = lbmi_k_aa_unswap(kp, f, stream);
+    if (ifail) return ifail;
   }
-  if (kp->nvel == 27) {
-    return swapped_in ? launch_aa_odd<27, true>(*kp, f, *h, wrapmask, st)
-      : launch_aa_odd<27, false>(*kp, f, *h, wrapmask, st);
-  }
+  if (kp->nvel == 19) return launch_aa_odd<19, true>(*kp, f, *h, wrapmask, st);
+  if (kp->nvel == 27) return launch_aa_odd<27, true>(*kp, f, *h, wrapmask, st);
   return (int) hipErrorInvalidValue;
 }
 

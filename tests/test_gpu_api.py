@@ -213,3 +213,85 @@ def test_nt_store_auto_and_explicit_agree():
         lb.free()
     for o in out[1:]:
         assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3], ids=["fused", "inplace", "fused_halo"])
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("LBMI_FUZZ_SEEDS", "12"))))
+def test_random_call_sequences_match_eager(mode, seed, tmp_path):
+    """State-machine fuzz: a random but legal interleaving of the step calls
+    with observers (device-to-host copies, moments, record packs, file
+    round trips, lbmi_lb_run) and tuning switches; every observation must be
+    what EAGER shows at the same point of the same sequence."""
+    import ludwig_amd
+    rng = np.random.default_rng(1000 + seed)
+    nvel = 19 if seed % 3 else 27
+    nlocal = (10, 14, 14) if seed % 2 else (9, 7, 12)     # whole blocks / ragged
+    p = lbo.make_param(nvel, nlocal, 1, "m10", 0.1, 0.3, 1.0, (1e-6, 0, -2e-6))
+    f0 = lbo.init_synthetic(p)
+    nsteps = 6
+    # the script: one list of actions, generated once, run in both modes
+    script = []
+    for n in range(nsteps):
+        for stage in ("collide", "halo", "propagation"):
+            script.append((stage,))
+            r = rng.random()
+            if r < 0.15:
+                script.append(("d2h",))
+            elif r < 0.25:
+                script.append(("moments",))
+            elif r < 0.32:
+                script.append(("records",))
+        r = rng.random()
+        if r < 0.2:
+            script.append(("tune", "blocked", int(rng.integers(0, 2))))
+        elif r < 0.35:
+            script.append(("tune", "nt_store", int(rng.integers(-1, 4))))
+        elif r < 0.45:
+            script.append(("tune", "xcd_group", int(rng.choice([0, 1, 4, 32]))))
+        elif r < 0.55:
+            script.append(("io", n))
+        elif r < 0.7:
+            script.append(("run", int(rng.integers(1, 4))))
+
+    def play(run_mode):
+        lb = ludwig_amd.LB(nvel, nlocal, 1, mode=run_mode)
+        lb.relaxation_set("m10", 0.1, 0.3)
+        lb.body_force_set((1e-6, 0, -2e-6))
+        hy = ludwig_amd.Hydro(lb.nall, lb.device)
+        lb.lb_memcpy_h2d(f0)
+        seen = []
+        for act in script:
+            if act[0] == "collide":
+                lb.lb_collide(hy)
+            elif act[0] == "halo":
+                lb.lb_halo()
+            elif act[0] == "propagation":
+                lb.lb_propagation()
+            elif act[0] == "d2h":
+                seen.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+            elif act[0] == "moments":
+                seen.append(lb.moments())
+            elif act[0] == "records":
+                seen.append(lb.lb_io_aggr_pack().copy())
+            elif act[0] == "tune":
+                lb.tune(act[1], act[2])
+            elif act[0] == "io":
+                lb.lb_io_write(tmp_path, act[1])
+                lb.lb_io_read(tmp_path, act[1])
+            elif act[0] == "run":
+                lb.run(hy, act[1])
+        seen.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+        seen.append(host_u(lb, hy))
+        lb.free()
+        return seen
+
+    def host_u(lb, hy):
+        lb.synchronize()
+        return interior(hy.u.cpu().numpy(), 1).copy()
+
+    ref = play(0)
+    out = play(mode)
+    assert len(ref) == len(out)
+    for k, (a, b) in enumerate(zip(ref, out)):
+        scale = max(1.0, float(np.max(np.abs(a))))
+        assert np.max(np.abs(np.asarray(a) - np.asarray(b))) < 1e-13 * scale, (k, script)
