@@ -215,6 +215,15 @@ def test_nt_store_auto_and_explicit_agree():
         assert np.array_equal(o[0], out[0][0]) and np.array_equal(o[1], out[0][1])
 
 
+@pytest.mark.parametrize("mode", [1, 3], ids=["fused", "fused_halo"])
+@pytest.mark.parametrize("seed", range(6))
+def test_random_call_sequences_self_ring(mode, seed, tmp_path):
+    """The same fuzz on the slab path: the X halo through a 1-rank RCCL
+    ring (interior / exchange / boundary planes, blocked order where the
+    lattice allows it)."""
+    _fuzz(mode, 500 + seed, tmp_path, ring=True)
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3], ids=["fused", "inplace", "fused_halo"])
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("LBMI_FUZZ_SEEDS", "12"))))
 def test_random_call_sequences_match_eager(mode, seed, tmp_path):
@@ -222,6 +231,10 @@ def test_random_call_sequences_match_eager(mode, seed, tmp_path):
     with observers (device-to-host copies, moments, record packs, file
     round trips, lbmi_lb_run) and tuning switches; every observation must be
     what EAGER shows at the same point of the same sequence."""
+    _fuzz(mode, seed, tmp_path, ring=False)
+
+
+def _fuzz(mode, seed, tmp_path, ring):
     import ludwig_amd
     rng = np.random.default_rng(1000 + seed)
     nvel = 19 if seed % 3 else 27
@@ -248,13 +261,18 @@ def test_random_call_sequences_match_eager(mode, seed, tmp_path):
             script.append(("tune", "nt_store", int(rng.integers(-1, 4))))
         elif r < 0.45:
             script.append(("tune", "xcd_group", int(rng.choice([0, 1, 4, 32]))))
+        elif r < 0.5 and ring:
+            script.append(("tune", "x_concurrent", int(rng.integers(0, 2))))
         elif r < 0.55:
             script.append(("io", n))
         elif r < 0.7:
             script.append(("run", int(rng.integers(1, 4))))
 
     def play(run_mode):
-        lb = ludwig_amd.LB(nvel, nlocal, 1, mode=run_mode)
+        lb = ludwig_amd.LB(nvel, nlocal, 1, mode=run_mode,
+                           halo_scheme=2 if ring else 0)
+        if ring:
+            lb.comm_init(ludwig_amd.LB.comm_unique_id())
         lb.relaxation_set("m10", 0.1, 0.3)
         lb.body_force_set((1e-6, 0, -2e-6))
         hy = ludwig_amd.Hydro(lb.nall, lb.device)
