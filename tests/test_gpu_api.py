@@ -242,6 +242,15 @@ def _fuzz(mode, seed, tmp_path, ring):
     p = lbo.make_param(nvel, nlocal, 1, "m10", 0.1, 0.3, 1.0, (1e-6, 0, -2e-6))
     f0 = lbo.init_synthetic(p)
     nsteps = 6
+    # some sequences with a force field, a block of solid sites, a local
+    # viscosity field (the optional inputs of lb_collide)
+    nall = lbo.nall(p)
+    force = 1e-6 * rng.standard_normal((3,) + nall) if seed % 4 == 1 else None
+    status = None
+    if seed % 5 == 2:
+        status = np.zeros(nall, dtype=np.int8)
+        status[2:4, 2:4, 2:5] = 1
+    eta = 0.1 * (1.0 + 0.3 * rng.random(nall)) if seed % 7 == 3 else None
     # the script: one list of actions, generated once, run in both modes
     script = []
     for n in range(nsteps):
@@ -275,7 +284,8 @@ def _fuzz(mode, seed, tmp_path, ring):
             lb.comm_init(ludwig_amd.LB.comm_unique_id())
         lb.relaxation_set("m10", 0.1, 0.3)
         lb.body_force_set((1e-6, 0, -2e-6))
-        hy = ludwig_amd.Hydro(lb.nall, lb.device)
+        hy = ludwig_amd.Hydro(lb.nall, lb.device, force=force, status=status,
+                              eta=eta)
         lb.lb_memcpy_h2d(f0)
         seen = []
         for act in script:
@@ -288,7 +298,7 @@ def _fuzz(mode, seed, tmp_path, ring):
             elif act[0] == "d2h":
                 seen.append(interior(lb.lb_memcpy_d2h(), 1).copy())
             elif act[0] == "moments":
-                seen.append(lb.moments())
+                seen.append(lb.moments(hy.status))
             elif act[0] == "records":
                 seen.append(lb.lb_io_aggr_pack().copy())
             elif act[0] == "tune":
