@@ -216,8 +216,8 @@ def main():
 
     fe = None
     if args.fe == "symmetric":
-        if world > 1 or args.nhalo < 2:
-            raise SystemExit("--fe symmetric: 1 GPU and --nhalo 2")
+        if args.nhalo < 2:
+            raise SystemExit("--fe symmetric needs --nhalo 2")
         if hydro is None:
             raise SystemExit("--fe symmetric needs --hydro 1")
         g = torch.Generator(device=lb.device)

@@ -337,7 +337,8 @@ int lbmi_hydro_field_set(lbmi_t * lb, double * field, int ncomp,
 
 /* field_halo (field.c:field_halo -> halo_swap_packed) for an SoA field of
  * nel components whose halo swap is nswap layers wide (phi with the
- * symmetric free energy: 2). Single rank. */
+ * symmetric free energy: 2). With slabs the X planes of every layer travel
+ * over RCCL, device to device. */
 int lbmi_field_halo_n(lbmi_t * lb, int nel, int nswap, double * data);
 
 /* The finite-difference choices of the free-energy sector, as the input

@@ -681,7 +681,8 @@ int lbmi_propagate_collide(lbmi_t * lb, const double * f, double * fprime,
  *****************************************************************************/
 
 static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
-			   double * data, int blocked, hipStream_t st) {
+			   double * data, int blocked, int layer,
+			   hipStream_t st) {
 
   size_t psz = (size_t) lb->kp.strx;
   size_t ns = (size_t) lb->kp.nsite;
@@ -702,10 +703,10 @@ static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
      * of the operations towards one peer is the same on both sides (lo
      * components first, then hi), which is what matches sends to receives,
      * also when prev == next (2 ranks) or prev == next == self (1 rank). */
-    size_t last = (size_t) (nh + lb->kp.nlocal[X] - 1)*psz;
-    size_t first = (size_t) nh*psz;
-    size_t halo_lo = (size_t) (nh - 1)*psz;
-    size_t halo_hi = (size_t) (nh + lb->kp.nlocal[X])*psz;
+    size_t last = (size_t) (nh + lb->kp.nlocal[X] - 1 - layer)*psz;
+    size_t first = (size_t) (nh + layer)*psz;
+    size_t halo_lo = (size_t) (nh - 1 - layer)*psz;
+    size_t halo_hi = (size_t) (nh + lb->kp.nlocal[X] + layer)*psz;
     NCCLCHECK(ncclGroupStart());
     for (int k = 0; k < sel->nlo; k++) {
       double * d = data + ns*(size_t) sel->lo[k];
@@ -732,7 +733,8 @@ static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
 
     /* sendlo: first interior plane, components sel->hi -> prev's high halo
      * sendhi: last interior plane, components sel->lo  -> next's low halo */
-    KCHECK(lbmi_k_halo_pack_x(&lb->kp, sel, data, lb->sendlo, lb->sendhi, blocked, st));
+    KCHECK(lbmi_k_halo_pack_x(&lb->kp, sel, data, lb->sendlo, lb->sendhi, blocked,
+			      layer, st));
 
     NCCLCHECK(ncclGroupStart());
     NCCLCHECK(ncclSend(lb->sendhi, nlo, ncclDouble, next, lb->comm, st));
@@ -741,7 +743,8 @@ static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
     NCCLCHECK(ncclRecv(lb->recvhi, nhi, ncclDouble, next, lb->comm, st));
     NCCLCHECK(ncclGroupEnd());
 
-    KCHECK(lbmi_k_halo_unpack_x(&lb->kp, sel, data, lb->recvlo, lb->recvhi, blocked, st));
+    KCHECK(lbmi_k_halo_unpack_x(&lb->kp, sel, data, lb->recvlo, lb->recvhi, blocked,
+				layer, st));
   }
 
   return 0;
@@ -751,7 +754,7 @@ static int lbmi_halo_generic(lbmi_t * lb, const lbmi_halo_sel_t sel[3],
 			     double * data, hipStream_t st) {
   int ifail;
   if (lb->opts.cartsz > 1 || lb->have_comm) {
-    ifail = lbmi_x_exchange(lb, &sel[X], data, 0, st);
+    ifail = lbmi_x_exchange(lb, &sel[X], data, 0, 0, st);
     if (ifail) return ifail;
   }
   else {
@@ -799,7 +802,7 @@ int lbmi_halo_x_pack(lbmi_t * lb, const double * f, int scheme,
   sel = lbmi_sel(lb, scheme);
   if (sel == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
   HIPCHECK(hipSetDevice(lb->device));
-  KCHECK(lbmi_k_halo_pack_x(&lb->kp, &sel[X], f, sendlo, sendhi, 0, lb->stream));
+  KCHECK(lbmi_k_halo_pack_x(&lb->kp, &sel[X], f, sendlo, sendhi, 0, 0, lb->stream));
   return 0;
 }
 
@@ -810,7 +813,7 @@ int lbmi_halo_x_unpack(lbmi_t * lb, double * f, int scheme,
   sel = lbmi_sel(lb, scheme);
   if (sel == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
   HIPCHECK(hipSetDevice(lb->device));
-  KCHECK(lbmi_k_halo_unpack_x(&lb->kp, &sel[X], f, recvlo, recvhi, 0, lb->stream));
+  KCHECK(lbmi_k_halo_unpack_x(&lb->kp, &sel[X], f, recvlo, recvhi, 0, 0, lb->stream));
   return 0;
 }
 
@@ -1031,7 +1034,7 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
 
     /* comm stream: exchange the boundary planes into the x halo planes */
     HIPCHECK(hipStreamWaitEvent(lb->comm_stream, lb->ev_ready, 0));
-    ifail = lbmi_x_exchange(lb, &lb->sel_reduced[X], lb->f, lb->blocked,
+    ifail = lbmi_x_exchange(lb, &lb->sel_reduced[X], lb->f, lb->blocked, 0,
 			    lb->comm_stream);
     if (ifail) return ifail;
     HIPCHECK(hipEventRecord(lb->ev_halo, lb->comm_stream));
@@ -1711,10 +1714,6 @@ int lbmi_field_halo_n(lbmi_t * lb, int nel, int nswap, double * data) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "nswap = %d (1..nhalo = %d)", nswap,
 		     lb->kp.nhalo);
   }
-  if (lb->opts.cartsz > 1) {
-    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "lbmi_field_halo_n: single rank "
-		     "only (use lbmi_field_halo for width 1 with slabs)");
-  }
   for (int d = 0; d < 3; d++) {
     if (nswap > lb->kp.nlocal[d]) {
       return lbmi_fail(LBMI_ERR_ARGUMENT, "nswap exceeds nlocal[%d]", d);
@@ -1726,7 +1725,17 @@ int lbmi_field_halo_n(lbmi_t * lb, int nel, int nswap, double * data) {
     sel.lo[sel.nlo++] = (int8_t) n;
     sel.hi[sel.nhi++] = (int8_t) n;
   }
-  KCHECK(lbmi_k_halo_copy(&lb->kp, X, &sel, data, nswap, lb->stream));
+  if (lb->opts.cartsz > 1 || lb->have_comm) {
+    /* slabs: the X planes of every layer over RCCL (device to device, where
+     * the reference stages them through the host, halo_swap.c:762-881) */
+    for (int layer = 0; layer < nswap; layer++) {
+      int ifail = lbmi_x_exchange(lb, &sel, data, 0, layer, lb->stream);
+      if (ifail) return ifail;
+    }
+  }
+  else {
+    KCHECK(lbmi_k_halo_copy(&lb->kp, X, &sel, data, nswap, lb->stream));
+  }
   KCHECK(lbmi_k_halo_copy(&lb->kp, Y, &sel, data, nswap, lb->stream));
   KCHECK(lbmi_k_halo_copy(&lb->kp, Z, &sel, data, nswap, lb->stream));
   return 0;

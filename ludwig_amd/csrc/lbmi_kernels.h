@@ -105,13 +105,15 @@ int lbmi_k_halo_copy(const lbmi_kparam_t * kp, int dir,
  * (components sel->hi: wanted by the lower neighbour's HIGH halo) into
  * buf_lo and the last interior plane (components sel->lo) into buf_hi;
  * unpack the reverse way. Buffer layout: [component k][plane site].
- * blocked != 0: data is a distribution array in the blocked order. */
+ * blocked != 0: data is a distribution array in the blocked order.
+ * layer: 0 for a width-1 swap; l for the (l+1)-th plane of a wider one. */
 int lbmi_k_halo_pack_x(const lbmi_kparam_t * kp, const lbmi_halo_sel_t * sel,
 		       const double * data, double * buf_lo, double * buf_hi,
-		       int blocked, void * stream);
+		       int blocked, int layer, void * stream);
 int lbmi_k_halo_unpack_x(const lbmi_kparam_t * kp, const lbmi_halo_sel_t * sel,
 			 double * data, const double * buf_lo,
-			 const double * buf_hi, int blocked, void * stream);
+			 const double * buf_hi, int blocked, int layer,
+			 void * stream);
 
 /* Record stream of the distribution files: pack != 0: f -> rec, else
  * rec -> f (interior sites only). rec: ninterior*nvel doubles (device). */

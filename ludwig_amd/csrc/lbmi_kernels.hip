@@ -1120,20 +1120,22 @@ __global__ __launch_bounds__(BLOCK)
 void k_halo_pack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
 		   const double * __restrict__ data,
 		   double * __restrict__ buf_lo, double * __restrict__ buf_hi,
-		   int blocked) {
+		   int blocked, int layer) {
 
+  /* layer l of a swap of several layers: the (l+1)-th interior plane from
+   * either end */
   int j = blockIdx.x*BLOCK + threadIdx.x;
   int psz = kp.strx;
   if (j >= psz) return;
   int k = blockIdx.y;
   const int nh = kp.nhalo;
   if (k < sel.nhi) {
-    size_t i = (size_t) nh*kp.strx + j;
+    size_t i = (size_t) (nh + layer)*kp.strx + j;
     buf_lo[(size_t) k*psz + j] = data[xaddr(kp, blocked, sel.hi[k], i)];
   }
   else {
     int kk = k - sel.nhi;
-    size_t i = (size_t) (nh + kp.nlocal[0] - 1)*kp.strx + j;
+    size_t i = (size_t) (nh + kp.nlocal[0] - 1 - layer)*kp.strx + j;
     buf_hi[(size_t) kk*psz + j] = data[xaddr(kp, blocked, sel.lo[kk], i)];
   }
 }
@@ -1146,7 +1148,8 @@ __global__ __launch_bounds__(BLOCK)
 void k_halo_unpack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
 		     double * __restrict__ data,
 		     const double * __restrict__ buf_lo,
-		     const double * __restrict__ buf_hi, int blocked) {
+		     const double * __restrict__ buf_hi, int blocked,
+		     int layer) {
 
   int j = blockIdx.x*BLOCK + threadIdx.x;
   int psz = kp.strx;
@@ -1157,12 +1160,12 @@ void k_halo_unpack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
    * high halo plane, y/z halo rows nobody pulls from) do not exist */
   const size_t nfull = blocked ? ((size_t) kp.nsite/LBW)*LBW : (size_t) kp.nsite;
   if (k < sel.nlo) {
-    size_t i = (size_t) (nh - 1)*kp.strx + j;
+    size_t i = (size_t) (nh - 1 - layer)*kp.strx + j;
     if (i < nfull) data[xaddr(kp, blocked, sel.lo[k], i)] = buf_lo[(size_t) k*psz + j];
   }
   else {
     int kk = k - sel.nlo;
-    size_t i = (size_t) (nh + kp.nlocal[0])*kp.strx + j;
+    size_t i = (size_t) (nh + kp.nlocal[0] + layer)*kp.strx + j;
     if (i < nfull) data[xaddr(kp, blocked, sel.hi[kk], i)] = buf_hi[(size_t) kk*psz + j];
   }
 }
@@ -2458,14 +2461,14 @@ extern "C" int lbmi_k_halo_copy(const lbmi_kparam_t * kp, int dir,
 extern "C" int lbmi_k_halo_pack_x(const lbmi_kparam_t * kp,
 				  const lbmi_halo_sel_t * sel,
 				  const double * data, double * buf_lo,
-				  double * buf_hi, int blocked,
+				  double * buf_hi, int blocked, int layer,
 				  void * stream) {
   hipStream_t st = (hipStream_t) stream;
   int ncomp = sel->nlo + sel->nhi;
   if (ncomp == 0) return 0;
   dim3 grid((kp->strx + BLOCK - 1)/BLOCK, ncomp), block(BLOCK);
   hipLaunchKernelGGL(k_halo_pack_x, grid, block, 0, st, *kp, *sel, data,
-		     buf_lo, buf_hi, blocked);
+		     buf_lo, buf_hi, blocked, layer);
   return (int) hipGetLastError();
 }
 
@@ -2473,13 +2476,13 @@ extern "C" int lbmi_k_halo_unpack_x(const lbmi_kparam_t * kp,
 				    const lbmi_halo_sel_t * sel,
 				    double * data, const double * buf_lo,
 				    const double * buf_hi, int blocked,
-				    void * stream) {
+				    int layer, void * stream) {
   hipStream_t st = (hipStream_t) stream;
   int ncomp = sel->nlo + sel->nhi;
   if (ncomp == 0) return 0;
   dim3 grid((kp->strx + BLOCK - 1)/BLOCK, ncomp), block(BLOCK);
   hipLaunchKernelGGL(k_halo_unpack_x, grid, block, 0, st, *kp, *sel, data,
-		     buf_lo, buf_hi, blocked);
+		     buf_lo, buf_hi, blocked, layer);
   return (int) hipGetLastError();
 }
 

@@ -332,3 +332,75 @@ def test_drop_regression_log(name, route):
                               lb.moments(), _host(lb, hy.u), h)
             check_drop_report(rep, case["reports"][str(step)])
     lb.free()
+
+
+@pytest.mark.parametrize("nel", [1, 3])
+def test_field_halo_width2_over_rccl_ring(nel):
+    """Width-2 field halo with the X planes of both layers through a 1-rank
+    RCCL ring = the device-side periodic copy, bit for bit."""
+    import ludwig_amd
+    import torch
+    nlocal = (7, 6, 5)
+    rng = np.random.default_rng(8)
+    out = []
+    for ring in (False, True):
+        lb = ludwig_amd.LB(19, nlocal, 2)
+        if ring:
+            lb.comm_init(ludwig_amd.LB.comm_unique_id())
+        a = np.zeros((nel,) + lb.nall)
+        rng2 = np.random.default_rng(8)
+        interior(a, 2)[...] = rng2.random((nel,) + nlocal)
+        t = _dev(lb, a if nel > 1 else a[0])
+        torch.cuda.synchronize()
+        lb.field_halo_n(t, 2)
+        out.append(_host(lb, t).copy())
+        lb.free()
+    assert np.array_equal(out[0], out[1])
+    assert np.count_nonzero(out[0]) == out[0].size
+
+
+def test_binary_fluid_steps_through_rccl_ring():
+    """The whole config-4 step with every X halo (phi width 2, u width 1, the
+    distributions) over a 1-rank RCCL ring: the slab form of the binary
+    fluid, against the oracle."""
+    import ludwig_amd
+    import torch
+    nlocal, h, nsteps = (10, 12, 12), 2, 4
+    a, b, kappa, mob = -0.00625, 0.00625, 0.004, 1.25
+    p = lbo.make_param(19, nlocal, h, "m10", 0.1, 0.3)
+    rng = np.random.default_rng(19)
+    phi0 = np.zeros(lbo.nall(p))
+    interior(phi0, h)[...] = 0.1 * rng.standard_normal(nlocal)
+    f0 = lbo.init_synthetic(p)
+    phi = phi0.copy()
+    f = f0.copy()
+    fp = np.zeros_like(f)
+    u = np.zeros((3,) + phi.shape)
+    rho = np.zeros(phi.shape)
+    for _ in range(nsteps):
+        force = np.zeros((3,) + phi.shape)
+        lbo.field_halo(p, phi, 2)
+        grad, delsq = lbo.grad(p, phi, 7)
+        lbo.symm_force(p, a, b, kappa, phi, grad, delsq, force)
+        lbo.field_halo(p, u, 1)
+        lbo.cahn_hilliard(p, a, b, kappa, mob, phi, delsq, u, order=2)
+        u[...] = 0.0
+        f, fp = lbo.step(p, f, fp, force, None, rho, u)
+
+    lb = ludwig_amd.LB(19, nlocal, h, mode=ludwig_amd.FUSED, halo_scheme=2)
+    lb.comm_init(ludwig_amd.LB.comm_unique_id())
+    lb.relaxation_set("m10", 0.1, 0.3)
+    lb.fe_scheme_set(7, 2)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, force=np.zeros((3,) + phi.shape))
+    pa = _dev(lb, phi0)
+    pb = torch.zeros_like(pa)
+    lb.lb_memcpy_h2d(f0)
+    for _ in range(nsteps):
+        lb.field_halo_n(pa, 2)
+        lb.field_halo_n(hy.u, 1)
+        lb.symmetric_step(a, b, kappa, mob, pa, hy.u, hy.force, pb, accumulate=False)
+        pa, pb = pb, pa
+        lb.step(hy)
+    assert relmax(interior(_host(lb, pa), h), interior(phi, h)) < 1e-12
+    assert relmax(interior(lb.lb_memcpy_d2h(), h), interior(f, h)) < 1e-12
+    lb.free()
