@@ -14,6 +14,11 @@
  *      stats_distribution_print() / distribution_stats_momentum()
  *                        src/stats_distribution.c:55,201
  *
+ *  and, one step out from that path: the
+ *  hydro housekeeping and field halos, the symmetric free-energy coupling
+ *  (gradients, force, Cahn-Hilliard), the distribution files, the
+ *  two-distribution collision and bounce-back on links for flat walls.
+ *
  *  Plain C: pointers, ints and doubles only. All array arguments are DEVICE
  *  pointers (hipMalloc or equivalent) unless stated otherwise. There is no
  *  CPU fallback: every compute entry point launches hand-written HIP kernels
@@ -122,7 +127,7 @@ typedef enum lbmi_mode_e {
 
 typedef struct lbmi_options_s {
   int nvel;                 /* 19 or 27 (lb_data.h:33-44)                    */
-  int ndist;                /* 1 (binary two-distribution LB: unsupported)   */
+  int ndist;                /* 1, or 2 (symmetric_lb: EAGER mode, one rank)  */
   int nlocal[3];            /* local lattice extent (cs_nlocal)              */
   int nhalo;                /* halo width of the allocation (cs_nhalo)       */
   int device;               /* HIP device ordinal, or -1: current device     */
