@@ -66,6 +66,9 @@ def parse():
                     help="phi: force + Cahn-Hilliard in one pass straight from "
                     "phi; grad: gradient arrays first (lbmi_field_grad), then "
                     "the one pass reading them")
+    ap.add_argument("--fe-halos", type=int, default=0,
+                    help="1: keep the field halo swaps of phi and u (the "
+                    "reference's structure) on one GPU as well")
     ap.add_argument("--selfring", type=int, default=0,
                     help="1 GPU only: route the X halo through a 1-rank RCCL "
                     "ring (exercises the N>1 step path: pack, send/recv, "
@@ -234,6 +237,8 @@ def main():
             fe["delsq"] = torch.zeros(lb.nall, dtype=torch.float64,
                                       device=lb.device)
         lb.fe_scheme_set(args.fe_grad, args.fe_order)
+        fe["periodic"] = (world == 1 and not args.selfring
+                          and args.fe_route == "phi" and not args.fe_halos)
         torch.cuda.synchronize()
 
     def fe_step():
@@ -241,6 +246,14 @@ def main():
         # hydro_f_zero is absorbed (the force kernel overwrites: no other
         # contribution exists in this configuration) and hydro_u_zero is
         # redundant on an all-fluid lattice (lb_collide writes u everywhere).
+        if fe["periodic"]:
+            # one rank: the pass wraps the periodic box by index, so neither
+            # field_halo(phi) nor hydro_u_halo is needed
+            lb.symmetric_step_periodic(fe["a"], fe["b"], fe["kappa"],
+                                       fe["mobility"], fe["phi"], hydro.u,
+                                       hydro.force, fe["phi2"], accumulate=False)
+            fe["phi"], fe["phi2"] = fe["phi2"], fe["phi"]
+            return
         lb.field_halo_n(fe["phi"], 2)                           # field_halo
         lb.field_halo_n(hydro.u, 1)                             # hydro_u_halo
         # phi_force_calculation + phi_cahn_hilliard, one pass over phi
@@ -379,8 +392,10 @@ def main():
                 "order": order,
                 "hydro_io": bool(args.hydro),
                 "free_energy": args.fe if args.fe == "none" else
-                "%s (%d-point gradients, advection order %d, from %s)"
-                % (args.fe, args.fe_grad, args.fe_order, args.fe_route),
+                "%s (%d-point gradients, advection order %d, from %s%s)"
+                % (args.fe, args.fe_grad, args.fe_order, args.fe_route,
+                   ", periodic wrap by index instead of field halos"
+                   if fe["periodic"] else ""),
                 "decomposition": "x-slab %d_1_1" % world
                                  + (" (1-rank RCCL ring)" if args.selfring else ""),
                 "halo": "index wrap (1 GPU); reduced X planes over RCCL (N>1)",

@@ -400,6 +400,17 @@ int lbmi_symmetric_step(lbmi_t * lb, double a, double b, double kappa,
 			double mobility, const double * phi, const double * u,
 			double * force, double * phi_out, int accumulate);
 
+/* lbmi_symmetric_step on ONE rank with periodic boundaries, without halo
+ * swaps of phi and u in front of it: the kernel takes the halo layers of
+ * phi from the periodic images and u across a face from the opposite face
+ * (what field_halo and hydro_u_halo, ludwig.c:563 and phi_cahn_hilliard.c:
+ * 240, would have supplied). Results identical to the halo-swapped form. */
+int lbmi_symmetric_step_periodic(lbmi_t * lb, double a, double b,
+				 double kappa, double mobility,
+				 const double * phi, const double * u,
+				 double * force, double * phi_out,
+				 int accumulate);
+
 /* The same single pass, with the gradients taken from the arrays grad and
  * delsq of lbmi_field_grad (valid on the interior and one layer around it)
  * instead of re-evaluated from phi: the cheaper route for the 27-point

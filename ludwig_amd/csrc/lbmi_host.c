@@ -1842,7 +1842,37 @@ int lbmi_symmetric_step(lbmi_t * lb, double a, double b, double kappa,
   HIPCHECK(hipSetDevice(lb->device));
   KCHECK(lbmi_k_symm_fe_step(&lb->kp, lb->grad_npt, lb->adv_order, a, b,
 			     kappa, mobility, phi, NULL, NULL, u, force,
-			     phi_out, accumulate, lb->stream));
+			     phi_out, accumulate, 0, lb->stream));
+  return 0;
+}
+
+/* The same on a single rank with periodic boundaries WITHOUT the halo swaps
+ * of phi and u in front of it: the kernel wraps by index what field_halo
+ * and hydro_u_halo would have supplied. */
+
+int lbmi_symmetric_step_periodic(lbmi_t * lb, double a, double b,
+				 double kappa, double mobility,
+				 const double * phi, const double * u,
+				 double * force, double * phi_out,
+				 int accumulate) {
+  if (lb == NULL || !phi || !u || !force || !phi_out) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  }
+  if (phi_out == phi) return lbmi_fail(LBMI_ERR_ARGUMENT, "phi_out aliases phi");
+  if (lb->kp.nhalo < 2) return lbmi_fail(LBMI_ERR_ARGUMENT, "needs nhalo >= 2");
+  if (lb->opts.cartsz > 1 || lb->have_comm) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "lbmi_symmetric_step_periodic: one "
+		     "rank (slabs: field halos + lbmi_symmetric_step)");
+  }
+  for (int d = 0; d < 3; d++) {
+    if (lb->kp.nlocal[d] < lb->kp.nhalo) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "nlocal[%d] < nhalo", d);
+    }
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_symm_fe_step(&lb->kp, lb->grad_npt, lb->adv_order, a, b,
+			     kappa, mobility, phi, NULL, NULL, u, force,
+			     phi_out, accumulate, 1, lb->stream));
   return 0;
 }
 
@@ -1859,7 +1889,7 @@ int lbmi_symmetric_step_grad(lbmi_t * lb, double a, double b, double kappa,
   HIPCHECK(hipSetDevice(lb->device));
   KCHECK(lbmi_k_symm_fe_step(&lb->kp, 0, lb->adv_order, a, b, kappa, mobility,
 			     phi, grad, delsq, u, force, phi_out, accumulate,
-			     lb->stream));
+			     0, lb->stream));
   return 0;
 }
 

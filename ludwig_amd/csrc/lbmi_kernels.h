@@ -127,7 +127,8 @@ int lbmi_k_field_set(const lbmi_kparam_t * kp, int ncomp, double * field,
 /* Symmetric free energy (row f2): 7-point gradients; thermodynamic force by
  * stress divergence, from grad/delsq arrays or (grad == NULL) from phi */
 /* npt: 7 | 27 point gradient stencil (0 in lbmi_k_symm_fe_step: use the
- * arrays grad, delsq); order: advection scheme order 1..4 */
+ * arrays grad, delsq); order: advection scheme order 1..4; wrap != 0 (npt 7
+ * or 27): the kernel wraps the periodic box by index, phi and u need no halo */
 int lbmi_k_grad(const lbmi_kparam_t * kp, int npt, const double * phi,
 		double * grad, double * delsq, void * stream);
 int lbmi_k_symm_force(const lbmi_kparam_t * kp, int npt, double a, double b,
@@ -143,7 +144,8 @@ int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, int npt, int order,
 			double a, double b, double kappa, double mobility,
 			const double * phi, const double * grad,
 			const double * delsq, const double * u, double * force,
-			double * phi_out, int accumulate, void * stream);
+			double * phi_out, int accumulate, int wrap,
+			void * stream);
 
 /* k_collide with fe->use_stress_relaxation for the symmetric free energy */
 int lbmi_k_collide_fe(const lbmi_kparam_t * kp, double * f,

@@ -1527,6 +1527,10 @@ void k_cahn_hilliard(lbmi_kparam_t kp, Symm q, double mobility, int order,
  * of the lattice) or an LDS tile (ip = index in the tile, its strides);
  * grad, delsq (NPT = 0 only), u, force, phi_out are global, indexed by i. */
 
+/* up[d], um[d]: the global site offsets to the +d and -d neighbours for the
+ * reads of u (the strides, or, for a kernel that wraps the periodic box by
+ * index instead of relying on a halo swap of u, the wrapped offsets) */
+
 template <bool ACCUMULATE, int NPT>
 __device__ __forceinline__
 void fe_step_site(const lbmi_kparam_t & kp, const Symm & q, double mobility,
@@ -1534,10 +1538,10 @@ void fe_step_site(const lbmi_kparam_t & kp, const Symm & q, double mobility,
 		  int psy, const double * __restrict__ grad,
 		  const double * __restrict__ delsq,
 		  const double * __restrict__ u, double * __restrict__ force,
-		  double * __restrict__ phi_out, int i) {
+		  double * __restrict__ phi_out, int i, const int (&up)[3],
+		  const int (&um)[3]) {
 
   const size_t ns = (size_t) kp.nsite;
-  const int str[3] = {kp.strx, kp.stry, 1};
   const int pstr[3] = {psx, psy, 1};
 
   /* stress and chemical potential at a site: from phi alone (NPT = 7, 27)
@@ -1572,7 +1576,7 @@ void fe_step_site(const lbmi_kparam_t & kp, const Symm & q, double mobility,
     }
     const double pm1 = phi[ip - pstr[id]], pp1 = phi[ip + pstr[id]];
     {
-      size_t j = (size_t) (i + str[id]);
+      size_t j = (size_t) (i + up[id]);
       at(ip + pstr[id], j, pth1, mu1, phi1);
       for (int ia = 0; ia < 3; ia++) f[ia] -= 0.5*(pth1[ia][id] + pth0[ia][id]);
       double uf = 0.5*(ud0 + u[ns*id + j]);
@@ -1581,7 +1585,7 @@ void fe_step_site(const lbmi_kparam_t & kp, const Symm & q, double mobility,
       fhi[id] = fl;
     }
     {
-      size_t j = (size_t) (i - str[id]);
+      size_t j = (size_t) (i + um[id]);
       at(ip - pstr[id], j, pth1, mu1, phi1);
       for (int ia = 0; ia < 3; ia++) f[ia] += 0.5*(pth1[ia][id] + pth0[ia][id]);
       double uf = 0.5*(ud0 + u[ns*id + j]);
@@ -1627,8 +1631,11 @@ void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility, int order,
   Site s = decode(kp, i);
   if (!s.interior) return;
 
+  const int up[3] = {kp.strx, kp.stry, 1};
+  const int um[3] = {-kp.strx, -kp.stry, -1};
   fe_step_site<ACCUMULATE, NPT>(kp, q, mobility, order, phi, i, kp.strx,
-				kp.stry, grad, delsq, u, force, phi_out, i);
+				kp.stry, grad, delsq, u, force, phi_out, i,
+				up, um);
 }
 
 /* The same pass with phi staged through LDS: a block of 256 threads owns a
@@ -1642,7 +1649,12 @@ void k_symm_fe_step(lbmi_kparam_t kp, Symm q, double mobility, int order,
 enum {FT_X = 4, FT_Y = 8, FT_Z = 32, FT_H = 2,
       FT_LX = FT_X + 2*FT_H, FT_LY = FT_Y + 2*FT_H, FT_LZ = FT_Z + 2*FT_H};
 
-template <bool ACCUMULATE, int NPT>
+/* WRAP: the periodic box is wrapped by index -- the tile takes phi of the
+ * halo layers from the periodic images inside the domain and u of a
+ * neighbour across a face from the opposite face -- so that neither phi nor
+ * u needs a halo swap beforehand (single rank). */
+
+template <bool ACCUMULATE, int NPT, bool WRAP>
 __global__ __launch_bounds__(FT_Y*FT_Z)
 void k_symm_fe_step_tiled(lbmi_kparam_t kp, Symm q, double mobility, int order,
 			  const double * __restrict__ phi,
@@ -1663,9 +1675,18 @@ void k_symm_fe_step_tiled(lbmi_kparam_t kp, Symm q, double mobility, int order,
 
   for (int l = (int) threadIdx.x; l < FT_LX*FT_LY*FT_LZ; l += FT_Y*FT_Z) {
     const int lz = l % FT_LZ, ly = (l / FT_LZ) % FT_LY, lx = l / (FT_LZ*FT_LY);
-    const int gx = x0 - FT_H + lx, gy = y0 - FT_H + ly, gz = z0 - FT_H + lz;
+    int gx = x0 - FT_H + lx, gy = y0 - FT_H + ly, gz = z0 - FT_H + lz;
     double v = 0.0;
     if (gx < kp.nall[0] && gy < kp.nall[1] && gz < kp.nall[2]) {
+      if constexpr (WRAP) {
+	/* a halo coordinate (at most nhalo <= nlocal away) -> its image */
+	if (gx < nh) gx += kp.nlocal[0];
+	else if (gx >= nh + kp.nlocal[0]) gx -= kp.nlocal[0];
+	if (gy < nh) gy += kp.nlocal[1];
+	else if (gy >= nh + kp.nlocal[1]) gy -= kp.nlocal[1];
+	if (gz < nh) gz += kp.nlocal[2];
+	else if (gz >= nh + kp.nlocal[2]) gz -= kp.nlocal[2];
+      }
       v = phi[(size_t) gx*kp.strx + (size_t) gy*kp.stry + gz];
     }
     tile[l] = v;
@@ -1681,9 +1702,19 @@ void k_symm_fe_step_tiled(lbmi_kparam_t kp, Symm q, double mobility, int order,
     if (gx >= nh + kp.nlocal[0]) break;
     const int i = gx*kp.strx + gy*kp.stry + gz;
     const int ip = ((tx + FT_H)*FT_LY + (ty + FT_H))*FT_LZ + (tz + FT_H);
+    int up[3] = {kp.strx, kp.stry, 1};
+    int um[3] = {-kp.strx, -kp.stry, -1};
+    if constexpr (WRAP) {
+      if (gx == nh + kp.nlocal[0] - 1) up[0] = -(kp.nlocal[0] - 1)*kp.strx;
+      if (gx == nh) um[0] = (kp.nlocal[0] - 1)*kp.strx;
+      if (gy == nh + kp.nlocal[1] - 1) up[1] = -(kp.nlocal[1] - 1)*kp.stry;
+      if (gy == nh) um[1] = (kp.nlocal[1] - 1)*kp.stry;
+      if (gz == nh + kp.nlocal[2] - 1) up[2] = -(kp.nlocal[2] - 1);
+      if (gz == nh) um[2] = kp.nlocal[2] - 1;
+    }
     fe_step_site<ACCUMULATE, NPT>(kp, q, mobility, order, tile, ip,
 				  FT_LY*FT_LZ, FT_LZ, nullptr, nullptr, u,
-				  force, phi_out, i);
+				  force, phi_out, i, up, um);
   }
 }
 
@@ -2593,23 +2624,35 @@ static void launch_fe_step(const lbmi_kparam_t * kp, int npt, int order,
 			   Symm q, double mobility, const double * phi,
 			   const double * grad, const double * delsq,
 			   const double * u, double * force, double * phi_out,
-			   hipStream_t st) {
-  if (npt != 0 && kp->fe_tiled) {
+			   int wrap, hipStream_t st) {
+  if (npt != 0 && (kp->fe_tiled || wrap)) {
     /* phi through an LDS tile */
     const int ntx = (kp->nlocal[0] + FT_X - 1)/FT_X;
     const int nty = (kp->nlocal[1] + FT_Y - 1)/FT_Y;
     const int ntz = (kp->nlocal[2] + FT_Z - 1)/FT_Z;
     const unsigned nblk = (unsigned) ntx*(unsigned) nty*(unsigned) ntz;
     dim3 tgrid(grid_for(nblk, (unsigned) kp->xcd_group)), tblock(FT_Y*FT_Z);
-    if (npt == 27) {
-      hipLaunchKernelGGL((k_symm_fe_step_tiled<ACCUMULATE, 27>), tgrid, tblock,
-			 0, st, *kp, q, mobility, order, phi, u, force, phi_out,
-			 nty, ntz, nblk);
+    if (wrap) {
+      if (npt == 27) {
+	hipLaunchKernelGGL((k_symm_fe_step_tiled<ACCUMULATE, 27, true>), tgrid,
+			   tblock, 0, st, *kp, q, mobility, order, phi, u,
+			   force, phi_out, nty, ntz, nblk);
+      }
+      else {
+	hipLaunchKernelGGL((k_symm_fe_step_tiled<ACCUMULATE, 7, true>), tgrid,
+			   tblock, 0, st, *kp, q, mobility, order, phi, u,
+			   force, phi_out, nty, ntz, nblk);
+      }
+    }
+    else if (npt == 27) {
+      hipLaunchKernelGGL((k_symm_fe_step_tiled<ACCUMULATE, 27, false>), tgrid,
+			 tblock, 0, st, *kp, q, mobility, order, phi, u, force,
+			 phi_out, nty, ntz, nblk);
     }
     else {
-      hipLaunchKernelGGL((k_symm_fe_step_tiled<ACCUMULATE, 7>), tgrid, tblock,
-			 0, st, *kp, q, mobility, order, phi, u, force, phi_out,
-			 nty, ntz, nblk);
+      hipLaunchKernelGGL((k_symm_fe_step_tiled<ACCUMULATE, 7, false>), tgrid,
+			 tblock, 0, st, *kp, q, mobility, order, phi, u, force,
+			 phi_out, nty, ntz, nblk);
     }
     return;
   }
@@ -2638,16 +2681,16 @@ extern "C" int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, int npt,
 				   const double * phi, const double * grad,
 				   const double * delsq, const double * u,
 				   double * force, double * phi_out,
-				   int accumulate, void * stream) {
+				   int accumulate, int wrap, void * stream) {
   hipStream_t st = (hipStream_t) stream;
   Symm q = {a, b, kappa};
   if (accumulate) {
     launch_fe_step<true>(kp, npt, order, q, mobility, phi, grad, delsq, u,
-			 force, phi_out, st);
+			 force, phi_out, wrap, st);
   }
   else {
     launch_fe_step<false>(kp, npt, order, q, mobility, phi, grad, delsq, u,
-			  force, phi_out, st);
+			  force, phi_out, wrap, st);
   }
   return (int) hipGetLastError();
 }

@@ -319,6 +319,14 @@ class LB:
             self._h, a, b, kappa, mobility, _ptr(phi), _ptr(u), _ptr(force),
             _ptr(phi_out), 1 if accumulate else 0))
 
+    def symmetric_step_periodic(self, a, b, kappa, mobility, phi, u, force,
+                                phi_out, accumulate=True):
+        """symmetric_step without halo swaps of phi and u: the kernel wraps
+        the periodic box by index (one rank)."""
+        _l.check(self._lib.lbmi_symmetric_step_periodic(
+            self._h, a, b, kappa, mobility, _ptr(phi), _ptr(u), _ptr(force),
+            _ptr(phi_out), 1 if accumulate else 0))
+
     def symmetric_step_grad(self, a, b, kappa, mobility, phi, grad, delsq, u,
                             force, phi_out, accumulate=True):
         """symmetric_step with the gradients read from the arrays of

@@ -112,6 +112,8 @@ SYMBOLS = [
     ("lbmi_symmetric_force", _i, [_vp, _d, _d, _d, _vp, _vp, _vp, _vp]),
     ("lbmi_cahn_hilliard", _i, [_vp, _d, _d, _d, _d, _vp, _vp, _vp, _vp]),
     ("lbmi_symmetric_step", _i, [_vp, _d, _d, _d, _d, _vp, _vp, _vp, _vp, _i]),
+    ("lbmi_symmetric_step_periodic", _i, [_vp, _d, _d, _d, _d, _vp, _vp, _vp,
+                                          _vp, _i]),
     ("lbmi_symmetric_step_grad", _i, [_vp, _d, _d, _d, _d, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _i]),
     ("lbmi_lb_records_pack", _i, [_vp, _vp]),

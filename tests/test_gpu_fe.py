@@ -404,3 +404,40 @@ def test_binary_fluid_steps_through_rccl_ring():
     assert relmax(interior(_host(lb, pa), h), interior(phi, h)) < 1e-12
     assert relmax(interior(lb.lb_memcpy_d2h(), h), interior(f, h)) < 1e-12
     lb.free()
+
+
+@pytest.mark.parametrize("npt,order", [(7, 1), (27, 2), (7, 3), (27, 4)])
+@pytest.mark.parametrize("nlocal", [(12, 10, 8), (33, 9, 34), (4, 3, 2)])
+def test_symmetric_step_periodic_equals_halo_swapped(nlocal, npt, order):
+    """The pass that wraps the periodic box by index = field halos of phi
+    (2 layers) and u (1 layer) followed by the plain pass, bit for bit."""
+    import ludwig_amd
+    import torch
+    h = 2
+    a, b, kappa, mob = -0.00625, 0.00625, 0.004, 1.25
+    lb = ludwig_amd.LB(19, nlocal, h)
+    lb.fe_scheme_set(npt, order)
+    rng = np.random.default_rng(31)
+    phi0 = np.zeros(lb.nall)
+    interior(phi0, h)[...] = 0.3 * rng.standard_normal(nlocal)
+    u0 = np.zeros((3,) + lb.nall)
+    interior(u0, h)[...] = 0.02 * rng.standard_normal((3,) + nlocal)
+    # halo-swapped form
+    p1, uu1 = _dev(lb, phi0), _dev(lb, u0)
+    f1 = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+    o1 = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    torch.cuda.synchronize()
+    lb.field_halo_n(p1, 2)
+    lb.field_halo_n(uu1, 1)
+    lb.symmetric_step(a, b, kappa, mob, p1, uu1, f1, o1, accumulate=False)
+    # wrap form: halos left as they are (zeros, and then garbage)
+    p2, uu2 = _dev(lb, phi0), _dev(lb, u0)
+    p2[:h] = 77.0
+    uu2[:, :, :h] = -55.0
+    f2 = torch.zeros_like(f1)
+    o2 = torch.zeros_like(o1)
+    torch.cuda.synchronize()
+    lb.symmetric_step_periodic(a, b, kappa, mob, p2, uu2, f2, o2, accumulate=False)
+    assert np.array_equal(interior(_host(lb, f2), h), interior(_host(lb, f1), h))
+    assert np.array_equal(interior(_host(lb, o2), h), interior(_host(lb, o1), h))
+    lb.free()
