@@ -527,13 +527,6 @@ static int lbmi_time_begin(lbmi_t * lb) {
    * microseconds between kernels */
   if ((lb->timing_count++ % lb->timing) != 0) return 0;
   lb->timing_now = 1;
-  if (!lb->ev_created) {
-    lb->ev_created = 1;               /* lbmi_free destroys the non-NULL ones */
-    for (int n = 0; n < LBMI_NEVENT; n++) {
-      HIPCHECK(hipEventCreate(&lb->ev0[n]));
-      HIPCHECK(hipEventCreate(&lb->ev1[n]));
-    }
-  }
   if (lb->nev == LBMI_NEVENT) {
     double ms; int n;
     int ifail = lbmi_timing_read(lb, &ms, &n);   /* drains into accumulators */
@@ -554,6 +547,16 @@ static int lbmi_time_end(lbmi_t * lb) {
 
 int lbmi_timing(lbmi_t * lb, int on) {
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (on > 0 && !lb->ev_created) {
+    /* here, not at the first timed launch: creating the events costs a
+     * fraction of a millisecond that must not land in a timed region */
+    HIPCHECK(hipSetDevice(lb->device));
+    lb->ev_created = 1;               /* lbmi_free destroys the non-NULL ones */
+    for (int n = 0; n < LBMI_NEVENT; n++) {
+      HIPCHECK(hipEventCreate(&lb->ev0[n]));
+      HIPCHECK(hipEventCreate(&lb->ev1[n]));
+    }
+  }
   lb->timing = (on > 0) ? on : 0;
   lb->timing_count = 0;
   lb->timing_now = 0;
