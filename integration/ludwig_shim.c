@@ -13,6 +13,9 @@
  *      lb_memcpy()       lb_data.h:156     (wraps  model.c:228-266)
  *      wall_bbl()        wall.h:99         (replaces wall.c:960-989; no slip)
  *      phi_lb_to_field() phi_lb_coupler.h  (replaces phi_lb_coupler.c:39-64)
+ *      hydro_u_zero(), hydro_f_zero()  hydro.h:64-65 (hydro.c:279-330)
+ *      field_halo()      field.h:96        (field.c; FIELD_HALO_TARGET only)
+ *      field_grad_compute() field_grad.h:49 (3d_7pt_fluid / 3d_27pt_fluid d2)
  *
  *  by unpacking lb_t / hydro_t / map_t and calling the C-ABI of
  *  include/lbmi.h. The other contents of collision.c / model.c /
@@ -24,7 +27,10 @@
  *      -Dlb_memcpy=lb_memcpy_ref
  *
  *  (and wall.c with -Dwall_bbl=wall_bbl_ref, phi_lb_coupler.c with
- *  -Dphi_lb_to_field=phi_lb_to_field_ref) so that their originals remain
+ *  -Dphi_lb_to_field=phi_lb_to_field_ref, hydro.c with -Dhydro_u_zero=
+ *  hydro_u_zero_ref -Dhydro_f_zero=hydro_f_zero_ref, field.c with -Dfield_halo=
+ *  field_halo_ref, field_grad.c with -Dfield_grad_compute=
+ *  field_grad_compute_ref) so that their originals remain
  *  available as fall-backs (slip walls, colloids, Lees-Edwards, host halo
  *  schemes, noise), and this file is compiled
  *  with the same -D_D3Q19_|-D_D3Q27_ -DADDR_SOA as the rest of libludwig.a
@@ -57,6 +63,9 @@
 #include "symmetric.h"
 #include "wall.h"
 #include "phi_lb_coupler.h"
+#include "gradient_3d_7pt_fluid.h"
+#include "gradient_3d_27pt_fluid.h"
+#include "leesedwards.h"
 
 #include "lbmi.h"
 
@@ -68,6 +77,10 @@ int lb_propagation_ref(lb_t * lb);
 int lb_memcpy_ref(lb_t * lb, tdpMemcpyKind flag);
 int wall_bbl_ref(wall_t * wall);
 int phi_lb_to_field_ref(field_t * phi, lb_t * lb);
+int hydro_u_zero_ref(hydro_t * hydro, const double uzero[3]);
+int hydro_f_zero_ref(hydro_t * hydro, const double fzero[3]);
+int field_halo_ref(field_t * field);
+int field_grad_compute_ref(field_grad_t * fgrad);
 
 /* One liblbmi handle per lb_t (Ludwig has one lb_t per rank) */
 
@@ -426,4 +439,104 @@ int lb_memcpy(lb_t * lb, tdpMemcpyKind flag) {
   }
 
   return lb_memcpy_ref(lb, flag);
+}
+
+
+/*****************************************************************************
+ *
+ *  Rows f1 / f2 of the scope table: what runs around the LB step with the
+ *  symmetric free energy. These need the handle of the lb_t, i.e. they take
+ *  effect once the first lb_collide / lb_halo has created it; until then
+ *  (initialisation) the originals run.
+ *
+ *  phi_force_calculation and phi_cahn_hilliard are NOT bound here: their
+ *  replacements (lbmi_symmetric_force, lbmi_cahn_hilliard, or the single
+ *  pass lbmi_symmetric_step[_periodic]) are valid under conditions only the
+ *  maintainer can assert -- symmetric free energy, stress-divergence force,
+ *  no walls / colloids / Lees-Edwards planes, no order-parameter noise, no
+ *  external chemical-potential gradient, pch->info.conserve == 0 -- and
+ *  change the ownership of phi (phi -> phi_out). INTEGRATION.md, section 7.
+ *
+ *****************************************************************************/
+
+static lbmi_t * shim_handle_if_any(cs_t * cs) {
+  int nlocal[3], mine[3];
+  if (shim_.h == NULL || shim_.lb == NULL) return NULL;
+  /* the same coordinate system as the lb_t the handle was made for */
+  cs_nlocal(cs, nlocal);
+  cs_nlocal(shim_.lb->cs, mine);
+  if (nlocal[X] != mine[X] || nlocal[Y] != mine[Y] || nlocal[Z] != mine[Z]) {
+    return NULL;
+  }
+  return shim_.h;
+}
+
+int hydro_u_zero(hydro_t * hydro, const double uzero[3]) {
+  lbmi_t * h = NULL;
+  assert(hydro);
+  h = shim_handle_if_any(hydro->cs);
+  if (h == NULL) return hydro_u_zero_ref(hydro, uzero);
+  SHIM_CHECK(shim_.lb, lbmi_hydro_field_set(h, shim_field_data(hydro->u), 3, uzero));
+  return 0;
+}
+
+int hydro_f_zero(hydro_t * hydro, const double fzero[3]) {
+  lbmi_t * h = NULL;
+  assert(hydro);
+  h = shim_handle_if_any(hydro->cs);
+  if (h == NULL) return hydro_f_zero_ref(hydro, fzero);
+  SHIM_CHECK(shim_.lb, lbmi_hydro_field_set(h, shim_field_data(hydro->force), 3, fzero));
+  return 0;
+}
+
+/* field_halo: the device scheme, no Lees-Edwards planes, halo width within
+ * the halo of the lattice (hydro_u_halo comes through here as well,
+ * hydro.c:190-197) */
+
+int field_halo(field_t * field) {
+  lbmi_t * h = NULL;
+  int nhalo = 0;
+  assert(field);
+  h = shim_handle_if_any(field->cs);
+  cs_nhalo(field->cs, &nhalo);
+  if (h == NULL || field->opts.haloscheme != FIELD_HALO_TARGET ||
+      (field->le && lees_edw_nplane_total(field->le) > 0) ||
+      field->nhcomm < 1 || field->nhcomm > nhalo || field->nf > 27) {
+    return field_halo_ref(field);
+  }
+  SHIM_CHECK(shim_.lb, lbmi_field_halo_n(h, field->nf, field->nhcomm,
+					 shim_field_data(field)));
+  return 0;
+}
+
+/* field_grad_compute for a scalar with the fluid-only 7- or 27-point
+ * stencils at level 2 (grad and delsq); anything else is the original */
+
+int field_grad_compute(field_grad_t * fgrad) {
+  lbmi_t * h = NULL;
+  double * grad = NULL;
+  double * delsq = NULL;
+  int npt = 0;
+  assert(fgrad);
+  assert(fgrad->d2);
+  h = shim_handle_if_any(fgrad->field->cs);
+  if (fgrad->d2 == grad_3d_7pt_fluid_d2) npt = 7;
+  if (fgrad->d2 == grad_3d_27pt_fluid_d2) npt = 27;
+  if (h == NULL || npt == 0 || fgrad->nf != 1 || fgrad->level != 2 ||
+      (fgrad->field->le && lees_edw_nplane_total(fgrad->field->le) > 0)) {
+    return field_grad_compute_ref(fgrad);
+  }
+  tdpAssert(tdpMemcpy(&grad, &fgrad->target->grad, sizeof(double *),
+		      tdpMemcpyDeviceToHost));
+  tdpAssert(tdpMemcpy(&delsq, &fgrad->target->delsq, sizeof(double *),
+		      tdpMemcpyDeviceToHost));
+  if (npt == 7) {
+    SHIM_CHECK(shim_.lb, lbmi_field_grad_7pt(h, shim_field_data(fgrad->field),
+					     grad, delsq));
+  }
+  else {
+    SHIM_CHECK(shim_.lb, lbmi_field_grad_27pt(h, shim_field_data(fgrad->field),
+					      grad, delsq));
+  }
+  return 0;
 }
