@@ -266,8 +266,10 @@ int lbmi_lb_run(lbmi_t * lb, const lbmi_hydro_t * hydro, int nsteps);
  * (ludwig.c:802-860): "no halo updates between bounce back and propagation".
  *   lbmi_wall_map        wall_init_map (wall.c:1219-1268): MAP_BOUNDARY (1)
  *                        into the DEVICE map `status` (nsite chars) at every
- *                        site, halo included, whose coordinate in a wall
- *                        direction is 0 or nlocal+1. One rank.
+ *                        site, halo included, whose GLOBAL coordinate in a
+ *                        wall direction is 0 or ntotal+1 (with X slabs: the
+ *                        low X wall on the first rank, the high one on the
+ *                        last).
  *   lbmi_wall_links_build  wall_init_boundaries + wall_init_uw (wall.c:
  *                        381-470, 864-890): a link for every interior
  *                        MAP_FLUID site i and p >= 1 with i + c_p

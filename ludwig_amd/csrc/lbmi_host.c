@@ -1185,9 +1185,6 @@ static void lbmi_wall_release(lbmi_t * lb) {
 
 static int lbmi_wall_args(const lbmi_t * lb, const int isboundary[3]) {
   if (lb == NULL || isboundary == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
-  if (lb->opts.cartsz != 1) {
-    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "walls: one rank (cartsz = 1)");
-  }
   return 0;
 }
 
@@ -1211,7 +1208,11 @@ int lbmi_wall_map(lbmi_t * lb, const int isboundary[3], char * status) {
       for (int kc = 0; kc < lb->kp.nall[Z]; kc++) {
 	/* coordinate 0 or nlocal + 1 in the reference's numbering */
 	int wall = 0;
-	if (isboundary[X] && (ic == h - 1 || ic == h + lb->kp.nlocal[X])) wall = 1;
+	/* X slabs: the global coordinate 0 lies below the first rank, the
+	 * global ntotal + 1 above the last (noffset in wall.c:1236-1240) */
+	if (isboundary[X] && ic == h - 1 && lb->opts.cartrank == 0) wall = 1;
+	if (isboundary[X] && ic == h + lb->kp.nlocal[X] &&
+	    lb->opts.cartrank == lb->opts.cartsz - 1) wall = 1;
 	if (isboundary[Y] && (jc == h - 1 || jc == h + lb->kp.nlocal[Y])) wall = 1;
 	if (isboundary[Z] && (kc == h - 1 || kc == h + lb->kp.nlocal[Z])) wall = 1;
 	if (wall) {
