@@ -127,7 +127,7 @@ typedef enum lbmi_mode_e {
 
 typedef struct lbmi_options_s {
   int nvel;                 /* 19 or 27 (lb_data.h:33-44)                    */
-  int ndist;                /* 1, or 2 (symmetric_lb: EAGER mode, one rank)  */
+  int ndist;                /* 1, or 2 (symmetric_lb: EAGER mode)            */
   int nlocal[3];            /* local lattice extent (cs_nlocal)              */
   int nhalo;                /* halo width of the allocation (cs_nhalo)       */
   int device;               /* HIP device ordinal, or -1: current device     */
@@ -247,7 +247,7 @@ int lbmi_lb_flush(lbmi_t * lb);
  * between (a host language with expensive foreign calls, a benchmark). */
 int lbmi_lb_run(lbmi_t * lb, const lbmi_hydro_t * hydro, int nsteps);
 
-/* ndist = 2, free_energy symmetric_lb (LBMI_MODE_EAGER, one rank): the
+/* ndist = 2, free_energy symmetric_lb (LBMI_MODE_EAGER): the
  * second distribution carries the order parameter. f holds both,
  * f[(n*nvel + p)*nsite + index]; lbmi_lb_halo and lbmi_lb_propagation move
  * both; lbmi_lb_moments looks at n = 0 (as stats_distribution.c does).

@@ -102,8 +102,7 @@ static shim_t shim_ = {NULL, NULL, LBMI_MODE_EAGER};
   } while (0)
 
 /* Can liblbmi take this lb_t? SoA build, device halo scheme, decomposition
- * along X only; two distributions (symmetric_lb) on a single rank. Anything
- * else uses the originals. */
+ * along X only. Anything else uses the originals. */
 
 static int shim_supported(lb_t * lb) {
   int cartsz[3];
@@ -113,7 +112,6 @@ static int shim_supported(lb_t * lb) {
   if (lb->haloscheme != LB_HALO_TARGET) return 0;
   cs_cartsz(lb->cs, cartsz);
   if (cartsz[Y] != 1 || cartsz[Z] != 1) return 0;
-  if (lb->ndist == 2 && cartsz[X] != 1) return 0;
   return 1;
 }
 

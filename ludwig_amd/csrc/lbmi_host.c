@@ -220,10 +220,9 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   if (opts->ndist != 1 && opts->ndist != 2) {
     return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = %d: 1 or 2", opts->ndist);
   }
-  if (opts->ndist == 2 && (opts->mode != LBMI_MODE_EAGER || opts->cartsz != 1)) {
-    /* the two-distribution (symmetric_lb) step: three stages, one rank */
-    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = 2 needs LBMI_MODE_EAGER "
-		     "and cartsz = 1");
+  if (opts->ndist == 2 && opts->mode != LBMI_MODE_EAGER) {
+    /* the two-distribution (symmetric_lb) step: three stages */
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = 2 needs LBMI_MODE_EAGER");
   }
   if (opts->nhalo < 1) return lbmi_fail(LBMI_ERR_ARGUMENT, "nhalo < 1");
   for (int d = 0; d < 3; d++) {

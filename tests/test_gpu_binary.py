@@ -182,3 +182,35 @@ def test_stress_relaxation_vs_reference(name, mode):
         lb.lb_propagation()
     assert relmax(interior(lb.lb_memcpy_d2h(), 1), interior(g["f_final"], 1)) < 1e-12
     lb.free()
+
+
+def test_binary_steps_on_the_slab_path():
+    """ndist = 2 with the X halo of both distributions and of phi through a
+    1-rank RCCL ring = the single-rank run, bit for bit."""
+    import ludwig_amd
+    import torch
+    g = load_golden("bin_q19_b")
+    meta = g["meta"]
+    out = []
+    for ring in (False, True):
+        lb = _lb(meta)
+        if ring:
+            lb.comm_init(ludwig_amd.LB.comm_unique_id())
+        hy = ludwig_amd.Hydro(lb.nall, lb.device)
+        lb.fe_scheme_set(27, 1)
+        phi = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+        grad = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+        delsq = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+        lb.lb_memcpy_h2d(g["f0"])
+        for _ in range(meta["nsteps"]):
+            lb.phi_to_field(phi)
+            lb.field_halo_n(phi, 1)
+            lb.field_grad(phi, grad, delsq)
+            lb.lb_collide_binary(hy, meta["a"], meta["b"], meta["kappa"],
+                                 meta["mobility"], phi, grad, delsq)
+            lb.lb_halo()
+            lb.lb_propagation()
+        out.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+        lb.free()
+    assert np.array_equal(out[0], out[1])
+    assert relmax(out[1], interior(g["f_final"], 1)) < 1e-12
