@@ -30,6 +30,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Before anything initialises HIP: the host driver supports dmabuf IPC only
+# (RCCL / device-memory sharing across processes fails without this), and all
+# ranks of a run share one node, so the control plane (gloo) and the RCCL
+# bootstrap go over loopback whatever the host name resolves to.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+
 PRELOAD_STEPS = 3
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -161,12 +170,8 @@ def main():
 
     if world > 1:
         # control plane only (barrier, max-reduction, id broadcast); the
-        # data path is the library's own RCCL communicator. All ranks share
-        # one node: rendezvous and bootstrap over loopback, whatever the
-        # host name resolves to (or does not).
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # data path is the library's own RCCL communicator (loopback
+        # defaults for both are set at the top of this file)
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
