@@ -302,6 +302,39 @@ int lbmi_wall_bbl_arrays(lbmi_t * lb, int nlink, const int * linki,
 			 const int * linku, const double ubot[3],
 			 const double utop[3], double * fnet);
 int lbmi_wall_momentum(lbmi_t * lb, double fnet[3]);
+/* map->target->status (DEVICE, nsite chars) for the MAP_COLLOID test of the
+ * bounce-back kernels (wall.c:1046-1061, 1146-1161): a link whose fluid site a
+ * colloid covers is left to the colloid's own bounce-back and only enters the
+ * momentum accounting. NULL (the default): no test. The pointer is kept. */
+int lbmi_wall_status_set(lbmi_t * lb, const char * status);
+
+/* Partial slip at flat walls (wall_slip_t, wall.h:25-50).
+ *   lbmi_wall_slip_set   wall_slip + wall_init_boundaries_slip (wall.c:285-316,
+ *                        489-593, with wall_link_normal :606-642,
+ *                        wall_link_slip_direction :658-693, wall_link_slip
+ *                        :707-757): slip fractions 0 <= s <= 1 of the bottom
+ *                        and top wall of each direction; for every link built by
+ *                        lbmi_wall_links_build the partner fluid site k, the
+ *                        partner direction q and the index of s (faces; edges
+ *                        = mean of the two faces; corners no slip). `status` =
+ *                        the DEVICE map the links were built from. All
+ *                        fractions zero: slip off again. From then on
+ *                        lbmi_wall_bbl runs wall_bbl_slip_kernel (wall.c:
+ *                        971, 1118-1205): f[j, nvel-p] = (1-s) f[i,p] +
+ *                        s f[k,q], walls at rest, first distribution only,
+ *                        as the reference.
+ *   lbmi_wall_slip_links copy linkk, linkq, links out (host, nlink ints each).
+ *   lbmi_wall_bbl_slip_arrays  the same on DEVICE arrays the caller owns, in
+ *                        the reference's types (wall.h:79-81); stab = the 19
+ *                        fractions wall->param->slip.s (host). */
+int lbmi_wall_slip_set(lbmi_t * lb, const char * status,
+		       const double sbot[3], const double stop[3]);
+int lbmi_wall_slip_links(lbmi_t * lb, int * linkk, int * linkq, int * links);
+int lbmi_wall_bbl_slip_arrays(lbmi_t * lb, int nlink, const int * linki,
+			      const int * linkj, const int * linkp,
+			      const int * linkk, const signed char * linkq,
+			      const signed char * links,
+			      const double stab[19], double * fnet);
 
 typedef struct lbmi_fe_symm_s {
   double a, b, kappa;        /* fe_symm_param_t, symmetric.h */

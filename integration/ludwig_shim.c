@@ -11,7 +11,7 @@
  *      lb_halo_swap()    lb_data.h:160     (replaces model.c:565-595)
  *      lb_propagation()  propagation.h:21  (replaces propagation.c:43-98)
  *      lb_memcpy()       lb_data.h:156     (wraps  model.c:228-266)
- *      wall_bbl()        wall.h:99         (replaces wall.c:960-989; no slip)
+ *      wall_bbl()        wall.h:99         (replaces wall.c:960-989, slip included)
  *      phi_lb_to_field() phi_lb_coupler.h  (replaces phi_lb_coupler.c:39-64)
  *      hydro_u_zero(), hydro_f_zero()  hydro.h:64-65 (hydro.c:279-330)
  *      field_halo()      field.h:96        (field.c; FIELD_HALO_TARGET only)
@@ -31,7 +31,7 @@
  *  hydro_u_zero_ref -Dhydro_f_zero=hydro_f_zero_ref, field.c with -Dfield_halo=
  *  field_halo_ref, field_grad.c with -Dfield_grad_compute=
  *  field_grad_compute_ref) so that their originals remain
- *  available as fall-backs (slip walls, colloids, Lees-Edwards, host halo
+ *  available as fall-backs (colloids, Lees-Edwards, host halo
  *  schemes, noise), and this file is compiled
  *  with the same -D_D3Q19_|-D_D3Q27_ -DADDR_SOA as the rest of libludwig.a
  *  and linked with -llbmi. See INTEGRATION.md.
@@ -340,7 +340,7 @@ int wall_bbl(wall_t * wall) {
 
   if (wall->nlink == 0) return 0;                /* wall.c:967 */
 
-  if (wall->param->slip.active || !shim_supported(wall->lb)) {
+  if (!shim_supported(wall->lb)) {
     return wall_bbl_ref(wall);
   }
   if (shim_.mode == LBMI_MODE_FUSED) {
@@ -360,11 +360,37 @@ int wall_bbl(wall_t * wall) {
 			tdpMemcpyDeviceToHost));
     tdpAssert(tdpMemcpy(&link[3], &wall->target->linku, sizeof(int *),
 			tdpMemcpyDeviceToHost));
-    SHIM_CHECK(wall->lb, lbmi_wall_bbl_arrays(shim_handle(wall->lb),
-					       wall->nlink, link[0], link[1],
-					       link[2], link[3],
-					       wall->param->ubot,
-					       wall->param->utop, fnet));
+    {
+      /* the kernels test map->status[i] for MAP_COLLOID (wall.c:1046, 1146) */
+      char * status = NULL;
+      tdpAssert(tdpMemcpy(&status, &wall->map->target->status, sizeof(char *),
+			  tdpMemcpyDeviceToHost));
+      SHIM_CHECK(wall->lb, lbmi_wall_status_set(shim_handle(wall->lb), status));
+    }
+    if (wall->param->slip.active) {                       /* wall.c:971 */
+      int * linkk = NULL;
+      int8_t * linkq = NULL;
+      int8_t * links = NULL;
+      tdpAssert(tdpMemcpy(&linkk, &wall->target->linkk, sizeof(int *),
+			  tdpMemcpyDeviceToHost));
+      tdpAssert(tdpMemcpy(&linkq, &wall->target->linkq, sizeof(int8_t *),
+			  tdpMemcpyDeviceToHost));
+      tdpAssert(tdpMemcpy(&links, &wall->target->links, sizeof(int8_t *),
+			  tdpMemcpyDeviceToHost));
+      SHIM_CHECK(wall->lb,
+		 lbmi_wall_bbl_slip_arrays(shim_handle(wall->lb), wall->nlink,
+					   link[0], link[1], link[2], linkk,
+					   (const signed char *) linkq,
+					   (const signed char *) links,
+					   wall->param->slip.s, fnet));
+    }
+    else {
+      SHIM_CHECK(wall->lb, lbmi_wall_bbl_arrays(shim_handle(wall->lb),
+						 wall->nlink, link[0], link[1],
+						 link[2], link[3],
+						 wall->param->ubot,
+						 wall->param->utop, fnet));
+    }
   }
 
   return 0;

@@ -88,6 +88,13 @@ struct lbmi_s {
   double * wall_fnet;                /* device accumulator, 3 doubles */
   double wall_ubot[3];
   double wall_utop[3];
+  const char * wall_status;          /* device map for the MAP_COLLOID test */
+  int slip_active;                   /* wall_slip_t */
+  double slip_s[19];
+  int * slip_k_dev;                  /* linkk, linkq, links (device) */
+  int8_t * slip_q_dev;
+  int8_t * slip_s_dev;
+  int * slip_host[3];                /* host copies, as ints */
   double rho0;
 
   /* kernel timing */
@@ -1167,6 +1174,20 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
 
 enum {LBMI_MAP_FLUID = 0, LBMI_MAP_BOUNDARY = 1};        /* map.h:23 */
 
+static void lbmi_slip_release(lbmi_t * lb) {
+  if (lb->slip_k_dev) hipFree(lb->slip_k_dev);
+  if (lb->slip_q_dev) hipFree(lb->slip_q_dev);
+  if (lb->slip_s_dev) hipFree(lb->slip_s_dev);
+  lb->slip_k_dev = NULL;
+  lb->slip_q_dev = NULL;
+  lb->slip_s_dev = NULL;
+  for (int k = 0; k < 3; k++) {
+    free(lb->slip_host[k]);
+    lb->slip_host[k] = NULL;
+  }
+  lb->slip_active = 0;
+}
+
 static void lbmi_wall_release(lbmi_t * lb) {
   for (int k = 0; k < 4; k++) {
     if (lb->link_dev[k]) hipFree(lb->link_dev[k]);
@@ -1174,6 +1195,7 @@ static void lbmi_wall_release(lbmi_t * lb) {
     lb->link_dev[k] = NULL;
     lb->link_host[k] = NULL;
   }
+  lbmi_slip_release(lb);
   if (lb->wall_part) hipFree(lb->wall_part);
   if (lb->wall_fnet) hipFree(lb->wall_fnet);
   lb->wall_part = NULL;
@@ -1333,6 +1355,14 @@ int lbmi_wall_velocity_set(lbmi_t * lb, const double ubot[3],
   return 0;
 }
 
+/* The map the bounce-back kernels test for MAP_COLLOID (or NULL: no test) */
+
+int lbmi_wall_status_set(lbmi_t * lb, const char * status) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  lb->wall_status = status;
+  return 0;
+}
+
 /* wall_bbl on link arrays owned by the caller (the reference keeps
  * wall->target->linki, linkj, linkp, linku and fnet on the device) */
 
@@ -1377,13 +1407,214 @@ int lbmi_wall_bbl_arrays(lbmi_t * lb, int nlink, const int * linki,
     tab.uw[2][ia] = ubot[ia];
   }
   KCHECK(lbmi_k_wall_bbl(&lb->kp, &tab, lb->f, nlink, linki, linkj, linkp,
-			 linku, lb->wall_part, fnet, lb->stream));
+			 linku, lb->wall_status, lb->wall_part, fnet,
+			 lb->stream));
+  return 0;
+}
+
+/* wall_slip (wall.c:285-316): faces, then the 12 edges XB_YB XB_YT XB_ZB
+ * XB_ZT XT_YB XT_YT XT_ZB XT_ZT YB_ZB YB_ZT YT_ZB YT_ZT (wall.h:25-41) */
+
+static int lbmi_slip_table(const double sbot[3], const double stop[3],
+			   double s[19]) {
+  const double face[3][2] = {{sbot[X], stop[X]}, {sbot[Y], stop[Y]},
+			     {sbot[Z], stop[Z]}};
+  int active = 0;
+  s[0] = 0.0;
+  for (int ia = 0; ia < 3; ia++) {
+    s[1 + 2*ia] = face[ia][0];
+    s[2 + 2*ia] = face[ia][1];
+    if (face[ia][0] != 0.0 || face[ia][1] != 0.0) active = 1;
+  }
+  for (int ta = 0; ta < 2; ta++) {
+    for (int tb = 0; tb < 2; tb++) {
+      s[7 + 4*ta + tb]  = 0.5*(face[X][ta] + face[Y][tb]);
+      s[9 + 4*ta + tb]  = 0.5*(face[X][ta] + face[Z][tb]);
+      s[15 + 2*ta + tb] = 0.5*(face[Y][ta] + face[Z][tb]);
+    }
+  }
+  return active;
+}
+
+int lbmi_wall_slip_set(lbmi_t * lb, const char * status,
+		       const double sbot[3], const double stop[3]) {
+  char * host = NULL;
+  int8_t * q8 = NULL;
+  int8_t * s8 = NULL;
+  size_t ns;
+  int nlink;
+  int ifail = 0;
+  double stab[19];
+
+  if (lb == NULL || sbot == NULL || stop == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->link_host[0] == NULL) return lbmi_fail(LBMI_ERR_STATE, "no links built");
+  for (int ia = 0; ia < 3; ia++) {                    /* wall_slip_valid */
+    if (!(sbot[ia] >= 0.0 && sbot[ia] <= 1.0) || !(stop[ia] >= 0.0 && stop[ia] <= 1.0)) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "slip fractions must lie in [0, 1]");
+    }
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  HIPCHECK(hipStreamSynchronize(lb->stream));
+  lbmi_slip_release(lb);
+  if (!lbmi_slip_table(sbot, stop, stab)) return 0;
+  if (status == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+
+  nlink = lb->nlink;
+  ns = (size_t) lb->kp.nsite;
+  host = (char *) malloc(ns);
+  q8 = (int8_t *) calloc((size_t) nlink + 1, 1);
+  s8 = (int8_t *) calloc((size_t) nlink + 1, 1);
+  for (int k = 0; k < 3; k++) {
+    lb->slip_host[k] = (int *) calloc((size_t) nlink + 1, sizeof(int));
+    if (lb->slip_host[k] == NULL) ifail = 1;
+  }
+  if (host == NULL || q8 == NULL || s8 == NULL) ifail = 1;
+  if (!ifail && hipMemcpy(host, status, ns, hipMemcpyDeviceToHost) != hipSuccess) ifail = 1;
+
+  for (int n = 0; n < nlink && !ifail; n++) {
+    const int i = lb->link_host[0][n];
+    const int p = lb->link_host[2][n];
+    const ptrdiff_t str[3] = {lb->kp.strx, lb->kp.stry, 1};
+    int wn[3], wt[3], cdotn = 0, modwn = 0, modwt = 0;
+    /* wall_link_normal: the axis neighbours of i along c_p that are not fluid */
+    for (int ia = 0; ia < 3; ia++) {
+      wn[ia] = (host[i + str[ia]*lb->cv[p][ia]] != LBMI_MAP_FLUID) ? -lb->cv[p][ia] : 0;
+      cdotn += lb->cv[p][ia]*wn[ia];
+      modwn += wn[ia]*wn[ia];
+    }
+    if (modwn == 0 || modwn != -cdotn) {
+      /* a convex edge: wall.c:557-558 asserts this away (flat walls only) */
+      ifail = 2;
+      break;
+    }
+    for (int ia = 0; ia < 3; ia++) {
+      wt[ia] = lb->cv[p][ia] - cdotn*wn[ia]/modwn;
+      modwt += wt[ia]*wt[ia];
+    }
+    if (modwt == 0) {
+      /* nothing tangential: plain bounce-back (k, q valid but unused) */
+      lb->slip_host[0][n] = i;
+      lb->slip_host[1][n] = p;
+      lb->slip_host[2][n] = 0;
+    }
+    else {
+      int q = -1, s = 0;
+      for (int m = 0; m < lb->kp.nvel; m++) {
+	if (lb->cv[m][X] == -2*wn[X] - lb->cv[p][X] &&
+	    lb->cv[m][Y] == -2*wn[Y] - lb->cv[p][Y] &&
+	    lb->cv[m][Z] == -2*wn[Z] - lb->cv[p][Z]) q = m;
+      }
+      if (q <= 0) { ifail = 2; break; }
+      if (modwn == 1) {
+	for (int ia = 0; ia < 3; ia++) {
+	  if (wn[ia] == +1) s = 1 + 2*ia;
+	  if (wn[ia] == -1) s = 2 + 2*ia;
+	}
+      }
+      if (modwn == 2) {
+	if (wn[X] != 0 && wn[Y] != 0) s = 7 + 4*(wn[X] == -1) + (wn[Y] == -1);
+	if (wn[X] != 0 && wn[Z] != 0) s = 9 + 4*(wn[X] == -1) + (wn[Z] == -1);
+	if (wn[Y] != 0 && wn[Z] != 0) s = 15 + 2*(wn[Y] == -1) + (wn[Z] == -1);
+      }
+      lb->slip_host[0][n] = (int) (i + str[X]*wt[X] + str[Y]*wt[Y] + wt[Z]);
+      lb->slip_host[1][n] = q;
+      lb->slip_host[2][n] = s;                        /* corners: 0 */
+    }
+    q8[n] = (int8_t) lb->slip_host[1][n];
+    s8[n] = (int8_t) lb->slip_host[2][n];
+  }
+
+  if (!ifail) {
+    size_t n1 = (size_t) nlink + 1;
+    if (hipMalloc((void **) &lb->slip_k_dev, n1*sizeof(int)) != hipSuccess ||
+	hipMalloc((void **) &lb->slip_q_dev, n1) != hipSuccess ||
+	hipMalloc((void **) &lb->slip_s_dev, n1) != hipSuccess ||
+	hipMemcpy(lb->slip_k_dev, lb->slip_host[0], n1*sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+	hipMemcpy(lb->slip_q_dev, q8, n1, hipMemcpyHostToDevice) != hipSuccess ||
+	hipMemcpy(lb->slip_s_dev, s8, n1, hipMemcpyHostToDevice) != hipSuccess) {
+      ifail = 1;
+    }
+  }
+  free(host);
+  free(q8);
+  free(s8);
+  if (ifail) {
+    lbmi_slip_release(lb);
+    if (ifail == 2) {
+      return lbmi_fail(LBMI_ERR_UNSUPPORTED, "slip: a link without a wall "
+		       "normal (solid sites other than flat walls)");
+    }
+    return lbmi_fail(LBMI_ERR_HIP, "slip links");
+  }
+  memcpy(lb->slip_s, stab, sizeof(stab));
+  lb->slip_active = 1;
+  return 0;
+}
+
+int lbmi_wall_slip_links(lbmi_t * lb, int * linkk, int * linkq, int * links) {
+  int * out[3] = {linkk, linkq, links};
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (!lb->slip_active) return lbmi_fail(LBMI_ERR_STATE, "slip is not active");
+  for (int k = 0; k < 3; k++) {
+    if (out[k]) memcpy(out[k], lb->slip_host[k], sizeof(int)*(size_t) lb->nlink);
+  }
+  return 0;
+}
+
+int lbmi_wall_bbl_slip_arrays(lbmi_t * lb, int nlink, const int * linki,
+			      const int * linkj, const int * linkp,
+			      const int * linkk, const signed char * linkq,
+			      const signed char * links,
+			      const double stab[19], double * fnet) {
+  lbmi_wall_tab_t tab;
+  double na[LBMI_NVEL_MAX];
+  double ma[LBMI_NVEL_MAX*LBMI_NVEL_MAX];
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+  if (lb->opts.mode != LBMI_MODE_EAGER &&
+      !(lb->opts.mode == LBMI_MODE_FUSED_HALO && !lb->pending_prop)) {
+    return lbmi_fail(LBMI_ERR_STATE, "walls need LBMI_MODE_EAGER or "
+		     "LBMI_MODE_FUSED_HALO (before lb_propagation)");
+  }
+  if (nlink == 0) return 0;
+  if (nlink < 0 || !linki || !linkj || !linkp || !linkk || !linkq || !links ||
+      !stab || !fnet) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_wall_bbl_slip_arrays: bad argument");
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  if (lb->wall_part == NULL || lb->wall_part_nblk < lbmi_k_wall_nblk(nlink)) {
+    if (lb->wall_part) HIPCHECK(hipFree(lb->wall_part));
+    lb->wall_part = NULL;
+    lb->wall_part_nblk = lbmi_k_wall_nblk(nlink);
+    HIPCHECK(hipMalloc((void **) &lb->wall_part,
+		       sizeof(double)*3*(size_t) lb->wall_part_nblk));
+  }
+  memset(&tab, 0, sizeof(tab));
+  tab.nvel = lb->kp.nvel;
+  tab.ndist = lb->opts.ndist;
+  tab.rho0 = lb->rho0;
+  if (lbmi_k_model(lb->kp.nvel, &tab.cv[0][0], tab.wv, na, ma) != 0) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "model tables");
+  }
+  for (int n = 0; n < 19; n++) tab.slip[n] = stab[n];
+  KCHECK(lbmi_k_wall_bbl_slip(&lb->kp, &tab, lb->f, nlink, linki, linkj, linkp,
+			      linkk, (const int8_t *) linkq,
+			      (const int8_t *) links, lb->wall_status,
+			      lb->wall_part, fnet, lb->stream));
   return 0;
 }
 
 int lbmi_wall_bbl(lbmi_t * lb) {
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (lb->link_host[0] == NULL) return lbmi_fail(LBMI_ERR_STATE, "no links built");
+  if (lb->slip_active) {                                     /* wall.c:971 */
+    return lbmi_wall_bbl_slip_arrays(lb, lb->nlink, lb->link_dev[0],
+				     lb->link_dev[1], lb->link_dev[2],
+				     lb->slip_k_dev,
+				     (const signed char *) lb->slip_q_dev,
+				     (const signed char *) lb->slip_s_dev,
+				     lb->slip_s, lb->wall_fnet);
+  }
   return lbmi_wall_bbl_arrays(lb, lb->nlink, lb->link_dev[0], lb->link_dev[1],
 			      lb->link_dev[2], lb->link_dev[3], lb->wall_ubot,
 			      lb->wall_utop, lb->wall_fnet);

@@ -164,7 +164,8 @@ int lbmi_k_collide_binary(const lbmi_kparam_t * kp, double * f2,
 
 /* Bounce-back on links (wall_bbl_kernel, wall.c:996-1107). Tables travel by
  * value; part: nblk*3 doubles of per-block momentum, added to fnet[3] (device)
- * by a one-thread epilogue in block order (deterministic). */
+ * by a one-thread epilogue in block order (deterministic). status (or NULL):
+ * links whose fluid site is MAP_COLLOID only enter the accounting. */
 typedef struct lbmi_wall_tab_s {
   int nvel;
   int ndist;
@@ -172,12 +173,23 @@ typedef struct lbmi_wall_tab_s {
   double wv[LBMI_NVEL_MAX];
   double rho0;
   double uw[3][3];              /* WALL_UZERO, WALL_UWTOP, WALL_UWBOT */
+  double slip[19];              /* slip fraction by wall_slip_enum_t */
 } lbmi_wall_tab_t;
 int lbmi_k_wall_nblk(int nlink);
 int lbmi_k_wall_bbl(const lbmi_kparam_t * kp, const lbmi_wall_tab_t * tab,
 		    double * f, int nlink, const int * linki,
 		    const int * linkj, const int * linkp, const int * linku,
-		    double * part, double * fnet, void * stream);
+		    const char * status, double * part, double * fnet,
+		    void * stream);
+
+/* wall_bbl_slip_kernel (wall.c:1118-1205): linkk, linkq, links as the
+ * reference keeps them (int, int8_t, int8_t) */
+int lbmi_k_wall_bbl_slip(const lbmi_kparam_t * kp, const lbmi_wall_tab_t * tab,
+			 double * f, int nlink, const int * linki,
+			 const int * linkj, const int * linkp,
+			 const int * linkk, const int8_t * linkq,
+			 const int8_t * links, const char * status,
+			 double * part, double * fnet, void * stream);
 
 /* Moments: partial (nblk x 12 doubles workspace) then final (out_dev[9]) */
 int lbmi_k_moments_nblk(void);

@@ -2219,37 +2219,11 @@ int model_tables(int8_t * cv, double * wv, double * na, double * ma) {
  * (shuffles + LDS) and added to fnet in block order. */
 
 enum {WALL_BLOCK = 256, WALL_NBLK_MAX = 1024};
+enum {MAP_COLLOID = 2};                                    /* map.h:23 */
 
-__global__ __launch_bounds__(WALL_BLOCK)
-void k_wall_bbl(lbmi_kparam_t kp, lbmi_wall_tab_t tab, double * __restrict__ f,
-		int nlink, const int * __restrict__ linki,
-		const int * __restrict__ linkj, const int * __restrict__ linkp,
-		const int * __restrict__ linku, double * __restrict__ part) {
-
-  const size_t ns = (size_t) kp.nsite;
-  const double rcs2 = 3.0;
-  double fx = 0.0, fy = 0.0, fz = 0.0;
-
-  for (int n = blockIdx.x*WALL_BLOCK + threadIdx.x; n < nlink;
-       n += gridDim.x*WALL_BLOCK) {
-    const int i = linki[n], j = linkj[n];
-    const int ij = linkp[n], ji = tab.nvel - ij, ia = linku[n];
-    const double cx = tab.cv[ij][0], cy = tab.cv[ij][1], cz = tab.cv[ij][2];
-    const double cdotu = cx*tab.uw[ia][0] + cy*tab.uw[ia][1] + cz*tab.uw[ia][2];
-    const double wall = 2.0*rcs2*tab.wv[ij]*tab.rho0*cdotu;
-    double fp = f[ns*ij + i];
-    const double force = 2.0*fp - wall;
-    fx += (force - 2.0*tab.wv[ij])*cx;
-    fy += (force - 2.0*tab.wv[ij])*cy;
-    fz += (force - 2.0*tab.wv[ij])*cz;
-    f[ns*ji + j] = fp - wall;
-    if (tab.ndist > 1) {
-      const size_t off = ns*(size_t) tab.nvel;
-      f[off + ns*ji + j] = f[off + ns*ij + i] - wall;
-    }
-  }
-
-  /* block reduction: 64-lane shuffles, then one LDS slot per wave */
+/* block reduction: 64-lane shuffles, then one LDS slot per wave */
+__device__ __forceinline__ void wall_block_sum(double fx, double fy, double fz,
+					       double * __restrict__ part) {
   for (int d = 32; d > 0; d >>= 1) {
     fx += shfl_down_d(fx, d);
     fy += shfl_down_d(fy, d);
@@ -2268,6 +2242,92 @@ void k_wall_bbl(lbmi_kparam_t kp, lbmi_wall_tab_t tab, double * __restrict__ f,
     part[3*blockIdx.x + 1] = s1;
     part[3*blockIdx.x + 2] = s2;
   }
+}
+
+__global__ __launch_bounds__(WALL_BLOCK)
+void k_wall_bbl(lbmi_kparam_t kp, lbmi_wall_tab_t tab, double * __restrict__ f,
+		int nlink, const int * __restrict__ linki,
+		const int * __restrict__ linkj, const int * __restrict__ linkp,
+		const int * __restrict__ linku,
+		const char * __restrict__ status, double * __restrict__ part) {
+
+  const size_t ns = (size_t) kp.nsite;
+  const double rcs2 = 3.0;
+  double fx = 0.0, fy = 0.0, fz = 0.0;
+
+  for (int n = blockIdx.x*WALL_BLOCK + threadIdx.x; n < nlink;
+       n += gridDim.x*WALL_BLOCK) {
+    const int i = linki[n], j = linkj[n];
+    const int ij = linkp[n], ji = tab.nvel - ij, ia = linku[n];
+    const double cx = tab.cv[ij][0], cy = tab.cv[ij][1], cz = tab.cv[ij][2];
+    const double cdotu = cx*tab.uw[ia][0] + cy*tab.uw[ia][1] + cz*tab.uw[ia][2];
+    const double wall = 2.0*rcs2*tab.wv[ij]*tab.rho0*cdotu;
+    double fp = f[ns*ij + i];
+    if (status != nullptr && status[i] == MAP_COLLOID) {
+      /* a colloid sits on the fluid side: its own bounce-back moves the
+       * populations; here only the accounting (wall.c:1048-1061) */
+      fp += f[ns*ji + j];
+      fx += (fp - 2.0*tab.wv[ij])*cx;
+      fy += (fp - 2.0*tab.wv[ij])*cy;
+      fz += (fp - 2.0*tab.wv[ij])*cz;
+      continue;
+    }
+    const double force = 2.0*fp - wall;
+    fx += (force - 2.0*tab.wv[ij])*cx;
+    fy += (force - 2.0*tab.wv[ij])*cy;
+    fz += (force - 2.0*tab.wv[ij])*cz;
+    f[ns*ji + j] = fp - wall;
+    if (tab.ndist > 1) {
+      const size_t off = ns*(size_t) tab.nvel;
+      f[off + ns*ji + j] = f[off + ns*ij + i] - wall;
+    }
+  }
+
+  wall_block_sum(fx, fy, fz, part);
+}
+
+/* wall_bbl_slip_kernel (wall.c:1118-1205) without colloids: a fraction s of
+ * what comes back along link n is the population q of the fluid site k one
+ * step along the wall from i (specular reflection), 1 - s is bounced back;
+ * walls at rest, LB_RHO only, as there. The normal factor w = -(c_p + c_q)/2
+ * is formed in integers, as there. */
+
+__global__ __launch_bounds__(WALL_BLOCK)
+void k_wall_bbl_slip(lbmi_kparam_t kp, lbmi_wall_tab_t tab,
+		     double * __restrict__ f, int nlink,
+		     const int * __restrict__ linki,
+		     const int * __restrict__ linkj,
+		     const int * __restrict__ linkp,
+		     const int * __restrict__ linkk,
+		     const int8_t * __restrict__ linkq,
+		     const int8_t * __restrict__ links,
+		     const char * __restrict__ status,
+		     double * __restrict__ part) {
+
+  const size_t ns = (size_t) kp.nsite;
+  double fsum[3] = {0.0, 0.0, 0.0};
+
+  for (int n = blockIdx.x*WALL_BLOCK + threadIdx.x; n < nlink;
+       n += gridDim.x*WALL_BLOCK) {
+    const int i = linki[n], j = linkj[n], k = linkk[n];
+    const int ij = linkp[n], ji = tab.nvel - ij, q = linkq[n];
+    const double s = tab.slip[links[n]];
+    const double fi = f[ns*ij + i];
+    const double fk = f[ns*q + k];
+    if (status != nullptr && status[i] == MAP_COLLOID) {     /* wall.c:1148-1161 */
+      const double fp = fi + f[ns*ji + j];
+      for (int a = 0; a < 3; a++) fsum[a] += (fp - 2.0*tab.wv[ij])*tab.cv[ij][a];
+      continue;
+    }
+    f[ns*ji + j] = (1.0 - s)*fi + s*fk;
+    for (int a = 0; a < 3; a++) {
+      const int iw = -((int) tab.cv[ij][a] + (int) tab.cv[q][a])/2;
+      const double w = iw;
+      fsum[a] += 2.0*(1.0 - s)*(fi - tab.wv[ij])*tab.cv[ij][a];
+      fsum[a] += 2.0*w*w*s*(fk - tab.wv[q])*tab.cv[q][a];
+    }
+  }
+  wall_block_sum(fsum[0], fsum[1], fsum[2], part);
 }
 
 __global__ void k_wall_fnet(int nblk, const double * __restrict__ part,
@@ -2768,13 +2828,30 @@ extern "C" int lbmi_k_wall_bbl(const lbmi_kparam_t * kp,
 			       const lbmi_wall_tab_t * tab, double * f,
 			       int nlink, const int * linki,
 			       const int * linkj, const int * linkp,
-			       const int * linku, double * part,
-			       double * fnet, void * stream) {
+			       const int * linku, const char * status,
+			       double * part, double * fnet, void * stream) {
   hipStream_t st = (hipStream_t) stream;
   int nblk = lbmi_k_wall_nblk(nlink);
   if (nlink <= 0) return 0;
   hipLaunchKernelGGL(k_wall_bbl, dim3(nblk), dim3(WALL_BLOCK), 0, st, *kp,
-		     *tab, f, nlink, linki, linkj, linkp, linku, part);
+		     *tab, f, nlink, linki, linkj, linkp, linku, status, part);
+  hipLaunchKernelGGL(k_wall_fnet, dim3(1), dim3(64), 0, st, nblk, part, fnet);
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_wall_bbl_slip(const lbmi_kparam_t * kp,
+				    const lbmi_wall_tab_t * tab, double * f,
+				    int nlink, const int * linki,
+				    const int * linkj, const int * linkp,
+				    const int * linkk, const int8_t * linkq,
+				    const int8_t * links, const char * status,
+				    double * part, double * fnet, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  int nblk = lbmi_k_wall_nblk(nlink);
+  if (nlink <= 0) return 0;
+  hipLaunchKernelGGL(k_wall_bbl_slip, dim3(nblk), dim3(WALL_BLOCK), 0, st, *kp,
+		     *tab, f, nlink, linki, linkj, linkp, linkk, linkq, links,
+		     status, part);
   hipLaunchKernelGGL(k_wall_fnet, dim3(1), dim3(64), 0, st, nblk, part, fnet);
   return (int) hipGetLastError();
 }

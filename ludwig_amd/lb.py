@@ -394,6 +394,28 @@ class LB:
         """wall_bbl: between lb_halo and lb_propagation (EAGER)."""
         _l.check(self._lib.lbmi_wall_bbl(self._h))
 
+    def wall_status_set(self, status):
+        """The device map wall_bbl tests for MAP_COLLOID (None: no test);
+        the tensor is kept alive by the handle."""
+        self._wall_status = status
+        _l.check(self._lib.lbmi_wall_status_set(
+            self._h, None if status is None else _ptr(status)))
+
+    def wall_slip_set(self, status, sbot, stop):
+        """wall_slip + wall_init_boundaries_slip for the links built: slip
+        fractions of the bottom / top wall of each direction (all zero: off).
+        wall_bbl then runs the reference's slip kernel."""
+        sb = (ctypes.c_double * 3)(*[float(x) for x in sbot])
+        st = (ctypes.c_double * 3)(*[float(x) for x in stop])
+        _l.check(self._lib.lbmi_wall_slip_set(self._h, _ptr(status), sb, st))
+
+    def wall_slip_links(self):
+        """(linkk, linkq, links): partner site, partner direction, index of s."""
+        arr = [np.zeros(max(self.nlink, 1), dtype=np.int32) for _ in range(3)]
+        _l.check(self._lib.lbmi_wall_slip_links(
+            self._h, *[a.ctypes.data_as(ctypes.c_void_p) for a in arr]))
+        return tuple(a[:self.nlink] for a in arr)
+
     def wall_momentum(self):
         out = (ctypes.c_double * 3)()
         _l.check(self._lib.lbmi_wall_momentum(self._h, out))

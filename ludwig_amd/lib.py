@@ -95,6 +95,11 @@ SYMBOLS = [
     ("lbmi_wall_bbl", _i, [_vp]),
     ("lbmi_wall_bbl_arrays", _i, [_vp, _i, _vp, _vp, _vp, _vp, _pd, _pd, _vp]),
     ("lbmi_wall_momentum", _i, [_vp, _pd]),
+    ("lbmi_wall_status_set", _i, [_vp, _vp]),
+    ("lbmi_wall_slip_set", _i, [_vp, _vp, _pd, _pd]),
+    ("lbmi_wall_slip_links", _i, [_vp, _vp, _vp, _vp]),
+    ("lbmi_wall_bbl_slip_arrays", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _pd, _vp]),
     ("lbmi_lb_phi_to_field", _i, [_vp, _vp]),
     ("lbmi_lb_collide_binary", _i, [_vp, ctypes.POINTER(HydroPtrs),
                                     ctypes.POINTER(FeSymm)]),

@@ -713,10 +713,29 @@ int lbo_wall_links(const lbo_param_t * p, const char * status,
   return nlink;
 }
 
+#define MAP_COLLOID_ 2           /* map.h:23 */
+
+/* status (may be NULL): a fluid-side site that a colloid covers (MAP_COLLOID)
+ * is not bounced; it only enters the accounting (wall.c:1048-1061, 1148-1161) */
+
+static int wall_colloid_link(const lbo_model_t * model, int nvel,
+			     ptrdiff_t nsite, const double * f,
+			     const char * status, int i, int j, int ij,
+			     double fnet[3]) {
+  if (status == NULL || status[i] != MAP_COLLOID_) return 0;
+  {
+    double fp = f[nsite*ij + i] + f[nsite*(nvel - ij) + j];
+    fnet[X] += (fp - 2.0*model->wv[ij])*model->cv[ij][X];
+    fnet[Y] += (fp - 2.0*model->wv[ij])*model->cv[ij][Y];
+    fnet[Z] += (fp - 2.0*model->wv[ij])*model->cv[ij][Z];
+  }
+  return 1;
+}
+
 int lbo_wall_bbl(const lbo_param_t * p, double * f, int nlink,
 		 const int * linki, const int * linkj, const int * linkp,
 		 const int * linku, const double ubot[3],
-		 const double utop[3], double fnet[3]) {
+		 const double utop[3], double fnet[3], const char * status) {
   int nall[3];
   ptrdiff_t str[3];
   ptrdiff_t nsite;
@@ -740,11 +759,165 @@ int lbo_wall_bbl(const lbo_param_t * p, double * f, int nlink,
       + model.cv[ij][Z]*uw[ia][Z];
     double fp = f[nsite*ij + linki[n]];
     double force = 2.0*fp - 2.0*rcs2*model.wv[ij]*p->rho0*cdotu;
+    if (wall_colloid_link(&model, p->nvel, nsite, f, status, linki[n],
+			  linkj[n], ij, fnet)) continue;
     fnet[X] += (force - 2.0*model.wv[ij])*model.cv[ij][X];
     fnet[Y] += (force - 2.0*model.wv[ij])*model.cv[ij][Y];
     fnet[Z] += (force - 2.0*model.wv[ij])*model.cv[ij][Z];
     fp = fp - 2.0*rcs2*model.wv[ij]*p->rho0*cdotu;
     f[nsite*ji + linkj[n]] = fp;
+  }
+  return 0;
+}
+
+/*
+ * lbo_wall_slip_table, lbo_wall_slip_links, lbo_wall_bbl_slip
+ *
+ * Flat walls with partial slip (row f4).
+ *
+ * lbo_wall_slip_table: wall_slip (wall.c:285-316): the 19-entry table of slip
+ * fractions, index = wall_slip_enum_t (wall.h:25-41): 0 no slip, 1..6 the
+ * faces XBOT XTOP YBOT YTOP ZBOT ZTOP, 7..18 the edges (mean of the two faces).
+ * Returns "active" (any fraction non-zero).
+ *
+ * lbo_wall_slip_links: wall_init_boundaries_slip (wall.c:489-593) with
+ * wall_link_normal (:606-642), wall_link_slip_direction (:658-693) and
+ * wall_link_slip (:707-757): for every link (i, p) the wall normal wn at the
+ * crossing (from the status of the three axis neighbours of i along c_p), the
+ * tangent wt = c_p - (c_p.wn/wn.wn) wn, the partner fluid site k = i + wt, the
+ * partner direction q with c_q = -2 wn - c_p, and the table index of the slip
+ * fraction (faces and edges; corners and purely normal links: no slip, and
+ * then k = i, q = p).
+ *
+ * lbo_wall_bbl_slip: wall_bbl_slip_kernel (wall.c:1118-1205), no colloids:
+ * f[j, nvel-p] = (1-s) f[i,p] + s f[k,q]; the momentum keeps the reference's
+ * integer arithmetic for the normal factor w = -(c_p + c_q)/2. LB_RHO only.
+ */
+
+int lbo_wall_slip_table(const double sbot[3], const double stop[3],
+			double s[19]) {
+  const double face[3][2] = {{sbot[X], stop[X]}, {sbot[Y], stop[Y]},
+			     {sbot[Z], stop[Z]}};
+  s[0] = 0.0;
+  for (int ia = 0; ia < 3; ia++) {
+    s[1 + 2*ia] = face[ia][0];
+    s[2 + 2*ia] = face[ia][1];
+  }
+  /* edges: XB_YB XB_YT XB_ZB XB_ZT XT_YB XT_YT XT_ZB XT_ZT YB_ZB YB_ZT YT_ZB
+   * YT_ZT (B = 0, T = 1) */
+  for (int ta = 0; ta < 2; ta++) {
+    for (int tb = 0; tb < 2; tb++) {
+      s[7 + 4*ta + tb]  = 0.5*(face[X][ta] + face[Y][tb]);
+      s[9 + 4*ta + tb]  = 0.5*(face[X][ta] + face[Z][tb]);
+      s[15 + 2*ta + tb] = 0.5*(face[Y][ta] + face[Z][tb]);
+    }
+  }
+  return (sbot[X] != 0.0 || sbot[Y] != 0.0 || sbot[Z] != 0.0 ||
+	  stop[X] != 0.0 || stop[Y] != 0.0 || stop[Z] != 0.0);
+}
+
+static void slip_normal(const lbo_model_t * model, const char * status,
+			const ptrdiff_t str[3], int i, int p, int wn[3]) {
+  for (int ia = 0; ia < 3; ia++) {
+    ptrdiff_t j = i + str[ia]*model->cv[p][ia];
+    wn[ia] = (status[j] != MAP_FLUID) ? -model->cv[p][ia] : 0;
+  }
+}
+
+int lbo_wall_slip_links(const lbo_param_t * p, const char * status, int nlink,
+			const int * linki, const int * linkp, int * linkk,
+			int * linkq, int * links) {
+  int nall[3];
+  ptrdiff_t str[3];
+  lbo_model_t model;
+
+  if (lbo_model_create(p->nvel, &model) != 0) return -1;
+  strides(p, nall, str);
+
+  for (int n = 0; n < nlink; n++) {
+    int wn[3], wt[3];
+    int pn = linkp[n];
+    int cvdotwn, modwn, modwt;
+
+    slip_normal(&model, status, str, linki[n], pn, wn);
+    cvdotwn = model.cv[pn][X]*wn[X] + model.cv[pn][Y]*wn[Y] + model.cv[pn][Z]*wn[Z];
+    modwn = wn[X]*wn[X] + wn[Y]*wn[Y] + wn[Z]*wn[Z];
+    if (modwn == 0 || modwn != -cvdotwn) return -2;     /* wall.c:557-558 */
+    for (int ia = 0; ia < 3; ia++) {
+      wt[ia] = model.cv[pn][ia] - cvdotwn*wn[ia]/modwn;
+    }
+    modwt = wt[X]*wt[X] + wt[Y]*wt[Y] + wt[Z]*wt[Z];
+
+    if (modwt == 0) {
+      linkk[n] = linki[n];
+      linkq[n] = pn;
+      links[n] = 0;
+    }
+    else {
+      int cq[3];
+      int q = -1;
+      int s = 0;
+      linkk[n] = (int) (linki[n] + str[X]*wt[X] + str[Y]*wt[Y] + str[Z]*wt[Z]);
+      for (int ia = 0; ia < 3; ia++) cq[ia] = -2*wn[ia] - model.cv[pn][ia];
+      for (int m = 0; m < p->nvel; m++) {
+	if (cq[X] == model.cv[m][X] && cq[Y] == model.cv[m][Y] &&
+	    cq[Z] == model.cv[m][Z]) q = m;
+      }
+      if (q <= 0) return -3;
+      linkq[n] = q;
+      if (modwn == 1) {
+	if (wn[X] == +1) s = 1;
+	if (wn[X] == -1) s = 2;
+	if (wn[Y] == +1) s = 3;
+	if (wn[Y] == -1) s = 4;
+	if (wn[Z] == +1) s = 5;
+	if (wn[Z] == -1) s = 6;
+      }
+      if (modwn == 2) {
+	/* XB_YB XB_YT XB_ZB XB_ZT XT_YB XT_YT XT_ZB XT_ZT YB_ZB YB_ZT YT_ZB YT_ZT */
+	if (wn[X] != 0 && wn[Y] != 0) s = 7 + 4*(wn[X] == -1) + (wn[Y] == -1);
+	if (wn[X] != 0 && wn[Z] != 0) s = 9 + 4*(wn[X] == -1) + (wn[Z] == -1);
+	if (wn[Y] != 0 && wn[Z] != 0) s = 15 + 2*(wn[Y] == -1) + (wn[Z] == -1);
+      }
+      links[n] = s;
+    }
+  }
+  return 0;
+}
+
+int lbo_wall_bbl_slip(const lbo_param_t * p, double * f, int nlink,
+		      const int * linki, const int * linkj, const int * linkp,
+		      const int * linkk, const int * linkq, const int * links,
+		      const double stab[19], double fnet[3],
+		      const char * status) {
+  int nall[3];
+  ptrdiff_t str[3];
+  ptrdiff_t nsite;
+  lbo_model_t model;
+
+  if (lbo_model_create(p->nvel, &model) != 0) return -1;
+  strides(p, nall, str);
+  nsite = (ptrdiff_t) nall[X]*nall[Y]*nall[Z];
+
+  for (int n = 0; n < nlink; n++) {
+    int ij = linkp[n];
+    int ji = p->nvel - ij;
+    int q = linkq[n];
+    double s = stab[links[n]];
+    double fi = f[nsite*ij + linki[n]];
+    double fk = f[nsite*q + linkk[n]];
+    double fp = (1.0 - s)*fi + s*fk;
+
+    if (wall_colloid_link(&model, p->nvel, nsite, f, status, linki[n],
+			  linkj[n], ij, fnet)) continue;
+    f[nsite*ji + linkj[n]] = fp;
+
+    for (int ia = 0; ia < 3; ia++) {
+      int iw = -(model.cv[ij][ia] + model.cv[q][ia])/2;      /* int, as there */
+      double w = iw;
+      fnet[ia] += 2.0*(1.0 - s)*(fi - model.wv[ij])*model.cv[ij][ia];
+      fnet[ia] += 2.0*w*w*s*(fk - model.wv[q])*model.cv[q][ia];
+    }
   }
   return 0;
 }

@@ -69,7 +69,17 @@ int lbo_wall_links(const lbo_param_t * p, const char * status,
 int lbo_wall_bbl(const lbo_param_t * p, double * f, int nlink,
 		 const int * linki, const int * linkj, const int * linkp,
 		 const int * linku, const double ubot[3],
-		 const double utop[3], double fnet[3]);
+		 const double utop[3], double fnet[3], const char * status);
+int lbo_wall_slip_table(const double sbot[3], const double stop[3],
+			double s[19]);
+int lbo_wall_slip_links(const lbo_param_t * p, const char * status, int nlink,
+			const int * linki, const int * linkp, int * linkk,
+			int * linkq, int * links);
+int lbo_wall_bbl_slip(const lbo_param_t * p, double * f, int nlink,
+		      const int * linki, const int * linkj, const int * linkp,
+		      const int * linkk, const int * linkq, const int * links,
+		      const double stab[19], double fnet[3],
+		      const char * status);
 int lbo_collide_visc(const lbo_param_t * p, double * f, const double * force,
 		     const char * status, const double * eta,
 		     double * rho_out, double * u_out);

@@ -83,7 +83,12 @@ def lib():
         _lib.lbo_wall_links.argtypes = [pp, ctypes.c_void_p, ip, ctypes.c_int,
                                         ip, ip, ip, ip]
         _lib.lbo_wall_bbl.argtypes = [pp, dp, ctypes.c_int, ip, ip, ip, ip, dp,
-                                      dp, dp]
+                                      dp, dp, ctypes.c_void_p]
+        _lib.lbo_wall_slip_table.argtypes = [dp, dp, dp]
+        _lib.lbo_wall_slip_links.argtypes = [pp, ctypes.c_void_p, ctypes.c_int,
+                                             ip, ip, ip, ip, ip]
+        _lib.lbo_wall_bbl_slip.argtypes = [pp, dp, ctypes.c_int, ip, ip, ip, ip,
+                                           ip, ip, dp, dp, ctypes.c_void_p]
         _lib.lbo_grad_7pt.argtypes = [pp, dp, dp, dp]
         _lib.lbo_grad_27pt.argtypes = [pp, dp, dp, dp]
         _lib.lbo_cahn_hilliard.argtypes = [pp, ctypes.c_double, ctypes.c_double,
@@ -199,14 +204,55 @@ def wall_links(p, status, isboundary):
     return tuple(a[:n] for a in arr)
 
 
-def wall_bbl(p, f, links, ubot, utop, fnet):
-    """wall_bbl: bounce-back on links in place; fnet (3) accumulates."""
+def _status_ptr(status):
+    if status is None:
+        return None, None
+    status = np.ascontiguousarray(status, dtype=np.int8)
+    return status, _ptr(status)
+
+
+def wall_bbl(p, f, links, ubot, utop, fnet, status=None):
+    """wall_bbl: bounce-back on links in place; fnet (3) accumulates. status
+    (optional): links whose fluid site is MAP_COLLOID (2) only enter fnet."""
+    keep, sp = _status_ptr(status)
     li, lj, lp, lu = [np.ascontiguousarray(a, dtype=np.int32) for a in links]
     ub = np.asarray(ubot, dtype=np.float64)
     ut = np.asarray(utop, dtype=np.float64)
     rc = lib().lbo_wall_bbl(ctypes.byref(p), _ptr(f), len(li), _ptr(li),
                             _ptr(lj), _ptr(lp), _ptr(lu), _ptr(ub), _ptr(ut),
-                            _ptr(fnet))
+                            _ptr(fnet), sp)
+    assert rc == 0
+
+
+def wall_slip_table(sbot, stop):
+    """wall_slip: (active, s[19]) indexed by wall_slip_enum_t."""
+    sb = np.asarray(sbot, dtype=np.float64)
+    st = np.asarray(stop, dtype=np.float64)
+    s = np.zeros(19)
+    active = lib().lbo_wall_slip_table(_ptr(sb), _ptr(st), _ptr(s))
+    return bool(active), s
+
+
+def wall_slip_links(p, status, links):
+    """wall_init_boundaries_slip: (linkk, linkq, links) for the links given."""
+    li, lj, lp, lu = [np.ascontiguousarray(a, dtype=np.int32) for a in links]
+    status = np.ascontiguousarray(status, dtype=np.int8)
+    out = [np.zeros(max(len(li), 1), dtype=np.int32) for _ in range(3)]
+    rc = lib().lbo_wall_slip_links(ctypes.byref(p), _ptr(status), len(li),
+                                   _ptr(li), _ptr(lp), *[_ptr(a) for a in out])
+    assert rc == 0, rc
+    return tuple(a[:len(li)] for a in out)
+
+
+def wall_bbl_slip(p, f, links, slip_links, stab, fnet, status=None):
+    """wall_bbl with slip: in place; fnet (3) accumulates."""
+    keep, sp = _status_ptr(status)
+    li, lj, lp, lu = [np.ascontiguousarray(a, dtype=np.int32) for a in links]
+    lk, lq, ls = [np.ascontiguousarray(a, dtype=np.int32) for a in slip_links]
+    stab = np.ascontiguousarray(stab, dtype=np.float64)
+    rc = lib().lbo_wall_bbl_slip(ctypes.byref(p), _ptr(f), len(li), _ptr(li),
+                                 _ptr(lj), _ptr(lp), _ptr(lk), _ptr(lq),
+                                 _ptr(ls), _ptr(stab), _ptr(fnet), sp)
     assert rc == 0
 
 

@@ -193,6 +193,18 @@ WALL_CASES = [
     ("wall_q19_x", 19, (6, 5, 4), (1, 0, 0), -0.01, 0.02, 0, 4),
     ("wall_q19_xyz", 19, (5, 6, 4), (1, 1, 1), 0.0, 0.0, 1, 4),
     ("wall_q27_z", 27, (5, 4, 6), (0, 0, 1), 0.01, -0.03, 0, 4),
+    # solid = 2: MAP_COLLOID marks on fluid sites after the links were built
+    ("wall_q19_colloid", 19, (6, 5, 4), (1, 0, 0), -0.01, 0.02, 2, 3),
+]
+
+
+# name, nvel, (nx, ny, nz), isboundary, sbot, stop, nsteps: walls at rest with
+# partial slip (wall_bbl_slip_kernel); faces, edges and corners
+SLIP_CASES = [
+    ("slip_q19_z", 19, (5, 4, 6), (0, 0, 1), (0, 0, 0.5), (0, 0, 1.0), 4),
+    ("slip_q19_xyz", 19, (5, 6, 4), (1, 1, 1), (0.5, 0.25, 1.0), (0.0, 0.75, 0.3), 4),
+    ("slip_q27_xy", 27, (4, 5, 6), (1, 1, 0), (1.0, 0.4, 0), (0.6, 0.0, 0), 4),
+    ("slip_q19_colloid", 19, (5, 4, 6), (0, 0, 1), (0, 0, 0.5), (0, 0, 1.0), 3, 2),
 ]
 
 
@@ -200,11 +212,19 @@ def run_wall_case(case, tmp):
     """Flat walls with bounce-back on links: status map, links and f after
     the first wall_bbl and after nsteps of collide, halo, wall_bbl,
     propagation; meta["fnet"] = the accumulated wall momentum."""
-    name, nvel, n, bnd, ubot, utop, solid, nsteps = case
+    slip = []
+    if isinstance(case[4], tuple):
+        name, nvel, n, bnd, sbot, stop, nsteps = case[:7]
+        ubot = utop = 0.0
+        solid = case[7] if len(case) > 7 else 0
+        slip = [repr(float(v)) for v in (*sbot, *stop)]
+    else:
+        name, nvel, n, bnd, ubot, utop, solid, nsteps = case
     exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
     prefix = os.path.join(tmp, name)
     subprocess.run([exe, "wall", prefix, *map(str, n), *map(str, bnd),
-                    repr(ubot), repr(utop), str(solid), str(nsteps)], check=True)
+                    repr(ubot), repr(utop), str(solid), str(nsteps), *slip],
+                   check=True)
     meta = json.load(open(prefix + ".json"))
     meta["name"] = name
     meta["scheme_name"] = "m10"
@@ -216,12 +236,15 @@ def run_wall_case(case, tmp):
     def loadi(key):
         return np.fromfile("%s.%s.i32" % (prefix, key), dtype="<i4")
 
-    return {"meta": np.array(json.dumps(meta)),
-            "status": loadi("status").reshape(nall).astype(np.int8),
-            "linki": loadi("linki"), "linkj": loadi("linkj"),
-            "linkp": loadi("linkp"), "linku": loadi("linku"),
-            "f0": load("f0", (nvel,)), "f_bbl": load("f_bbl", (nvel,)),
-            "f_final": load("f_final", (nvel,))}
+    out = {"meta": np.array(json.dumps(meta)),
+           "status": loadi("status").reshape(nall).astype(np.int8),
+           "linki": loadi("linki"), "linkj": loadi("linkj"),
+           "linkp": loadi("linkp"), "linku": loadi("linku"),
+           "f0": load("f0", (nvel,)), "f_bbl": load("f_bbl", (nvel,)),
+           "f_final": load("f_final", (nvel,))}
+    if slip:
+        out.update(linkk=loadi("linkk"), linkq=loadi("linkq"), links=loadi("links"))
+    return out
 
 
 # name, nvel, (nx, ny, nz), timestep
@@ -278,7 +301,7 @@ def main():
             fn = os.path.join(GOLD, case[0] + ".npz")
             np.savez_compressed(fn, **out)
             print("wrote", fn, os.path.getsize(fn))
-        for case in WALL_CASES:
+        for case in WALL_CASES + SLIP_CASES:
             out = run_wall_case(case, tmp)
             fn = os.path.join(GOLD, case[0] + ".npz")
             np.savez_compressed(fn, **out)

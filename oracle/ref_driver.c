@@ -38,6 +38,7 @@
  *    ref_driver relax <prefix> nx ny nz a b kappa mobility eta zeta fx nsteps
  *               (ONE distribution, fe->use_stress_relaxation: collision.c:413)
  *    ref_driver wall <prefix> nx ny nz bx by bz uboty utopy solid nsteps
+ *               [sbx sby sbz stx sty stz]     (partial slip, wall.c:285-316)
  *               (flat walls: lb_collide, lb_halo, wall_bbl, lb_propagation)
  *    ref_driver io <dir> nx ny nz timestep      (lb_io_write into <dir>)
  *    ref_driver ioread <dir> nx ny nz timestep  (lb_io_read from <dir>)
@@ -565,6 +566,7 @@ static int run_wall(int argc, char ** argv) {
   int periodic[3];
   wall_param_t wp = {0};
   int nsteps = atoi(argv[12]);
+  int colloid = 0;
 
   pe_t * pe = NULL;
   cs_t * cs = NULL;
@@ -589,7 +591,23 @@ static int run_wall(int argc, char ** argv) {
   wp.ubot[Y] = atof(argv[9]);
   wp.utop[Y] = atof(argv[10]);
   c.solid = atoi(argv[11]);
+  if (c.solid == 2) {
+    /* 2: no solid block, but MAP_COLLOID marks on some fluid sites after the
+     * links exist (the accounting-only branch, wall.c:1048-1061, 1148-1161) */
+    c.solid = 0;
+    colloid = 1;
+  }
   for (int ia = 0; ia < 3; ia++) periodic[ia] = 1 - wp.isboundary[ia];
+  if (argc == 19) {
+    /* partial slip: sbot[3] stop[3] (wall_slip, wall.c:285-316) */
+    double sbot[3] = {atof(argv[13]), atof(argv[14]), atof(argv[15])};
+    double stop[3] = {atof(argv[16]), atof(argv[17]), atof(argv[18])};
+    wp.slip = wall_slip(sbot, stop);
+    if (!wall_slip_valid(&wp.slip)) {
+      fprintf(stderr, "ref_driver: invalid slip fractions\n");
+      return 1;
+    }
+  }
 
   MPI_Init(&argc, &argv);
   pe_create(MPI_COMM_WORLD, PE_QUIET, &pe);
@@ -625,6 +643,16 @@ static int run_wall(int argc, char ** argv) {
   init_map(cs, map, &c);
   wall_create(pe, cs, map, lb, &wall);
   wall_commit(wall, &wp);
+  if (colloid) {
+    for (int ic = 1; ic <= c.ntotal[X]; ic++) {
+      for (int jc = 1; jc <= c.ntotal[Y]; jc++) {
+	for (int kc = 1; kc <= c.ntotal[Z]; kc++) {
+	  if ((ic + 2*jc + 3*kc) % 5 != 0) continue;
+	  map_status_set(map, cs_index(cs, ic, jc, kc), MAP_COLLOID);
+	}
+      }
+    }
+  }
 
   {
     size_t nf = (size_t) lb->nsite*lb->model.nvel;
@@ -645,6 +673,15 @@ static int run_wall(int argc, char ** argv) {
     dump_i32(prefix, "linkj", wall->linkj, wall->nlink);
     dump_i32(prefix, "linkp", wall->linkp, wall->nlink);
     dump_i32(prefix, "linku", wall->linku, wall->nlink);
+    if (wp.slip.active) {
+      int * tmp = (int *) calloc((size_t) wall->nlink + 1, sizeof(int));
+      dump_i32(prefix, "linkk", wall->linkk, wall->nlink);
+      for (int n = 0; n < wall->nlink; n++) tmp[n] = wall->linkq[n];
+      dump_i32(prefix, "linkq", tmp, wall->nlink);
+      for (int n = 0; n < wall->nlink; n++) tmp[n] = wall->links[n];
+      dump_i32(prefix, "links", tmp, wall->nlink);
+      free(tmp);
+    }
     dump(prefix, "f0", lb->f, nf);
 
     for (int n = 0; n < nsteps; n++) {
@@ -666,11 +703,16 @@ static int run_wall(int argc, char ** argv) {
 	    " \"fbody\": [0.0, 0.0, 0.0], \"isboundary\": [%d, %d, %d],"
 	    " \"ubot\": [0.0, %.17g, 0.0], \"utop\": [0.0, %.17g, 0.0],"
 	    " \"solid\": %d, \"nlink\": %d, \"nsteps\": %d,"
+	    " \"slip\": %d, \"sbot\": [%.17g, %.17g, %.17g],"
+	    " \"stop\": [%.17g, %.17g, %.17g],"
 	    " \"fnet\": [%.17g, %.17g, %.17g], \"layout\": \"soa\"}\n",
 	    NVEL, c.ntotal[X], c.ntotal[Y], c.ntotal[Z],
 	    nall[X], nall[Y], nall[Z], lb->nsite, c.eta, c.zeta,
 	    wp.isboundary[X], wp.isboundary[Y], wp.isboundary[Z],
-	    wp.ubot[Y], wp.utop[Y], c.solid, wall->nlink, nsteps,
+	    wp.ubot[Y], wp.utop[Y], 2*colloid + c.solid, wall->nlink, nsteps,
+	    wp.slip.active, wp.slip.s[WALL_SLIP_XBOT], wp.slip.s[WALL_SLIP_YBOT],
+	    wp.slip.s[WALL_SLIP_ZBOT], wp.slip.s[WALL_SLIP_XTOP],
+	    wp.slip.s[WALL_SLIP_YTOP], wp.slip.s[WALL_SLIP_ZTOP],
 	    fnet[X], fnet[Y], fnet[Z]);
     fclose(fp);
     free(status);
@@ -775,7 +817,7 @@ int main(int argc, char ** argv) {
   if ((argc == 10 || argc == 12) && strcmp(argv[1], "fe") == 0) {
     return run_fe(argc, argv);
   }
-  if (argc == 13 && strcmp(argv[1], "wall") == 0) {
+  if ((argc == 13 || argc == 19) && strcmp(argv[1], "wall") == 0) {
     return run_wall(argc, argv);
   }
   if (argc == 14 && (strcmp(argv[1], "binary") == 0 ||

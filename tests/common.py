@@ -51,6 +51,12 @@ def golden_wall_names():
                   for f in glob.glob(os.path.join(GOLDEN_DIR, "wall_*.npz")))
 
 
+def golden_slip_names():
+    """Fixtures of flat walls with partial slip (slip_*)."""
+    return sorted(os.path.basename(f)[:-4]
+                  for f in glob.glob(os.path.join(GOLDEN_DIR, "slip_*.npz")))
+
+
 def load_io_golden(name):
     """Files written by the reference's lb_io_write (io_q19, io_q27): the
     metadata text, the data file name and bytes, and the f they hold."""

@@ -7,7 +7,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle import lb_oracle as lbo                                    # noqa: E402
-from tests.common import golden_wall_names, interior, load_golden, relmax  # noqa: E402
+from tests.common import (golden_slip_names, golden_wall_names, interior,  # noqa: E402
+                          load_golden, relmax)
 
 
 def _setup(g, mode=0):
@@ -17,11 +18,20 @@ def _setup(g, mode=0):
     lb = ludwig_amd.LB(meta["nvel"], tuple(meta["nlocal"]), 1, mode=mode)
     lb.relaxation_set("m10", meta["eta"], meta["zeta"])
     st0 = np.zeros(lb.nall, dtype=np.int8)
-    if meta["solid"]:
+    if meta["solid"] == 1:
         st0[2:4, 2:4, 2:4] = 1
     hy = ludwig_amd.Hydro(lb.nall, lb.device, status=st0)
     torch.cuda.synchronize()
     return lb, hy, meta
+
+
+def _mark_colloids(lb, hy, g):
+    """solid = 2 fixtures: the reference marked some fluid sites MAP_COLLOID
+    AFTER its links were built; the bounce-back kernels test the map."""
+    import torch
+    hy.status.copy_(torch.tensor(g["status"], dtype=torch.int8))
+    lb.wall_status_set(hy.status)
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("name", golden_wall_names())
@@ -30,7 +40,8 @@ def test_wall_map_and_links_exact(name):
     lb, hy, meta = _setup(g)
     lb.wall_map(meta["isboundary"], hy.status)
     lb.synchronize()
-    assert np.array_equal(hy.status.cpu().numpy(), g["status"])
+    assert np.array_equal(hy.status.cpu().numpy(),
+                          np.where(g["status"] == 2, 0, g["status"]))
     n = lb.wall_links_build(hy.status, meta["isboundary"])
     assert n == meta["nlink"]
     li, lj, lp, lu = lb.wall_links()
@@ -50,6 +61,8 @@ def test_wall_steps_vs_reference(name, mode):
     lb.wall_map(meta["isboundary"], hy.status)
     lb.wall_links_build(hy.status, meta["isboundary"])
     lb.wall_velocity_set(meta["ubot"], meta["utop"])
+    if meta["solid"] == 2:
+        _mark_colloids(lb, hy, g)
     lb.lb_memcpy_h2d(g["f0"])
     nv = meta["nvel"]
     for n in range(meta["nsteps"]):
@@ -195,3 +208,162 @@ def test_walls_on_the_slab_path(bnd, mode):
         lb.free()
     assert np.array_equal(out[0][0], out[1][0])
     assert np.max(np.abs(out[0][1] - out[1][1])) < 1e-13
+
+
+# Partial slip (wall_init_boundaries_slip, wall_bbl_slip_kernel)
+
+@pytest.mark.parametrize("mode", [0, 3], ids=["eager", "fused_halo"])
+@pytest.mark.parametrize("name", golden_slip_names())
+def test_slip_vs_reference(name, mode):
+    """Links k, q, s identical to the reference's; the values its slip kernel
+    wrote, four whole steps and the wall momentum."""
+    g = load_golden(name)
+    lb, hy, meta = _setup(g, mode)
+    lb.wall_map(meta["isboundary"], hy.status)
+    assert lb.wall_links_build(hy.status, meta["isboundary"]) == meta["nlink"]
+    lb.wall_slip_set(hy.status, meta["sbot"], meta["stop"])
+    lk, lq, ls = lb.wall_slip_links()
+    assert np.array_equal(lk, g["linkk"])
+    assert np.array_equal(lq, g["linkq"])
+    assert np.array_equal(ls, g["links"])
+    if meta["solid"] == 2:
+        _mark_colloids(lb, hy, g)
+    lb.lb_memcpy_h2d(g["f0"])
+    nv = meta["nvel"]
+    for n in range(meta["nsteps"]):
+        lb.lb_collide(hy)
+        lb.lb_halo()
+        lb.wall_bbl()
+        if n == 0:
+            f = lb.lb_memcpy_d2h().reshape(nv, -1)
+            ref = g["f_bbl"].reshape(nv, -1)
+            q = nv - g["linkp"]
+            assert np.max(np.abs(f[q, g["linkj"]] - ref[q, g["linkj"]])) < 1e-15
+        lb.lb_propagation()
+    f = lb.lb_memcpy_d2h()
+    fl = (g["status"] == 0)[1:-1, 1:-1, 1:-1]
+    assert relmax(interior(f, 1)[:, fl], interior(g["f_final"], 1)[:, fl]) < 1e-12
+    fnet = lb.wall_momentum()
+    scale = max(1.0, np.abs(np.array(meta["fnet"])).max())
+    assert np.max(np.abs(fnet - np.array(meta["fnet"]))) < 1e-12 * scale
+    # slip links pair up with one s: mass is conserved
+    if meta["solid"] != 2:
+        assert abs(interior(f, 1)[:, fl].sum() - interior(g["f0"], 1)[:, fl].sum()) < 1e-11
+    lb.free()
+
+
+def test_slip_arrays_entry_point_and_switch_off():
+    """lbmi_wall_bbl_slip_arrays on caller-owned device arrays in the
+    reference's types (int, int8_t, int8_t) = the handle's own links; all
+    fractions zero = the no-slip kernel again; bad fractions are refused."""
+    import ctypes
+    import ludwig_amd
+    import torch
+    from ludwig_amd import lib as L
+    g = load_golden("slip_q27_xy")
+    lb, hy, meta = _setup(g)
+    lb.wall_map(meta["isboundary"], hy.status)
+    lb.wall_links_build(hy.status, meta["isboundary"])
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.wall_slip_links()                            # not active yet
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.wall_slip_set(hy.status, (1.5, 0, 0), (0, 0, 0))
+    lb.wall_slip_set(hy.status, meta["sbot"], meta["stop"])
+    rng = np.random.default_rng(5)
+    f0 = rng.random((27,) + lb.nall)
+    lb.lb_memcpy_h2d(f0)
+    lb.wall_bbl()
+    mine = lb.lb_memcpy_d2h()
+    fnet_mine = lb.wall_momentum()
+
+    _, stab = lbo.wall_slip_table(meta["sbot"], meta["stop"])
+    dev = lb.device
+    li, lj, lp = [torch.tensor(g[k], dtype=torch.int32, device=dev)
+                  for k in ("linki", "linkj", "linkp")]
+    lk = torch.tensor(g["linkk"], dtype=torch.int32, device=dev)
+    lq = torch.tensor(g["linkq"].astype(np.int8), device=dev)
+    ls = torch.tensor(g["links"].astype(np.int8), device=dev)
+    fnet = torch.zeros(3, dtype=torch.float64, device=dev)
+    lb.lb_memcpy_h2d(f0)
+    torch.cuda.synchronize()
+    L.check(L.library().lbmi_wall_bbl_slip_arrays(
+        lb._h, len(g["linki"]), li.data_ptr(), lj.data_ptr(), lp.data_ptr(),
+        lk.data_ptr(), lq.data_ptr(), ls.data_ptr(),
+        (ctypes.c_double * 19)(*stab), fnet.data_ptr()))
+    lb.synchronize()
+    assert np.array_equal(lb.lb_memcpy_d2h(), mine)
+    assert np.array_equal(fnet.cpu().numpy(), fnet_mine)
+
+    # against the oracle on the same random state
+    p = lbo.make_param(27, meta["nlocal"], 1, "m10", meta["eta"], meta["zeta"])
+    ref = f0.copy()
+    fo = np.zeros(3)
+    lbo.wall_bbl_slip(p, ref, (g["linki"], g["linkj"], g["linkp"], g["linku"]),
+                      (g["linkk"], g["linkq"], g["links"]), stab, fo)
+    # (1-s) f_i + s f_k: one rounding (fma) here, two in the oracle
+    assert np.max(np.abs(mine - ref)) < 2e-16
+    assert np.max(np.abs(fnet_mine - fo)) < 1e-12 * max(1.0, np.abs(fo).max())
+
+    # slip off: plain bounce-back
+    lb.wall_slip_set(hy.status, (0, 0, 0), (0, 0, 0))
+    lb.lb_memcpy_h2d(f0)
+    lb.wall_bbl()
+    f = lb.lb_memcpy_d2h().reshape(27, -1)
+    q = 27 - g["linkp"]
+    assert np.array_equal(f[q, g["linkj"]], f0.reshape(27, -1)[g["linkp"], g["linki"]])
+    lb.free()
+
+
+def test_slip_refuses_solid_blocks():
+    """A link at a convex edge of a solid block has no wall normal: the
+    reference asserts (wall.c:557-558); here the call fails."""
+    import ludwig_amd
+    g = load_golden("wall_q19_xyz")                     # walls + a solid block
+    lb, hy, meta = _setup(g)
+    lb.wall_map(meta["isboundary"], hy.status)
+    lb.wall_links_build(hy.status, meta["isboundary"])
+    with pytest.raises(ludwig_amd.LbmiError):
+        lb.wall_slip_set(hy.status, (0.5, 0, 0), (0, 0, 0))
+    lb.free()
+
+
+@pytest.mark.parametrize("s", [0.0, 1.0])
+def test_slip_channel_flow(s):
+    """A body force along x between z walls: with free slip (s = 1) nothing
+    holds the fluid and the profile stays flat (plug flow, u = F t / rho);
+    with s = 0 the slip kernel is plain bounce-back and gives the parabola."""
+    import ludwig_amd
+    import torch
+    n = (4, 4, 12)
+    lb = ludwig_amd.LB(19, n, 1)
+    lb.relaxation_set("bgk", 1.0 / 6.0, 1.0 / 6.0)
+    fx = 1e-6
+    lb.body_force_set((fx, 0, 0))
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, status=np.zeros(lb.nall, dtype=np.int8))
+    torch.cuda.synchronize()
+    lb.wall_map((0, 0, 1), hy.status)
+    lb.wall_links_build(hy.status, (0, 0, 1))
+    if s > 0.0:
+        lb.wall_slip_set(hy.status, (0, 0, s), (0, 0, s))
+    w = ludwig_amd.model(19)["wv"]
+    f0 = np.zeros((19,) + lb.nall)
+    for p in range(19):
+        interior(f0[p], 1)[...] = w[p]
+    lb.lb_memcpy_h2d(f0)
+    nstep = 400
+    for _ in range(nstep):
+        lb.lb_collide(hy)
+        lb.lb_halo()
+        lb.wall_bbl()
+        lb.lb_propagation()
+    lb.lb_collide(hy)
+    lb.synchronize()
+    ux = interior(hy.u.cpu().numpy(), 1)[0].mean(axis=(0, 1))
+    if s == 1.0:
+        assert np.max(np.abs(ux - ux.mean())) < 1e-12
+        assert abs(ux.mean() - fx * (nstep + 0.5)) < 1e-3 * fx * nstep
+    else:
+        assert ux[0] < 0.5 * ux[n[2] // 2]             # held at the walls
+        assert np.allclose(ux, ux[::-1], rtol=0, atol=1e-12)
+    assert abs(lb.moments()[1] - n[0] * n[1] * n[2]) < 1e-9
+    lb.free()
