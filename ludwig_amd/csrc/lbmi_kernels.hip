@@ -2330,14 +2330,24 @@ void k_wall_bbl_slip(lbmi_kparam_t kp, lbmi_wall_tab_t tab,
   wall_block_sum(fsum[0], fsum[1], fsum[2], part);
 }
 
-__global__ void k_wall_fnet(int nblk, const double * __restrict__ part,
-			    double * __restrict__ fnet) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+/* One wavefront: lane l adds the partials of blocks l, l + 64, ... in that
+ * order, then a shuffle tree: a fixed order for a given number of blocks (no
+ * atomics), and 16 dependent steps instead of 1024 for the largest grid. */
+__global__ __launch_bounds__(64)
+void k_wall_fnet(int nblk, const double * __restrict__ part,
+		 double * __restrict__ fnet) {
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblk; b++) {
+  for (int b = threadIdx.x; b < nblk; b += 64) {
     s0 += part[3*b]; s1 += part[3*b + 1]; s2 += part[3*b + 2];
   }
-  fnet[0] += s0; fnet[1] += s1; fnet[2] += s2;
+  for (int d = 32; d > 0; d >>= 1) {
+    s0 += shfl_down_d(s0, d);
+    s1 += shfl_down_d(s1, d);
+    s2 += shfl_down_d(s2, d);
+  }
+  if (threadIdx.x == 0) {
+    fnet[0] += s0; fnet[1] += s1; fnet[2] += s2;
+  }
 }
 
 extern "C" int lbmi_k_collide(const lbmi_kparam_t * kp, double * f,
