@@ -87,6 +87,9 @@ def parse():
     ap.add_argument("--timing-period", type=int, default=4,
                     help="HIP-event timing of every k-th kernel launch inside "
                     "the timed region (1 = all)")
+    ap.add_argument("--own-stream", type=int, default=0,
+                    help="1: the library's private non-blocking stream "
+                    "instead of torch's current (the legacy default) stream")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
@@ -188,7 +191,8 @@ def main():
             "fused_halo": ludwig_amd.FUSED_HALO}[args.mode]
     lb = ludwig_amd.LB(args.nvel, dec.nlocal, args.nhalo, mode=mode,
                        halo_scheme=ludwig_amd.HALO_REDUCED, device=local_rank,
-                       cartsz=world, cartrank=rank)
+                       cartsz=world, cartrank=rank,
+                       own_stream=bool(args.own_stream))
     zeta = 0.3 if args.scheme == "m10" else 0.1
     lb.relaxation_set(args.scheme, 0.1, zeta)
     for kv in filter(None, args.tune.split(",")):
