@@ -247,8 +247,11 @@ int lbmi_lb_flush(lbmi_t * lb);
  * between (a host language with expensive foreign calls, a benchmark). */
 int lbmi_lb_run(lbmi_t * lb, const lbmi_hydro_t * hydro, int nsteps);
 
-/* ndist = 2, free_energy symmetric_lb (LBMI_MODE_EAGER): the
- * second distribution carries the order parameter. f holds both,
+/* ndist = 2, free_energy symmetric_lb (LBMI_MODE_EAGER or
+ * LBMI_MODE_FUSED_HALO: there lbmi_lb_propagation of both distributions is
+ * deferred into the next lbmi_lb_collide_binary, and lbmi_lb_phi_to_field
+ * called in between takes phi of the propagated state from the pending
+ * array): the second distribution carries the order parameter. f holds both,
  * f[(n*nvel + p)*nsite + index]; lbmi_lb_halo and lbmi_lb_propagation move
  * both; lbmi_lb_moments looks at n = 0 (as stats_distribution.c does).
  *   lbmi_lb_phi_to_field   phi_lb_to_field (phi_lb_coupler.c:39-112):

@@ -176,7 +176,7 @@ static lbmi_t * shim_handle(lb_t * lb) {
     opts.halo_scheme = LBMI_HALO_FULL;           /* halo_swap_packed semantics */
     opts.mode = LBMI_MODE_EAGER;
     if (mode && mode[0] == 'f' && lb->ndist == 1) opts.mode = LBMI_MODE_FUSED;
-    if (mode && mode[0] == 'h' && lb->ndist == 1) opts.mode = LBMI_MODE_FUSED_HALO;
+    if (mode && mode[0] == 'h') opts.mode = LBMI_MODE_FUSED_HALO;  /* ndist 1 or 2 */
 
     SHIM_CHECK(lb, lbmi_create(&opts, &shim_.h));
     /* Ludwig launches all its kernels on the default stream

@@ -227,9 +227,10 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   if (opts->ndist != 1 && opts->ndist != 2) {
     return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = %d: 1 or 2", opts->ndist);
   }
-  if (opts->ndist == 2 && opts->mode != LBMI_MODE_EAGER) {
+  if (opts->ndist == 2 && opts->mode != LBMI_MODE_EAGER &&
+      opts->mode != LBMI_MODE_FUSED_HALO) {
     /* the two-distribution (symmetric_lb) step: three stages */
-    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = 2 needs LBMI_MODE_EAGER");
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = 2 needs LBMI_MODE_EAGER or LBMI_MODE_FUSED_HALO");
   }
   if (opts->nhalo < 1) return lbmi_fail(LBMI_ERR_ARGUMENT, "nhalo < 1");
   for (int d = 0; d < 3; d++) {
@@ -1674,7 +1675,9 @@ int lbmi_lb_phi_to_field(lbmi_t * lb, double * phi) {
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   if (lb->opts.ndist != 2) return lbmi_fail(LBMI_ERR_STATE, "needs ndist = 2");
   HIPCHECK(hipSetDevice(lb->device));
-  KCHECK(lbmi_k_phi_from_g(&lb->kp, lb->f, phi, lb->stream));
+  /* FUSED_HALO with the propagation pending: phi of the propagated state,
+   * straight from the post-collision array (which has its halo) */
+  KCHECK(lbmi_k_phi_from_g(&lb->kp, lb->f, phi, lb->pending_prop, lb->stream));
   return 0;
 }
 
@@ -1695,9 +1698,24 @@ int lbmi_lb_collide_binary(lbmi_t * lb, const lbmi_hydro_t * hydro,
   h.status = NULL;
   h.eta = NULL;                    /* fixed rates, collision.c:862-876 */
   HIPCHECK(hipSetDevice(lb->device));
+  if (lb->pending_halo && !lb->pending_prop) {
+    return lbmi_fail(LBMI_ERR_STATE, "lb_collide after lb_halo without "
+		     "lb_propagation");
+  }
   /* (1/tau_2) = 2/(2M + 1), collision.c:1965-1968 */
-  KCHECK(lbmi_k_collide_binary(&lb->kp, lb->f, &h, fe->a, fe->b, fe->kappa,
-			       2.0/(1.0 + 2.0*fe->mobility), fe->phi,
+  if (lb->pending_prop) {
+    /* FUSED_HALO: propagation(t) of both distributions inside collision(t+1) */
+    KCHECK(lbmi_k_collide_binary(&lb->kp, lb->f, lb->fprime, &h, fe->a, fe->b,
+				 fe->kappa, 2.0/(1.0 + 2.0*fe->mobility),
+				 fe->phi, fe->grad, fe->delsq, lb->stream));
+    lb->pending_prop = 0;
+    lb->pending_halo = 0;
+    lb->halo_done = 0;
+    lbmi_swapf(lb);
+    return 0;
+  }
+  KCHECK(lbmi_k_collide_binary(&lb->kp, lb->f, lb->f, &h, fe->a, fe->b,
+			       fe->kappa, 2.0/(1.0 + 2.0*fe->mobility), fe->phi,
 			       fe->grad, fe->delsq, lb->stream));
   return 0;
 }
@@ -1723,8 +1741,11 @@ int lbmi_lb_halo(lbmi_t * lb) {
     }
     if (lb->opts.mode == LBMI_MODE_FUSED_HALO) {
       /* eager: f gets its halo now; only the propagation will be deferred */
-      int ifail = lbmi_halo(lb, lb->f, lb->opts.halo_scheme);
-      if (ifail) return ifail;
+      for (int n = 0; n < lb->opts.ndist; n++) {
+	size_t off = (size_t) n*(size_t) lb->kp.nvel*(size_t) lb->kp.nsite;
+	int ifail = lbmi_halo(lb, lb->f + off, lb->opts.halo_scheme);
+	if (ifail) return ifail;
+      }
       lb->halo_done = 1;
     }
     lb->pending_halo = 1;
@@ -1773,7 +1794,10 @@ int lbmi_lb_propagation(lbmi_t * lb) {
 	int ifail = lbmi_unblock(lb);
 	if (ifail) return ifail;
       }
-      KCHECK(lbmi_k_propagate(&lb->kp, lb->f, lb->fprime, lb->stream));
+      for (int n = 0; n < lb->opts.ndist; n++) {
+	size_t off = (size_t) n*(size_t) lb->kp.nvel*(size_t) lb->kp.nsite;
+	KCHECK(lbmi_k_propagate(&lb->kp, lb->f + off, lb->fprime + off, lb->stream));
+      }
       lbmi_swapf(lb);
       return 0;
     }
@@ -1838,7 +1862,10 @@ int lbmi_lb_flush(lbmi_t * lb) {
     lb->halo_done = 0;
   }
   if (lb->pending_prop) {
-    KCHECK(lbmi_k_propagate(&lb->kp, lb->f, lb->fprime, lb->stream));
+    for (int n = 0; n < lb->opts.ndist; n++) {
+      size_t off = (size_t) n*(size_t) lb->kp.nvel*(size_t) lb->kp.nsite;
+      KCHECK(lbmi_k_propagate(&lb->kp, lb->f + off, lb->fprime + off, lb->stream));
+    }
     lbmi_swapf(lb);
     lb->pending_prop = 0;
   }

@@ -154,9 +154,12 @@ int lbmi_k_collide_fe(const lbmi_kparam_t * kp, double * f,
 		      const double * delsq, void * stream);
 
 /* Two distributions (symmetric_lb): f2[(n*nvel + p)*nsite + i] */
+/* pull != 0 / src != f2: a propagation is pending on the array read (it has
+ * its halo): populations come from i - c_p, results go to f2 */
 int lbmi_k_phi_from_g(const lbmi_kparam_t * kp, const double * f2,
-		      double * phi, void * stream);
-int lbmi_k_collide_binary(const lbmi_kparam_t * kp, double * f2,
+		      double * phi, int pull, void * stream);
+int lbmi_k_collide_binary(const lbmi_kparam_t * kp, const double * src,
+			  double * f2,
 			  const lbmi_hydro_dev_t * h, double a, double b,
 			  double kappa, double rtau2, const double * phi,
 			  const double * grad, const double * delsq,

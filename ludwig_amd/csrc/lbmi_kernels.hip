@@ -1736,10 +1736,11 @@ void k_symm_fe_step_tiled(lbmi_kparam_t kp, Symm q, double mobility, int order,
  * is re-projected from phi, jphi (relaxed towards phi u at rtau2) and
  * sphi = phi u u + mu delta. f2[(n*NVEL + p)*nsite + i]. */
 
-template <int NVEL>
+template <int NVEL, bool PULL>
 __global__ __launch_bounds__(BLOCK)
 void k_phi_from_g(lbmi_kparam_t kp, const double * __restrict__ f2,
 		  double * __restrict__ phi, int i0, int i1, unsigned nblk) {
+  using M = Model<NVEL>;
   unsigned lb;
   if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
   int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
@@ -1749,13 +1750,23 @@ void k_phi_from_g(lbmi_kparam_t kp, const double * __restrict__ f2,
   const size_t ns = (size_t) kp.nsite;
   const double * __restrict__ g = f2 + ns*NVEL;
   double sum = 0.0;
-  static_for<0, NVEL>([&](auto P) { sum += g[ns*P + i]; });
+  /* PULL: the propagation is pending (FUSED_HALO): population p of this
+   * site still sits at i - c_p of the post-collision array, halo included */
+  static_for<0, NVEL>([&](auto P) {
+    constexpr int p = P;
+    const int off = PULL ? (M::c(p,0)*kp.strx + M::c(p,1)*kp.stry + M::c(p,2)) : 0;
+    sum += g[ns*p + (i - off)];
+  });
   phi[i] = sum;
 }
 
-template <int NVEL, int SCHEME>
+/* PULL = false: in place on f2 (src == f2). PULL = true: propagation(t)
+ * fused in: populations pulled from src (the post-collision array with its
+ * halo), results written to f2 (the other array), as k_propagate_collide
+ * does for one distribution. */
+template <int NVEL, int SCHEME, bool PULL>
 __global__ __launch_bounds__(BLOCK)
-void k_collide_binary(lbmi_kparam_t kp, double * __restrict__ f2,
+void k_collide_binary(lbmi_kparam_t kp, const double * src, double * f2,
 		      lbmi_hydro_dev_t h, Symm q, double rtau2,
 		      const double * __restrict__ phi,
 		      const double * __restrict__ grad,
@@ -1771,12 +1782,17 @@ void k_collide_binary(lbmi_kparam_t kp, double * __restrict__ f2,
   if (!s.interior) return;
 
   const size_t ns = (size_t) kp.nsite;
-  double * __restrict__ g = f2 + ns*NVEL;
+  double * g = f2 + ns*NVEL;
+  const double * gsrc = src + ns*NVEL;
 
   double fl[NVEL];
-  static_for<0, NVEL>([&](auto P) { fl[P] = f2[ns*P + i]; });
   double gl[NVEL];
-  static_for<1, NVEL>([&](auto P) { gl[P] = g[ns*P + i]; });
+  static_for<0, NVEL>([&](auto P) {
+    constexpr int p = P;
+    const int off = PULL ? (M::c(p,0)*kp.strx + M::c(p,1)*kp.stry + M::c(p,2)) : 0;
+    fl[p] = src[ns*p + (i - off)];
+    if constexpr (p > 0) gl[p] = gsrc[ns*p + (i - off)];
+  });
 
   double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
   if (h.force) {
@@ -2775,16 +2791,24 @@ extern "C" int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, int npt,
 }
 
 extern "C" int lbmi_k_phi_from_g(const lbmi_kparam_t * kp, const double * f2,
-				 double * phi, void * stream) {
+				 double * phi, int pull, void * stream) {
   hipStream_t st = (hipStream_t) stream;
   Range1D r = interior_range(*kp);
   dim3 grid(r.grid), block(BLOCK);
-  if (kp->nvel == 19) {
-    hipLaunchKernelGGL((k_phi_from_g<19>), grid, block, 0, st, *kp, f2, phi,
+  if (kp->nvel == 19 && !pull) {
+    hipLaunchKernelGGL((k_phi_from_g<19, false>), grid, block, 0, st, *kp, f2, phi,
+		       r.i0, r.i1, r.nblk);
+  }
+  else if (kp->nvel == 19) {
+    hipLaunchKernelGGL((k_phi_from_g<19, true>), grid, block, 0, st, *kp, f2, phi,
+		       r.i0, r.i1, r.nblk);
+  }
+  else if (kp->nvel == 27 && !pull) {
+    hipLaunchKernelGGL((k_phi_from_g<27, false>), grid, block, 0, st, *kp, f2, phi,
 		       r.i0, r.i1, r.nblk);
   }
   else if (kp->nvel == 27) {
-    hipLaunchKernelGGL((k_phi_from_g<27>), grid, block, 0, st, *kp, f2, phi,
+    hipLaunchKernelGGL((k_phi_from_g<27, true>), grid, block, 0, st, *kp, f2, phi,
 		       r.i0, r.i1, r.nblk);
   }
   else {
@@ -2793,8 +2817,9 @@ extern "C" int lbmi_k_phi_from_g(const lbmi_kparam_t * kp, const double * f2,
   return (int) hipGetLastError();
 }
 
-template <int NVEL>
-static int launch_collide_binary(const lbmi_kparam_t & kp, double * f2,
+template <int NVEL, bool PULL>
+static int launch_collide_binary(const lbmi_kparam_t & kp, const double * src,
+				 double * f2,
 				 const lbmi_hydro_dev_t & h, Symm q,
 				 double rtau2, const double * phi,
 				 const double * grad, const double * delsq,
@@ -2803,17 +2828,17 @@ static int launch_collide_binary(const lbmi_kparam_t & kp, double * f2,
   dim3 grid(r.grid), block(BLOCK);
   switch (kp.scheme) {
   case LBMI_M10:
-    hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_M10>), grid, block, 0, st,
-		       kp, f2, h, q, rtau2, phi, grad, delsq, r.i0, r.i1, r.nblk);
+    hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_M10, PULL>), grid, block, 0, st,
+		       kp, src, f2, h, q, rtau2, phi, grad, delsq, r.i0, r.i1, r.nblk);
     break;
   case LBMI_BGK:
-    hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_BGK>), grid, block, 0, st,
-		       kp, f2, h, q, rtau2, phi, grad, delsq, r.i0, r.i1, r.nblk);
+    hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_BGK, PULL>), grid, block, 0, st,
+		       kp, src, f2, h, q, rtau2, phi, grad, delsq, r.i0, r.i1, r.nblk);
     break;
   case LBMI_TRT:
     if constexpr (NVEL == 19) {
-      hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_TRT>), grid, block, 0,
-			 st, kp, f2, h, q, rtau2, phi, grad, delsq, r.i0, r.i1,
+      hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_TRT, PULL>), grid, block, 0,
+			 st, kp, src, f2, h, q, rtau2, phi, grad, delsq, r.i0, r.i1,
 			 r.nblk);
       break;
     }
@@ -2824,15 +2849,23 @@ static int launch_collide_binary(const lbmi_kparam_t & kp, double * f2,
   return (int) hipGetLastError();
 }
 
-extern "C" int lbmi_k_collide_binary(const lbmi_kparam_t * kp, double * f2,
+extern "C" int lbmi_k_collide_binary(const lbmi_kparam_t * kp,
+				     const double * src, double * f2,
 				     const lbmi_hydro_dev_t * h, double a,
 				     double b, double kappa, double rtau2,
 				     const double * phi, const double * grad,
 				     const double * delsq, void * stream) {
   hipStream_t st = (hipStream_t) stream;
   Symm q = {a, b, kappa};
-  if (kp->nvel == 19) return launch_collide_binary<19>(*kp, f2, *h, q, rtau2, phi, grad, delsq, st);
-  if (kp->nvel == 27) return launch_collide_binary<27>(*kp, f2, *h, q, rtau2, phi, grad, delsq, st);
+  /* src == f2: in place; otherwise pull from src (propagation fused in) */
+  if (src == f2) {
+    if (kp->nvel == 19) return launch_collide_binary<19, false>(*kp, f2, f2, *h, q, rtau2, phi, grad, delsq, st);
+    if (kp->nvel == 27) return launch_collide_binary<27, false>(*kp, f2, f2, *h, q, rtau2, phi, grad, delsq, st);
+  }
+  else {
+    if (kp->nvel == 19) return launch_collide_binary<19, true>(*kp, src, f2, *h, q, rtau2, phi, grad, delsq, st);
+    if (kp->nvel == 27) return launch_collide_binary<27, true>(*kp, src, f2, *h, q, rtau2, phi, grad, delsq, st);
+  }
   return (int) hipErrorInvalidValue;
 }
 

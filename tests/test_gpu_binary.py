@@ -12,9 +12,9 @@ from oracle import lb_oracle as lbo                                    # noqa: E
 from tests.common import golden_binary_names, interior, load_golden, relmax  # noqa: E402
 
 
-def _lb(meta, scheme="m10"):
+def _lb(meta, scheme="m10", mode=0):
     import ludwig_amd
-    lb = ludwig_amd.LB(meta["nvel"], tuple(meta["nlocal"]), 1, ndist=2)
+    lb = ludwig_amd.LB(meta["nvel"], tuple(meta["nlocal"]), 1, ndist=2, mode=mode)
     lb.relaxation_set(scheme, meta["eta"], meta["zeta"])
     lb.body_force_set(meta["fbody"])
     return lb
@@ -60,14 +60,17 @@ def test_binary_collision_vs_reference(name):
     lb.free()
 
 
+@pytest.mark.parametrize("mode", [0, 3], ids=["eager", "fused_halo"])
 @pytest.mark.parametrize("name", golden_binary_names())
-def test_binary_steps_vs_reference(name):
-    """Whole steps as ludwig.c runs them with free_energy symmetric_lb."""
+def test_binary_steps_vs_reference(name, mode):
+    """Whole steps as ludwig.c runs them with free_energy symmetric_lb.
+    FUSED_HALO: the propagation of both distributions is deferred into the
+    next collision, and phi_lb_to_field pulls from the pending state."""
     import ludwig_amd
     import torch
     g = load_golden(name)
     meta = g["meta"]
-    lb = _lb(meta)
+    lb = _lb(meta, mode=mode)
     hy = ludwig_amd.Hydro(lb.nall, lb.device)
     lb.fe_scheme_set(27, 1)
     phi = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
@@ -92,8 +95,9 @@ def test_binary_steps_vs_reference(name):
     lb.free()
 
 
+@pytest.mark.parametrize("mode", [0, 3], ids=["eager", "fused_halo"])
 @pytest.mark.parametrize("nvel,scheme", [(19, "bgk"), (19, "trt"), (27, "bgk")])
-def test_binary_seeded_vs_oracle(nvel, scheme):
+def test_binary_seeded_vs_oracle(nvel, scheme, mode):
     """Larger box, other relaxation schemes, a force field: oracle parity."""
     import ludwig_amd
     import torch
@@ -114,7 +118,7 @@ def test_binary_seeded_vs_oracle(nvel, scheme):
     for _ in range(3):
         f2, fp2, _, _, _ = lbo.step_binary(p, f2, fp2, a, b, kappa, mob, force, u)
 
-    lb = ludwig_amd.LB(nvel, nlocal, 1, ndist=2)
+    lb = ludwig_amd.LB(nvel, nlocal, 1, ndist=2, mode=mode)
     lb.relaxation_set(scheme, 0.1, 0.2)
     lb.body_force_set((1e-6, 0, 0))
     lb.fe_scheme_set(27, 1)
@@ -139,6 +143,8 @@ def test_binary_rejections():
     import ludwig_amd
     with pytest.raises(ludwig_amd.LbmiError):
         ludwig_amd.LB(19, (4, 4, 4), 1, ndist=2, mode=ludwig_amd.FUSED)
+    with pytest.raises(ludwig_amd.LbmiError):
+        ludwig_amd.LB(19, (4, 4, 4), 1, ndist=2, mode=ludwig_amd.INPLACE)
     with pytest.raises(ludwig_amd.LbmiError):
         ludwig_amd.LB(19, (4, 4, 4), 1, ndist=3)
     lb = ludwig_amd.LB(19, (4, 4, 4), 1, ndist=2)
@@ -184,7 +190,8 @@ def test_stress_relaxation_vs_reference(name, mode):
     lb.free()
 
 
-def test_binary_steps_on_the_slab_path():
+@pytest.mark.parametrize("mode", [0, 3], ids=["eager", "fused_halo"])
+def test_binary_steps_on_the_slab_path(mode):
     """ndist = 2 with the X halo of both distributions and of phi through a
     1-rank RCCL ring = the single-rank run, bit for bit."""
     import ludwig_amd
@@ -193,7 +200,7 @@ def test_binary_steps_on_the_slab_path():
     meta = g["meta"]
     out = []
     for ring in (False, True):
-        lb = _lb(meta)
+        lb = _lb(meta, mode=mode)
         if ring:
             lb.comm_init(ludwig_amd.LB.comm_unique_id())
         hy = ludwig_amd.Hydro(lb.nall, lb.device)
@@ -214,3 +221,52 @@ def test_binary_steps_on_the_slab_path():
         lb.free()
     assert np.array_equal(out[0], out[1])
     assert relmax(out[1], interior(g["f_final"], 1)) < 1e-12
+
+
+def test_binary_fused_halo_is_eager_at_every_observation():
+    """FUSED_HALO with two distributions: copies out after any call of the
+    step, the wall bounce-back between lb_halo and lb_propagation, and phi
+    taken while the propagation is pending, all equal EAGER bit for bit."""
+    import ludwig_amd
+    import torch
+    g = load_golden("bin_q19_a")
+    meta = g["meta"]
+    nv = meta["nvel"]
+    obs = []
+    for mode in (0, 3):
+        rec = []
+        lb = _lb(meta, mode=mode)
+        hy = ludwig_amd.Hydro(lb.nall, lb.device,
+                              status=np.zeros(lb.nall, dtype=np.int8))
+        torch.cuda.synchronize()
+        lb.wall_map((0, 0, 1), hy.status)
+        lb.wall_links_build(hy.status, (0, 0, 1))
+        lb.wall_velocity_set((0.01, 0, 0), (-0.01, 0, 0))
+        lb.fe_scheme_set(7, 1)
+        phi = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+        grad = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+        delsq = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+        lb.lb_memcpy_h2d(g["f0"])
+        for n in range(5):
+            lb.phi_to_field(phi)
+            rec.append(interior(_host(lb, phi), 1).copy())
+            lb.field_halo_n(phi, 1)
+            lb.field_grad(phi, grad, delsq)
+            lb.lb_collide_binary(hy, meta["a"], meta["b"], meta["kappa"],
+                                 meta["mobility"], phi, grad, delsq)
+            if n == 1:
+                rec.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+            lb.lb_halo()
+            lb.wall_bbl()
+            if n == 2:
+                rec.append(lb.lb_memcpy_d2h().copy())       # halo and bounce included
+            lb.lb_propagation()
+            if n == 3:
+                rec.append(interior(lb.lb_memcpy_d2h(), 1).copy())   # flushes
+        rec.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+        rec.append(lb.wall_momentum())
+        lb.free()
+        obs.append(rec)
+    assert len(obs[0]) == len(obs[1])
+    for a, b in zip(obs[0], obs[1]):
+        assert np.array_equal(a, b)

@@ -64,9 +64,9 @@ def walls(args, mode, slip):
              "" if t_bbl is None else " (wall_bbl alone %.4f ms)" % t_bbl), flush=True)
 
 
-def binary(args):
+def binary(args, mode):
     n = tuple(args.size)
-    lb = ludwig_amd.LB(19, n, 2, ndist=2)            # nhalo 2: field gradients
+    lb = ludwig_amd.LB(19, n, 2, ndist=2, mode=mode)  # nhalo 2: field gradients
     lb.relaxation_set("m10", 0.1, 0.3)
     hy = ludwig_amd.Hydro(lb.nall, lb.device, force=np.zeros((3,) + lb.nall))
     dev = lb.device
@@ -92,6 +92,12 @@ def binary(args):
         lb.lb_propagation()
 
     ms = timed(step, lb, args.steps)
+    sites = n[0] * n[1] * n[2]
+    if mode != ludwig_amd.EAGER:
+        print("two distributions (symmetric_lb), FUSED_HALO: %.4f ms/step = %.0f MLUPS"
+              % (ms, 1e-3 * sites / ms), flush=True)
+        lb.free()
+        return
     parts = {}
     for name, fn in (("phi_lb_to_field", lambda: lb.phi_to_field(phi)),
                      ("field_halo", lambda: lb.field_halo_n(phi, 2)),
@@ -116,7 +122,8 @@ def main():
     for mode in (ludwig_amd.EAGER, ludwig_amd.FUSED_HALO):
         for slip in (0, 1):
             walls(args, mode, slip)
-    binary(args)
+    binary(args, ludwig_amd.EAGER)
+    binary(args, ludwig_amd.FUSED_HALO)
 
 
 if __name__ == "__main__":
