@@ -1379,9 +1379,13 @@ template <int NPT>
 __global__ __launch_bounds__(BLOCK)
 void k_grad(lbmi_kparam_t kp, const double * __restrict__ phi,
 	    double * __restrict__ grad, double * __restrict__ delsq,
-	    int i0, int i1) {
-  int i = i0 + (int) (blockIdx.x*BLOCK + threadIdx.x);
-  if (i >= i1) return;
+	    int i0, int i1, unsigned nblk) {
+  /* XCD-aware block order: neighbouring blocks (which share the y+-1 rows
+   * and x+-1 planes of phi) on the same XCD, i.e. behind the same L2 */
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
   Site s = decode(kp, i);
   const int ne = kp.nhalo - 1;
   const int nh = kp.nhalo;
@@ -2649,14 +2653,16 @@ extern "C" int lbmi_k_grad(const lbmi_kparam_t * kp, int npt,
   int ne = kp->nhalo - 1;
   int i0 = (kp->nhalo - ne)*kp->strx;
   int i1 = (kp->nhalo + kp->nlocal[0] + ne)*kp->strx;
-  dim3 grid((unsigned) ((i1 - i0 + BLOCK - 1)/BLOCK)), block(BLOCK);
+  int i0a = (i0/LBMI_ALIGN)*LBMI_ALIGN;
+  unsigned nblk = (unsigned) ((i1 - i0a + BLOCK - 1)/BLOCK);
+  dim3 grid(grid_for(nblk, (unsigned) kp->xcd_group)), block(BLOCK);
   if (npt == 27) {
     hipLaunchKernelGGL((k_grad<27>), grid, block, 0, st, *kp, phi, grad,
-		       delsq, i0, i1);
+		       delsq, i0, i1, nblk);
   }
   else {
     hipLaunchKernelGGL((k_grad<7>), grid, block, 0, st, *kp, phi, grad, delsq,
-		       i0, i1);
+		       i0, i1, nblk);
   }
   return (int) hipGetLastError();
 }
