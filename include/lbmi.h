@@ -525,7 +525,11 @@ int lbmi_timing_read(lbmi_t * lb, double * ms_total, int * nlaunch);
  *            per direction (default), 0 = zero-copy sends of the planes;
  * "x_concurrent": 1 = slabs: the two boundary planes run on a third stream
  *            beside the interior launch once the halo has arrived (default),
- *            0 = after it on the compute stream. */
+ *            0 = after it on the compute stream;
+ * "graph":   1 = lbmi_lb_run on one GPU in FUSED mode issues its steps as
+ *            launches of ONE hipGraph holding two steady-state steps (for
+ *            lattices whose step is as short as a launch), 0 = step by step
+ *            (default). */
 int lbmi_tune(lbmi_t * lb, const char * key, int value);
 
 /* ---- multi-GPU: 1-d slab decomposition along X over RCCL ---------------- */

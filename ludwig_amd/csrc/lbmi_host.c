@@ -89,6 +89,18 @@ struct lbmi_s {
   double wall_ubot[3];
   double wall_utop[3];
   const char * wall_status;          /* device map for the MAP_COLLOID test */
+  /* lbmi_lb_run: two steady-state steps captured in a hipGraph */
+  int use_graph;
+  hipGraphExec_t run_graph;
+  hipEvent_t ev_graph;
+  struct {
+    const double * f;
+    const double * fprime;
+    lbmi_hydro_dev_t h;
+    lbmi_kparam_t kp;
+    int nt_store_mode;
+    hipStream_t stream;
+  } run_key;
   int slip_active;                   /* wall_slip_t */
   double slip_s[19];
   int * slip_k_dev;                  /* linkk, linkq, links (device) */
@@ -381,6 +393,7 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
  *****************************************************************************/
 
 static void lbmi_wall_release(lbmi_t * lb);
+static void lbmi_run_graph_release(lbmi_t * lb);
 
 int lbmi_free(lbmi_t * lb) {
 
@@ -400,6 +413,8 @@ int lbmi_free(lbmi_t * lb) {
   if (lb->mom_work) hipFree(lb->mom_work);
   if (lb->mom_out) hipFree(lb->mom_out);
   lbmi_wall_release(lb);
+  lbmi_run_graph_release(lb);
+  if (lb->ev_graph) hipEventDestroy(lb->ev_graph);
   if (lb->ev_created) {
     for (int n = 0; n < LBMI_NEVENT; n++) {
       if (lb->ev0[n]) hipEventDestroy(lb->ev0[n]);
@@ -616,6 +631,12 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
   }
   if (strcmp(key, "x_concurrent") == 0) {
     lb->x_concurrent = (value != 0);
+    return 0;
+  }
+  if (strcmp(key, "graph") == 0) {
+    /* lbmi_lb_run on one GPU in FUSED mode: pairs of steps as one hipGraph
+     * launch (fewer, cheaper launches for lattices whose step is short) */
+    lb->use_graph = (value != 0);
     return 0;
   }
   if (strcmp(key, "blocked") == 0) {
@@ -1876,14 +1897,112 @@ int lbmi_lb_flush(lbmi_t * lb) {
 /* nsteps of the LB part of the main loop (ludwig.c:802-860) in one call:
  * lb_collide, lb_halo, lb_propagation with the same hydro object each step */
 
+static int lbmi_one_step(lbmi_t * lb, const lbmi_hydro_t * hydro) {
+  int ifail = lbmi_lb_collide(lb, hydro);
+  if (ifail) return ifail;
+  ifail = lbmi_lb_halo(lb);
+  if (ifail) return ifail;
+  return lbmi_lb_propagation(lb);
+}
+
+static void lbmi_run_graph_release(lbmi_t * lb) {
+  if (lb->run_graph) hipGraphExecDestroy(lb->run_graph);
+  lb->run_graph = NULL;
+  memset(&lb->run_key, 0, sizeof(lb->run_key));
+}
+
+/* The steady state of FUSED on one GPU is ONE kernel per step, f -> fprime
+ * and back: two steps leave the handle where it was, so a graph of two steps
+ * can be launched any number of times. Captured through the ordinary step
+ * functions (capture records the launches, the host-side state advances as
+ * usual), keyed on everything the two launches carry by value or address. */
+
+static int lbmi_run_graph_pairs(lbmi_t * lb, const lbmi_hydro_t * hydro,
+				int npairs) {
+  lbmi_hydro_dev_t h = lbmi_hydro_dev(hydro);
+  /* the legacy default stream cannot be captured: borrow the private one */
+  hipStream_t user = lb->stream;
+  hipStream_t cs = (user != NULL) ? user : lb->own_stream;
+
+  if (lb->ev_graph == NULL) {
+    HIPCHECK(hipEventCreateWithFlags(&lb->ev_graph, hipEventDisableTiming));
+  }
+  if (lb->run_graph == NULL || lb->run_key.f != lb->f ||
+      lb->run_key.fprime != lb->fprime || lb->run_key.stream != cs ||
+      lb->run_key.nt_store_mode != lb->nt_store_mode ||
+      memcmp(&lb->run_key.h, &h, sizeof(h)) != 0 ||
+      memcmp(&lb->run_key.kp, &lb->kp, sizeof(lb->kp)) != 0) {
+    hipGraph_t graph = NULL;
+    int ifail = 0;
+    lbmi_run_graph_release(lb);
+    lb->run_key.f = lb->f;
+    lb->run_key.fprime = lb->fprime;
+    lb->run_key.h = h;
+    lb->run_key.nt_store_mode = lb->nt_store_mode;
+    lb->run_key.stream = cs;
+    HIPCHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    lb->stream = cs;
+    ifail = lbmi_one_step(lb, hydro);
+    if (ifail == 0) ifail = lbmi_one_step(lb, hydro);
+    lb->stream = user;
+    if (hipStreamEndCapture(cs, &graph) != hipSuccess || ifail != 0 ||
+	graph == NULL) {
+      if (graph) hipGraphDestroy(graph);
+      lbmi_run_graph_release(lb);
+      return ifail ? ifail : lbmi_fail(LBMI_ERR_HIP, "lbmi_lb_run: stream capture");
+    }
+    /* (kp after the capture: the launches set kp.nt_store on the way) */
+    lb->run_key.kp = lb->kp;
+    if (hipGraphInstantiate(&lb->run_graph, graph, NULL, NULL, 0) != hipSuccess) {
+      hipGraphDestroy(graph);
+      lbmi_run_graph_release(lb);
+      return lbmi_fail(LBMI_ERR_HIP, "lbmi_lb_run: hipGraphInstantiate");
+    }
+    HIPCHECK(hipGraphDestroy(graph));
+    /* nothing has run yet: the capture advanced the host-side state by two
+     * steps, which leaves it where it was; the launches below do the work */
+  }
+
+  if (cs != user) {
+    HIPCHECK(hipEventRecord(lb->ev_graph, user));
+    HIPCHECK(hipStreamWaitEvent(cs, lb->ev_graph, 0));
+  }
+  for (int n = 0; n < npairs; n++) {
+    HIPCHECK(hipGraphLaunch(lb->run_graph, cs));
+  }
+  if (cs != user) {
+    HIPCHECK(hipEventRecord(lb->ev_graph, cs));
+    HIPCHECK(hipStreamWaitEvent(user, lb->ev_graph, 0));
+  }
+  return 0;
+}
+
 int lbmi_lb_run(lbmi_t * lb, const lbmi_hydro_t * hydro, int nsteps) {
+  int n = 0;
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
-  for (int n = 0; n < nsteps; n++) {
-    int ifail = lbmi_lb_collide(lb, hydro);
-    if (ifail) return ifail;
-    ifail = lbmi_lb_halo(lb);
-    if (ifail) return ifail;
-    ifail = lbmi_lb_propagation(lb);
+
+  if (lb->use_graph && lb->opts.mode == LBMI_MODE_FUSED &&
+      lb->opts.cartsz == 1 && !lb->have_comm && lb->opts.ndist == 1 &&
+      hydro != NULL && !lb->timing && nsteps >= 6) {
+    /* two ordinary steps reach the steady state from wherever the handle is
+     * (after a flush: collide in place, then SoA -> blocked) */
+    for (; n < 2; n++) {
+      int ifail = lbmi_one_step(lb, hydro);
+      if (ifail) return ifail;
+    }
+    if (lb->pending_prop && lb->pending_halo && !lb->layout_swapped &&
+	(lb->blocked != 0) == (lbmi_blocked_ok(lb) != 0)) {
+      int npairs = (nsteps - n)/2;
+      int ifail;
+      HIPCHECK(hipSetDevice(lb->device));
+      ifail = lbmi_run_graph_pairs(lb, hydro, npairs);
+      if (ifail) return ifail;
+      n += 2*npairs;
+    }
+  }
+
+  for (; n < nsteps; n++) {
+    int ifail = lbmi_one_step(lb, hydro);
     if (ifail) return ifail;
   }
   return 0;

@@ -323,3 +323,46 @@ def _fuzz(mode, seed, tmp_path, ring):
     for k, (a, b) in enumerate(zip(ref, out)):
         scale = max(1.0, float(np.max(np.abs(a))))
         assert np.max(np.abs(np.asarray(a) - np.asarray(b))) < 1e-13 * scale, (k, script)
+
+
+@pytest.mark.parametrize("own_stream", [False, True], ids=["torch_stream", "own_stream"])
+@pytest.mark.parametrize("nvel,scheme", [(19, "m10"), (19, "trt"), (27, "bgk")])
+def test_lb_run_as_graph_equals_steps(nvel, scheme, own_stream):
+    """tune("graph", 1): lbmi_lb_run launches pairs of steady-state steps as
+    one hipGraph. Same results as step by step, bit for bit: odd and even
+    counts, from a fresh and from a flushed handle, after the parameters or the
+    arrays changed (the graph is keyed on them), and observers in between."""
+    import ludwig_amd
+    import torch
+    n = (24, 12, 20)
+    p = lbo.make_param(nvel, n, 1, scheme, 0.1, 0.2)
+    f0 = lbo.init_synthetic(p)
+    frc = 1e-6 * np.random.default_rng(3).standard_normal((3,) + lbo.nall(p))
+    out = []
+    for graph in (0, 1):
+        lb = ludwig_amd.LB(nvel, n, 1, mode=ludwig_amd.FUSED, own_stream=own_stream)
+        lb.relaxation_set(scheme, 0.1, 0.2)
+        lb.tune("graph", graph)
+        hy = ludwig_amd.Hydro(lb.nall, lb.device, force=frc)
+        torch.cuda.synchronize()
+        lb.lb_memcpy_h2d(f0)
+        rec = []
+        lb.run(hy, 9)                                   # odd: 2 + 3 pairs + 1
+        rec.append(interior(lb.lb_memcpy_d2h(), 1).copy())      # flushes
+        lb.run(hy, 12)                                  # from a flushed handle
+        lb.run(hy, 7)                                   # graph re-used or re-keyed
+        rec.append(lb.moments())
+        lb.body_force_set((1e-6, 0, -2e-6))             # parameters by value in the graph
+        lb.run(hy, 8)
+        rec.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+        lb.step(hy)                                     # parity of f / fprime changes
+        lb.run(hy, 10)
+        lb.synchronize()
+        rec.append(interior(hy.u.cpu().numpy(), 1).copy())
+        rec.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+        lb.run(hy, 3)                                   # too short for the graph
+        rec.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+        lb.free()
+        out.append(rec)
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
