@@ -84,7 +84,7 @@ def parse():
                     "ring (exercises the N>1 step path: pack, send/recv, "
                     "unpack, interior/boundary split)")
     ap.add_argument("--tune", default="", help="key=value,... (lbmi_tune)")
-    ap.add_argument("--timing-period", type=int, default=4,
+    ap.add_argument("--timing-period", type=int, default=8,
                     help="HIP-event timing of every k-th kernel launch inside "
                     "the timed region (1 = all)")
     ap.add_argument("--own-stream", type=int, default=0,
