@@ -461,9 +461,9 @@ int lbmi_symmetric_step_grad(lbmi_t * lb, double a, double b, double kappa,
 
 /* The on-disk record stream of the distribution files, lb_io_aggr_pack /
  * lb_io_aggr_unpack with lb_write_buf / lb_read_buf (model.c:1385-1430,
- * 1479-1550): nvel doubles in p order per interior site, sites in
+ * 1479-1550): ndist*nvel doubles in [n][p] order per interior site, sites in
  * (ic, jc, kc) order. records: DEVICE buffer of nlocal[X]*nlocal[Y]*
- * nlocal[Z]*nvel doubles. pack flushes a deferred state first. */
+ * nlocal[Z]*ndist*nvel doubles. pack flushes a deferred state first. */
 int lbmi_lb_records_pack(lbmi_t * lb, double * records);
 int lbmi_lb_records_unpack(lbmi_t * lb, const double * records);
 

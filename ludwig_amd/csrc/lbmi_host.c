@@ -2276,16 +2276,14 @@ int lbmi_symmetric_step_grad(lbmi_t * lb, double a, double b, double kappa,
 int lbmi_lb_records_pack(lbmi_t * lb, double * records) {
   int ifail;
   if (lb == NULL || records == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
-  if (lb->opts.ndist != 1) return lbmi_fail(LBMI_ERR_UNSUPPORTED, "records: ndist = 1 only");
   ifail = lbmi_lb_flush(lb);
   if (ifail) return ifail;
-  KCHECK(lbmi_k_records(&lb->kp, lb->f, records, 1, lb->stream));
+  KCHECK(lbmi_k_records(&lb->kp, lb->opts.ndist, lb->f, records, 1, lb->stream));
   return 0;
 }
 
 int lbmi_lb_records_unpack(lbmi_t * lb, const double * records) {
   if (lb == NULL || records == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
-  if (lb->opts.ndist != 1) return lbmi_fail(LBMI_ERR_UNSUPPORTED, "records: ndist = 1 only");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   HIPCHECK(hipSetDevice(lb->device));
   /* reading a checkpoint replaces the state: nothing stays pending */
@@ -2298,7 +2296,8 @@ int lbmi_lb_records_unpack(lbmi_t * lb, const double * records) {
   if (lb->layout_swapped) {
     lb->layout_swapped = 0;
   }
-  KCHECK(lbmi_k_records(&lb->kp, lb->f, (double *) records, 0, lb->stream));
+  KCHECK(lbmi_k_records(&lb->kp, lb->opts.ndist, lb->f, (double *) records, 0,
+			lb->stream));
   return 0;
 }
 
@@ -2435,7 +2434,6 @@ static int lbmi_io_transfer(lbmi_t * lb, const char * fn, int writing,
 static int lbmi_io_args(lbmi_t * lb, const char * dir, int ntotal_x,
 			int offset_x) {
   if (lb == NULL || dir == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
-  if (lb->opts.ndist != 1) return lbmi_fail(LBMI_ERR_UNSUPPORTED, "i/o: ndist = 1 only");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   if (offset_x < 0 || offset_x + lb->kp.nlocal[X] > ntotal_x) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "planes %d..%d outside 0..%d", offset_x,
@@ -2455,14 +2453,14 @@ int lbmi_lb_io_write(lbmi_t * lb, const char * dir, int timestep,
   if (ifail) return ifail;
   if (offset_x == 0) {
     int ntotal[3] = {ntotal_x, lb->kp.nlocal[Y], lb->kp.nlocal[Z]};
-    ifail = lbmi_io_metadata_write(dir, "dist", lb->kp.nvel, ntotal);
+    ifail = lbmi_io_metadata_write(dir, "dist", lb->kp.nvel*lb->opts.ndist, ntotal);
     if (ifail) return ifail;
   }
   ifail = lbmi_io_filename(dir, "dist", timestep, fn, sizeof(fn));
   if (ifail) return ifail;
   /* fprime is dead between steps once nothing is pending: pack there */
-  KCHECK(lbmi_k_records(&lb->kp, lb->f, lb->fprime, 1, lb->stream));
-  plane = sizeof(double)*(size_t) lb->kp.nvel*lb->kp.nlocal[Y]*lb->kp.nlocal[Z];
+  KCHECK(lbmi_k_records(&lb->kp, lb->opts.ndist, lb->f, lb->fprime, 1, lb->stream));
+  plane = sizeof(double)*(size_t) lb->kp.nvel*lb->opts.ndist*lb->kp.nlocal[Y]*lb->kp.nlocal[Z];
   nbytes = plane*(size_t) lb->kp.nlocal[X];
   return lbmi_io_transfer(lb, fn, 1, lb->fprime, nbytes,
 			  (off_t) (plane*(size_t) offset_x));
@@ -2477,7 +2475,7 @@ int lbmi_lb_io_read(lbmi_t * lb, const char * dir, int timestep,
   HIPCHECK(hipSetDevice(lb->device));
   ifail = lbmi_io_filename(dir, "dist", timestep, fn, sizeof(fn));
   if (ifail) return ifail;
-  plane = sizeof(double)*(size_t) lb->kp.nvel*lb->kp.nlocal[Y]*lb->kp.nlocal[Z];
+  plane = sizeof(double)*(size_t) lb->kp.nvel*lb->opts.ndist*lb->kp.nlocal[Y]*lb->kp.nlocal[Z];
   nbytes = plane*(size_t) lb->kp.nlocal[X];
   ifail = lbmi_io_transfer(lb, fn, 0, lb->fprime, nbytes,
 			   (off_t) (plane*(size_t) offset_x));

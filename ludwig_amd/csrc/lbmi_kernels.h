@@ -116,9 +116,10 @@ int lbmi_k_halo_unpack_x(const lbmi_kparam_t * kp, const lbmi_halo_sel_t * sel,
 			 void * stream);
 
 /* Record stream of the distribution files: pack != 0: f -> rec, else
- * rec -> f (interior sites only). rec: ninterior*nvel doubles (device). */
-int lbmi_k_records(const lbmi_kparam_t * kp, double * f, double * rec,
-		   int pack, void * stream);
+ * rec -> f (interior sites only). rec: ninterior*ndist*nvel doubles (device),
+ * the record of a site is [n][p]. */
+int lbmi_k_records(const lbmi_kparam_t * kp, int ndist, double * f,
+		   double * rec, int pack, void * stream);
 
 /* hydro_field_set: all nsite sites of ncomp (1..3) components := v[] */
 int lbmi_k_field_set(const lbmi_kparam_t * kp, int ncomp, double * field,

@@ -1188,7 +1188,7 @@ void k_halo_unpack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
  * coalesced (population-major reads of 512 B per wave, contiguous record
  * writes), 2*nvel*8 bytes per site of HBM traffic. */
 
-enum {RB = 256};
+enum {RB1 = 256, RB2 = 128};
 
 __device__ __forceinline__
 size_t interior_site(const lbmi_kparam_t & kp, long long ib) {
@@ -1202,7 +1202,10 @@ size_t interior_site(const lbmi_kparam_t & kp, long long ib) {
     + (size_t) (z + kp.nhalo);
 }
 
-template <int NVEL, bool PACK>
+/* NVEL here = values per site = ndist*nvel (19, 27, 38, 54): the record of a
+ * site is [n][p], which is the component order of f. RB sites per block
+ * (128 for the two-distribution records: the tile stays below 64 KB). */
+template <int NVEL, bool PACK, int RB>
 __global__ __launch_bounds__(RB)
 void k_records(lbmi_kparam_t kp, double * __restrict__ f,
 	       double * __restrict__ rec, long long ninterior) {
@@ -2616,23 +2619,27 @@ extern "C" int lbmi_k_halo_unpack_x(const lbmi_kparam_t * kp,
   return (int) hipGetLastError();
 }
 
-extern "C" int lbmi_k_records(const lbmi_kparam_t * kp, double * f,
+template <int NCOMP, int RBT>
+static int launch_records(const lbmi_kparam_t & kp, double * f, double * rec,
+			  int pack, hipStream_t st) {
+  long long nint = (long long) kp.nlocal[0]*kp.nlocal[1]*kp.nlocal[2];
+  dim3 grid((unsigned) ((nint + RBT - 1)/RBT)), block(RBT);
+  if (pack) hipLaunchKernelGGL((k_records<NCOMP, true, RBT>), grid, block, 0, st, kp, f, rec, nint);
+  else hipLaunchKernelGGL((k_records<NCOMP, false, RBT>), grid, block, 0, st, kp, f, rec, nint);
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_records(const lbmi_kparam_t * kp, int ndist, double * f,
 			      double * rec, int pack, void * stream) {
   hipStream_t st = (hipStream_t) stream;
-  long long nint = (long long) kp->nlocal[0]*kp->nlocal[1]*kp->nlocal[2];
-  dim3 grid((unsigned) ((nint + RB - 1)/RB)), block(RB);
-  if (kp->nvel == 19) {
-    if (pack) hipLaunchKernelGGL((k_records<19, true>), grid, block, 0, st, *kp, f, rec, nint);
-    else hipLaunchKernelGGL((k_records<19, false>), grid, block, 0, st, *kp, f, rec, nint);
+  switch (kp->nvel*ndist) {
+  case 19: return launch_records<19, RB1>(*kp, f, rec, pack, st);
+  case 27: return launch_records<27, RB1>(*kp, f, rec, pack, st);
+  case 38: return launch_records<38, RB2>(*kp, f, rec, pack, st);
+  case 54: return launch_records<54, RB2>(*kp, f, rec, pack, st);
+  default: break;
   }
-  else if (kp->nvel == 27) {
-    if (pack) hipLaunchKernelGGL((k_records<27, true>), grid, block, 0, st, *kp, f, rec, nint);
-    else hipLaunchKernelGGL((k_records<27, false>), grid, block, 0, st, *kp, f, rec, nint);
-  }
-  else {
-    return (int) hipErrorInvalidValue;
-  }
-  return (int) hipGetLastError();
+  return (int) hipErrorInvalidValue;
 }
 
 extern "C" int lbmi_k_field_set(const lbmi_kparam_t * kp, int ncomp,

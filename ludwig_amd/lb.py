@@ -337,9 +337,9 @@ class LB:
 
     def lb_io_aggr_pack(self):
         """lb_io_aggr_pack (model.c:1479): the binary record stream as a
-        host array (nx, ny, nz, nvel)."""
+        host array (nx, ny, nz, ndist*nvel); the record of a site is [n][p]."""
         torch = _torch()
-        rec = torch.empty(self.nlocal + (self.nvel,), dtype=torch.float64,
+        rec = torch.empty(self.nlocal + (self.ndist * self.nvel,), dtype=torch.float64,
                           device=self.device)
         torch.cuda.synchronize(self.device)
         _l.check(self._lib.lbmi_lb_records_pack(self._h, _ptr(rec)))
@@ -351,7 +351,7 @@ class LB:
         a record stream."""
         torch = _torch()
         rec = torch.from_numpy(np.ascontiguousarray(records, dtype=np.float64))
-        assert tuple(rec.shape) == self.nlocal + (self.nvel,)
+        assert tuple(rec.shape) == self.nlocal + (self.ndist * self.nvel,)
         rec = rec.to(self.device)
         torch.cuda.synchronize(self.device)
         _l.check(self._lib.lbmi_lb_records_unpack(self._h, _ptr(rec)))

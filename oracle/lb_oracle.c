@@ -1222,7 +1222,9 @@ int lbo_init_synthetic(const lbo_param_t * p, const int ntotal[3],
  * lb_write_buf (model.c:1385-1402, 1479-1510) -- one record of nvel doubles
  * in p order per INTERIOR site, sites in (ic, jc, kc) order, independent of
  * the memory order -- and its inverse lb_io_aggr_unpack / lb_read_buf
- * (model.c:1412-1430, 1520-1550). ndist = 1.
+ * (model.c:1412-1430, 1520-1550). With ndist distributions the record is [n][p],
+ * i.e. the component order of f: call with p->nvel = ndist*nvel (only the count
+ * is used here).
  */
 
 int lbo_records_pack(const lbo_param_t * p, const double * f, double * rec) {

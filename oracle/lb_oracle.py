@@ -351,17 +351,30 @@ def moments(p, f, status=None):
     return out
 
 
-def records_pack(p, f):
-    """lb_io_aggr_pack (binary): (nx, ny, nz, nvel) record stream."""
-    rec = np.zeros(tuple(p.nlocal) + (p.nvel,))
-    rc = lib().lbo_records_pack(ctypes.byref(p), _ptr(f), _ptr(rec))
+def _records_param(p, ndist):
+    """The record of a site is [n][p] = the component order of f: ndist
+    distributions are records of ndist*nvel values (lb_write_buf)."""
+    if ndist == 1:
+        return p
+    q = type(p)()
+    ctypes.memmove(ctypes.byref(q), ctypes.byref(p), ctypes.sizeof(p))
+    q.nvel = p.nvel * ndist
+    return q
+
+
+def records_pack(p, f, ndist=1):
+    """lb_io_aggr_pack (binary): (nx, ny, nz, ndist*nvel) record stream."""
+    q = _records_param(p, ndist)
+    rec = np.zeros(tuple(p.nlocal) + (q.nvel,))
+    rc = lib().lbo_records_pack(ctypes.byref(q), _ptr(f), _ptr(rec))
     assert rc == 0
     return rec
 
 
-def records_unpack(p, f, rec):
+def records_unpack(p, f, rec, ndist=1):
+    q = _records_param(p, ndist)
     rec = np.ascontiguousarray(rec, dtype=np.float64)
-    rc = lib().lbo_records_unpack(ctypes.byref(p), _ptr(f), _ptr(rec))
+    rc = lib().lbo_records_unpack(ctypes.byref(q), _ptr(f), _ptr(rec))
     assert rc == 0
 
 

@@ -251,17 +251,20 @@ def run_wall_case(case, tmp):
 IO_CASES = [
     ("io_q19", 19, (6, 5, 4), 7),
     ("io_q27", 27, (5, 4, 6), 123456),
+    ("io_q19_2dist", 19, (4, 6, 5), 40, 2),         # ndist = 2: records of 38 doubles
 ]
 
 
 def run_io_case(case, tmp):
     """lb_io_write of the reference (MPI-IO mode, one file): the metadata
     file (text), the data file (bytes) and the f they were written from."""
-    name, nvel, n, timestep = case
+    name, nvel, n, timestep = case[:4]
+    ndist = case[4] if len(case) > 4 else 1
     exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
     d = os.path.join(tmp, name)
     os.makedirs(d)
-    subprocess.run([exe, "io", d, *map(str, n), str(timestep)], check=True,
+    subprocess.run([exe, "io", d, *map(str, n), str(timestep)]
+                   + ([str(ndist)] if ndist != 1 else []), check=True,
                    stdout=subprocess.DEVNULL)
     datafile = "dist-%9.9d.001-001" % timestep
     nall = tuple(m + 2 for m in n)
@@ -269,7 +272,7 @@ def run_io_case(case, tmp):
             "datafile": np.array(datafile),
             "data": np.fromfile(os.path.join(d, datafile), dtype=np.uint8),
             "f0": np.fromfile(os.path.join(d, "written.f0.f64"),
-                              dtype="<f8").reshape((nvel,) + nall),
+                              dtype="<f8").reshape((ndist * nvel,) + nall),
             "timestep": np.array(timestep)}
 
 

@@ -774,20 +774,33 @@ static int run_io(int argc, char ** argv) {
     lb_data_options_t opts = lb_data_options_default();
     opts.ndim = NDIM;
     opts.nvel = NVEL;
-    opts.ndist = 1;
+    opts.ndist = (argc == 8) ? atoi(argv[7]) : 1;
     opts.iodata.input = io_options_with_mode(IO_MODE_MPIIO);
     opts.iodata.output = io_options_with_mode(IO_MODE_MPIIO);
     lb_data_create(pe, cs, &opts, &lb);
   }
   {
     io_event_t event = {0};
-    size_t nf = (size_t) lb->nsite*lb->model.nvel;
+    size_t nf = (size_t) lb->nsite*lb->model.nvel*lb->ndist;
     if (reading) {
       lb_io_read(lb, timestep, &event);
       dump("readback", "f", lb->f, nf);
     }
     else {
       init_f(cs, lb, &c);
+      if (lb->ndist == 2) {
+	/* something to tell the second distribution from the first */
+	for (int ic = 1; ic <= c.ntotal[X]; ic++) {
+	  for (int jc = 1; jc <= c.ntotal[Y]; jc++) {
+	    for (int kc = 1; kc <= c.ntotal[Z]; kc++) {
+	      int index = cs_index(cs, ic, jc, kc);
+	      for (int p = 0; p < lb->model.nvel; p++) {
+		lb_f_set(lb, index, p, LB_PHI, 0.1*(lcg_uniform() - 0.5));
+	      }
+	    }
+	  }
+	}
+      }
       dump("written", "f0", lb->f, nf);
       lb_io_write(lb, timestep, &event);
     }
@@ -824,8 +837,8 @@ int main(int argc, char ** argv) {
 		     strcmp(argv[1], "relax") == 0)) {
     return run_binary(argc, argv);
   }
-  if (argc == 7 && (strcmp(argv[1], "io") == 0 ||
-		    strcmp(argv[1], "ioread") == 0)) {
+  if ((argc == 7 || argc == 8) && (strcmp(argv[1], "io") == 0 ||
+				   strcmp(argv[1], "ioread") == 0)) {
     return run_io(argc, argv);
   }
 

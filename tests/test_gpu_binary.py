@@ -151,8 +151,6 @@ def test_binary_rejections():
     hy = ludwig_amd.Hydro(lb.nall, lb.device)
     with pytest.raises(ludwig_amd.LbmiError):
         lb.lb_collide(hy)                      # the single-fluid entry point
-    with pytest.raises(ludwig_amd.LbmiError):
-        lb.lb_io_aggr_pack()
     lb.free()
     lb = ludwig_amd.LB(19, (4, 4, 4), 1)
     with pytest.raises(ludwig_amd.LbmiError):

@@ -15,18 +15,22 @@ from tests.common import interior, load_io_golden
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.path.join(HERE, "..", "oracle", "_ref")
-CASES = [("io_q19", 19), ("io_q27", 27)]
+CASES = [("io_q19", 19), ("io_q27", 27), ("io_q19_2dist", 19)]
 
 
 def _nlocal(g):
     return tuple(n - 2 for n in g["f0"].shape[1:])
 
 
+def _ndist(g, nvel):
+    return g["f0"].shape[0] // nvel
+
+
 @pytest.mark.parametrize("name,nvel", CASES)
 def test_metadata_file_identical_to_reference(name, nvel, tmp_path):
     import ludwig_amd
     g = load_io_golden(name)
-    ludwig_amd.io_metadata_write(tmp_path, "dist", nvel, _nlocal(g))
+    ludwig_amd.io_metadata_write(tmp_path, "dist", nvel * _ndist(g, nvel), _nlocal(g))
     text = open(tmp_path / "dist-metadata.001-001").read()
     assert text == g["metadata"]                  # byte for byte
 
@@ -43,10 +47,11 @@ def test_data_file_name(name, nvel, tmp_path):
 def test_oracle_record_stream_is_the_reference_file(name, nvel):
     g = load_io_golden(name)
     p = lbo.make_param(nvel, _nlocal(g), 1)
-    rec = lbo.records_pack(p, np.ascontiguousarray(g["f0"]))
+    nd = _ndist(g, nvel)
+    rec = lbo.records_pack(p, np.ascontiguousarray(g["f0"]), nd)
     assert rec.tobytes() == g["data"]
     f = np.zeros_like(g["f0"])
-    lbo.records_unpack(p, f, np.frombuffer(g["data"], dtype="<f8").copy())
+    lbo.records_unpack(p, f, np.frombuffer(g["data"], dtype="<f8").copy(), nd)
     assert np.array_equal(interior(f, 1), interior(g["f0"], 1))
 
 
@@ -62,12 +67,14 @@ def test_reference_reads_our_files(name, nvel, tmp_path):
     n = _nlocal(g)
     p = lbo.make_param(nvel, n, 1)
     rng = np.random.default_rng(3)
+    nd = _ndist(g, nvel)
     f = np.zeros_like(g["f0"])
-    interior(f, 1)[...] = rng.random((nvel,) + n)
-    ludwig_amd.io_metadata_write(tmp_path, "dist", nvel, n)
+    interior(f, 1)[...] = rng.random((nd * nvel,) + n)
+    ludwig_amd.io_metadata_write(tmp_path, "dist", nd * nvel, n)
     with open(ludwig_amd.io_filename(tmp_path, "dist", 42), "wb") as fp:
-        fp.write(lbo.records_pack(p, f).tobytes())
-    subprocess.run([exe, "ioread", str(tmp_path), *map(str, n), "42"], check=True,
+        fp.write(lbo.records_pack(p, f, nd).tobytes())
+    subprocess.run([exe, "ioread", str(tmp_path), *map(str, n), "42"]
+                   + ([str(nd)] if nd != 1 else []), check=True,
                    stdout=subprocess.DEVNULL)
     back = np.fromfile(tmp_path / "readback.f.f64", dtype="<f8").reshape(f.shape)
     assert np.array_equal(interior(back, 1), interior(f, 1))
