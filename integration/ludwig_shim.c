@@ -11,6 +11,8 @@
  *      lb_halo_swap()    lb_data.h:160     (replaces model.c:565-595)
  *      lb_propagation()  propagation.h:21  (replaces propagation.c:43-98)
  *      lb_memcpy()       lb_data.h:156     (wraps  model.c:228-266)
+ *      lb_io_write(), lb_io_read()  lb_data.h  (replace model.c:1568-1649 in
+ *                        MPI-IO mode, one file, binary records)
  *      wall_bbl()        wall.h:99         (replaces wall.c:960-989, slip included)
  *      phi_lb_to_field() phi_lb_coupler.h  (replaces phi_lb_coupler.c:39-64)
  *      hydro_u_zero(), hydro_f_zero()  hydro.h:64-65 (hydro.c:279-330)
@@ -24,7 +26,8 @@
  *
  *      -Dlb_collide=lb_collide_ref -Dlb_halo=lb_halo_ref
  *      -Dlb_halo_swap=lb_halo_swap_ref -Dlb_propagation=lb_propagation_ref
- *      -Dlb_memcpy=lb_memcpy_ref
+ *      -Dlb_memcpy=lb_memcpy_ref -Dlb_io_write=lb_io_write_ref
+ *      -Dlb_io_read=lb_io_read_ref
  *
  *  (and wall.c with -Dwall_bbl=wall_bbl_ref, phi_lb_coupler.c with
  *  -Dphi_lb_to_field=phi_lb_to_field_ref, hydro.c with -Dhydro_u_zero=
@@ -75,6 +78,8 @@ int lb_collide_ref(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
 int lb_halo_swap_ref(lb_t * lb, lb_halo_enum_t flag);
 int lb_propagation_ref(lb_t * lb);
 int lb_memcpy_ref(lb_t * lb, tdpMemcpyKind flag);
+int lb_io_write_ref(lb_t * lb, int timestep, io_event_t * event);
+int lb_io_read_ref(lb_t * lb, int timestep, io_event_t * event);
 int wall_bbl_ref(wall_t * wall);
 int phi_lb_to_field_ref(field_t * phi, lb_t * lb);
 int hydro_u_zero_ref(hydro_t * hydro, const double uzero[3]);
@@ -465,6 +470,83 @@ int lb_memcpy(lb_t * lb, tdpMemcpyKind flag) {
   return lb_memcpy_ref(lb, flag);
 }
 
+
+/*****************************************************************************
+ *
+ *  lb_io_write, lb_io_read  (model.c:1568-1649), row f3
+ *
+ *  The reference copies all of f to the host, packs the records there and
+ *  writes through MPI-IO. In its MPI-IO mode with one file (i/o grid 1_1_1)
+ *  and binary records, an X slab is one contiguous byte range of that file:
+ *  the records are packed on the device and written from there, the files
+ *  are the same byte for byte. Anything else (old-style i/o, several files,
+ *  ASCII records) goes to the original.
+ *
+ *****************************************************************************/
+
+static int shim_io_supported(lb_t * lb, const io_metadata_t * meta) {
+  if (!shim_supported(lb)) return 0;
+  if (meta->options.mode != IO_MODE_MPIIO) return 0;
+  if (meta->options.iorformat != IO_RECORD_BINARY) return 0;
+  if (meta->options.iogrid[X] != 1 || meta->options.iogrid[Y] != 1 ||
+      meta->options.iogrid[Z] != 1) return 0;
+  return 1;
+}
+
+int lb_io_write(lb_t * lb, int timestep, io_event_t * event) {
+
+  assert(lb);
+  assert(event);
+
+  if (!shim_io_supported(lb, &lb->output)) {
+    return lb_io_write_ref(lb, timestep, event);   /* via lb_memcpy: flushes */
+  }
+
+  {
+    int ntotal[3], noffset[3];
+    cs_ntotal(lb->cs, ntotal);
+    cs_nlocal_offset(lb->cs, noffset);
+    io_event_record(event, IO_EVENT_AGGR);
+    io_event_record(event, IO_EVENT_WRITE);
+    /* the metadata file (rank at offset 0) and this rank's byte range */
+    SHIM_CHECK(lb, lbmi_lb_io_write(shim_handle(lb), ".", timestep, ntotal[X],
+				    noffset[X]));
+    shim_sync_pointers(lb, shim_.h);                /* a flush may have swapped */
+    lb->output.iswriten = 1;
+    io_event_report(event, &lb->output, "dist");
+  }
+
+  return 0;
+}
+
+int lb_io_read(lb_t * lb, int timestep, io_event_t * event) {
+
+  assert(lb);
+  assert(event);
+
+  if (!shim_io_supported(lb, &lb->input)) {
+    if (shim_.h && shim_.lb == lb) {
+      /* the original fills the HOST copy; nothing deferred may survive it */
+      SHIM_CHECK(lb, lbmi_lb_flush(shim_.h));
+      shim_sync_pointers(lb, shim_.h);
+    }
+    return lb_io_read_ref(lb, timestep, event);
+  }
+
+  {
+    int ntotal[3], noffset[3];
+    cs_ntotal(lb->cs, ntotal);
+    cs_nlocal_offset(lb->cs, noffset);
+    SHIM_CHECK(lb, lbmi_lb_io_read(shim_handle(lb), ".", timestep, ntotal[X],
+				   noffset[X]));
+    shim_sync_pointers(lb, shim_.h);
+    /* ludwig.c:333-340 goes on with the host copy (it is copied to the
+     * device again there): keep it in step */
+    lb_memcpy_ref(lb, tdpMemcpyDeviceToHost);
+  }
+
+  return 0;
+}
 
 /*****************************************************************************
  *
