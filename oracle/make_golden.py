@@ -55,17 +55,20 @@ VISC_CASES = [
 ]
 
 
-def run_case(case, tmp, visc=0):
+def run_case(case, tmp, visc=0, exe=None, env=None):
+    """exe, env: another build of the same driver (tests/test_gpu_shim.py runs
+    the reference's HIP target, with and without the binding, this way)."""
     (name, nvel, n, nhalo, scheme, eta, zeta, fb, ff, solid, nsteps,
      keep_halo) = case
-    exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
+    if exe is None:
+        exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
     prefix = os.path.join(tmp, name)
     args = [exe, "dump", prefix, *map(str, n), str(nhalo), scheme,
             repr(eta), repr(zeta), *[repr(float(x)) for x in fb],
             str(ff), str(solid), str(nsteps)]
     if visc:
         args.append("1")
-    subprocess.run(args, check=True)
+    subprocess.run(args, check=True, env=env)
     meta = json.load(open(prefix + ".json"))
     meta["name"] = name
     meta["scheme_name"] = scheme
