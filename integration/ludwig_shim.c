@@ -130,25 +130,51 @@ static void shim_device_f(lb_t * lb, double ** f, double ** fprime) {
 		      tdpMemcpyDeviceToHost));
 }
 
-static double * shim_field_data(field_t * field) {
-  double * data = NULL;
-  tdpAssert(tdpMemcpy(&data, &field->target->data, sizeof(double *),
-		      tdpMemcpyDeviceToHost));
+/* Device data pointers are fixed once an object exists, and every fetch is a
+ * blocking copy that drains the stream: remember them (objects of these
+ * types live as long as the run). */
+
+#define SHIM_NCACHE 32
+static struct { const void * obj; void * data; } shim_cache_[SHIM_NCACHE];
+static int shim_ncache_ = 0;
+
+static void * shim_cached(const void * obj, const void * device_member,
+			  size_t sz) {
+  void * data = NULL;
+  for (int n = 0; n < shim_ncache_; n++) {
+    if (shim_cache_[n].obj == obj) return shim_cache_[n].data;
+  }
+  tdpAssert(tdpMemcpy(&data, device_member, sz, tdpMemcpyDeviceToHost));
+  if (shim_ncache_ < SHIM_NCACHE) {
+    shim_cache_[shim_ncache_].obj = obj;
+    shim_cache_[shim_ncache_].data = data;
+    shim_ncache_ += 1;
+  }
   return data;
+}
+
+static double * shim_field_data(field_t * field) {
+  return (double *) shim_cached(field, &field->target->data, sizeof(double *));
 }
 
 /* After any call that swaps f and fprime, make lb->target->f/fprime point
  * at the current arrays, so that foreign kernels (wall.c:930-950,
  * bbl.c:294-360, stats_distribution.c:322) keep working. */
 
+static double * last_f = NULL;         /* what lb->target holds now */
+static double * last_fprime = NULL;
+
 static void shim_sync_pointers(lb_t * lb, lbmi_t * h) {
   double * f = NULL;
   double * fprime = NULL;
   SHIM_CHECK(lb, lbmi_lb_pointers(h, &f, &fprime));
+  if (f == last_f && fprime == last_fprime) return;    /* nothing swapped */
   tdpAssert(tdpMemcpy(&lb->target->f, &f, sizeof(double *),
 		      tdpMemcpyHostToDevice));
   tdpAssert(tdpMemcpy(&lb->target->fprime, &fprime, sizeof(double *),
 		      tdpMemcpyHostToDevice));
+  last_f = f;
+  last_fprime = fprime;
 }
 
 static lbmi_t * shim_handle(lb_t * lb) {
@@ -193,6 +219,8 @@ static lbmi_t * shim_handle(lb_t * lb) {
 
     shim_device_f(lb, &f, &fprime);
     SHIM_CHECK(lb, lbmi_lb_bind(shim_.h, f, fprime));
+    last_f = f;
+    last_fprime = fprime;
 
     if (cartsz[X] > 1) {
       /* ncclUniqueId from rank 0 of the Cartesian communicator */
@@ -269,8 +297,7 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
     SHIM_CHECK(lb, lbmi_set_relaxation(h, scheme, rho0, eta, zeta));
     SHIM_CHECK(lb, lbmi_set_body_force(h, fbody));
 
-    tdpAssert(tdpMemcpy(&status, &map->target->status, sizeof(char *),
-			tdpMemcpyDeviceToHost));
+    status = (char *) shim_cached(map, &map->target->status, sizeof(char *));
     hy.force  = shim_field_data(hydro->force);
     hy.status = status;
     hy.rho    = shim_field_data(hydro->rho);
