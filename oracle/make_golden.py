@@ -211,7 +211,7 @@ SLIP_CASES = [
 ]
 
 
-def run_wall_case(case, tmp):
+def run_wall_case(case, tmp, exe=None, env=None):
     """Flat walls with bounce-back on links: status map, links and f after
     the first wall_bbl and after nsteps of collide, halo, wall_bbl,
     propagation; meta["fnet"] = the accumulated wall momentum."""
@@ -223,11 +223,12 @@ def run_wall_case(case, tmp):
         slip = [repr(float(v)) for v in (*sbot, *stop)]
     else:
         name, nvel, n, bnd, ubot, utop, solid, nsteps = case
-    exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
+    if exe is None:
+        exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
     prefix = os.path.join(tmp, name)
     subprocess.run([exe, "wall", prefix, *map(str, n), *map(str, bnd),
                     repr(ubot), repr(utop), str(solid), str(nsteps), *slip],
-                   check=True)
+                   check=True, env=env)
     meta = json.load(open(prefix + ".json"))
     meta["name"] = name
     meta["scheme_name"] = "m10"
@@ -258,17 +259,18 @@ IO_CASES = [
 ]
 
 
-def run_io_case(case, tmp):
+def run_io_case(case, tmp, exe=None, env=None):
     """lb_io_write of the reference (MPI-IO mode, one file): the metadata
     file (text), the data file (bytes) and the f they were written from."""
     name, nvel, n, timestep = case[:4]
     ndist = case[4] if len(case) > 4 else 1
-    exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
+    if exe is None:
+        exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
     d = os.path.join(tmp, name)
     os.makedirs(d)
     subprocess.run([exe, "io", d, *map(str, n), str(timestep)]
                    + ([str(ndist)] if ndist != 1 else []), check=True,
-                   stdout=subprocess.DEVNULL)
+                   stdout=subprocess.DEVNULL, env=env)
     datafile = "dist-%9.9d.001-001" % timestep
     nall = tuple(m + 2 for m in n)
     return {"metadata": np.array(open(os.path.join(d, "dist-metadata.001-001")).read()),

@@ -684,13 +684,22 @@ static int run_wall(int argc, char ** argv) {
     }
     dump(prefix, "f0", lb->f, nf);
 
+    /* device builds (no-ops on the CPU): the state goes over, dumps come back */
+    lb_memcpy(lb, tdpMemcpyHostToDevice);
+    hydro_memcpy(hydro, tdpMemcpyHostToDevice);
+    map_memcpy(map, tdpMemcpyHostToDevice);
+
     for (int n = 0; n < nsteps; n++) {
       lb_collide(lb, hydro, map, noise, NULL, NULL);
       lb_halo(lb);
       wall_bbl(wall);
-      if (n == 0) dump(prefix, "f_bbl", lb->f, nf);
+      if (n == 0) {
+	lb_memcpy(lb, tdpMemcpyDeviceToHost);
+	dump(prefix, "f_bbl", lb->f, nf);
+      }
       lb_propagation(lb);
     }
+    lb_memcpy(lb, tdpMemcpyDeviceToHost);
     dump(prefix, "f_final", lb->f, nf);
     wall_momentum(wall, fnet);
 
@@ -784,6 +793,8 @@ static int run_io(int argc, char ** argv) {
     size_t nf = (size_t) lb->nsite*lb->model.nvel*lb->ndist;
     if (reading) {
       lb_io_read(lb, timestep, &event);
+      /* (ludwig.c:333-340 copies the host array to the device afterwards;
+       * here the host array is what is dumped) */
       dump("readback", "f", lb->f, nf);
     }
     else {
@@ -802,6 +813,7 @@ static int run_io(int argc, char ** argv) {
 	}
       }
       dump("written", "f0", lb->f, nf);
+      lb_memcpy(lb, tdpMemcpyHostToDevice);       /* device builds */
       lb_io_write(lb, timestep, &event);
     }
   }

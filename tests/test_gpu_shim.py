@@ -85,3 +85,54 @@ def test_shim_with_viscosity_model(case):
     with tempfile.TemporaryDirectory() as tmp:
         out = mg.run_case(case, tmp, visc=1, exe=exe, env=env)
     _compare(out, load_golden(case[0]), case[3])
+
+
+WALLS = mg.WALL_CASES + mg.SLIP_CASES
+
+
+@pytest.mark.parametrize("mode", ["eager", "halo"])
+@pytest.mark.parametrize("case", WALLS, ids=[c[0] for c in WALLS])
+def test_shim_wall_bbl(case, mode):
+    """wall_bbl of the binding -- no-slip with moving walls, partial slip, the
+    MAP_COLLOID branch -- on the reference's own device link arrays, between
+    the binding's lb_halo and lb_propagation."""
+    nvel = case[1]
+    exe = _exe(nvel, shim=True)
+    env = dict(os.environ, LBMI_MODE=mode)
+    with tempfile.TemporaryDirectory() as tmp:
+        out = mg.run_wall_case(case, tmp, exe=exe, env=env)
+    g = load_golden(case[0])
+    for key in ("status", "linki", "linkj", "linkp", "linku"):
+        assert np.array_equal(out[key], g[key])
+    q = nvel - g["linkp"]
+    a = out["f_bbl"].reshape(nvel, -1)[q, g["linkj"]]
+    b = g["f_bbl"].reshape(nvel, -1)[q, g["linkj"]]
+    assert np.max(np.abs(a - b)) < 1e-15
+    fl = (g["status"] == 0)[1:-1, 1:-1, 1:-1]
+    assert relmax(interior(out["f_final"], 1)[:, fl], interior(g["f_final"], 1)[:, fl]) < 1e-12
+    import json
+    fnet = np.array(json.loads(str(out["meta"]))["fnet"])
+    ref = np.array(g["meta"]["fnet"])
+    assert np.max(np.abs(fnet - ref)) < 1e-12 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("case", mg.IO_CASES, ids=[c[0] for c in mg.IO_CASES])
+def test_shim_lb_io_write_and_read(case, tmp_path):
+    """lb_io_write of the binding (records packed on the device, written from
+    there) = the files of the reference byte for byte; lb_io_read of the
+    binding restores the host copy the caller goes on with."""
+    import subprocess
+    nvel, n, timestep = case[1], case[2], case[3]
+    ndist = case[4] if len(case) > 4 else 1
+    exe = _exe(nvel, shim=True)
+    env = dict(os.environ, LBMI_MODE="fused")
+    out = mg.run_io_case(case, str(tmp_path), exe=exe, env=env)
+    g = np.load(os.path.join(HERE, "golden", case[0] + ".npz"))
+    assert str(out["metadata"]) == str(g["metadata"])
+    assert out["data"].tobytes() == g["data"].tobytes()
+    d = os.path.join(str(tmp_path), case[0])
+    subprocess.run([exe, "ioread", d, *map(str, n), str(timestep)]
+                   + ([str(ndist)] if ndist != 1 else []), check=True, env=env,
+                   stdout=subprocess.DEVNULL)
+    back = np.fromfile(os.path.join(d, "readback.f.f64"), dtype="<f8").reshape(g["f0"].shape)
+    assert np.array_equal(interior(back, 1), interior(g["f0"], 1))
