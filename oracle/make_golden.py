@@ -144,15 +144,16 @@ RELAX_CASES = [
 ]
 
 
-def run_relax_case(case, tmp):
+def run_relax_case(case, tmp, exe=None, env=None):
     """lb_collide with fe->use_stress_relaxation = 1 (collision.c:413-429):
     the symmetric stress of a fixed phi in the equilibrium stress."""
     name, nvel, n, a, b, kappa, mob, eta, zeta, fx, nsteps = case
-    exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
+    if exe is None:
+        exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
     prefix = os.path.join(tmp, name)
     subprocess.run([exe, "relax", prefix, *map(str, n), repr(a), repr(b),
                     repr(kappa), repr(mob), repr(eta), repr(zeta), repr(fx),
-                    str(nsteps)], check=True)
+                    str(nsteps)], check=True, env=env)
     meta = json.load(open(prefix + ".json"))
     meta["name"] = name
     nall = tuple(meta["nall"])
@@ -167,17 +168,18 @@ def run_relax_case(case, tmp):
             "f_final": load("f_final", (nvel,))}
 
 
-def run_binary_case(case, tmp):
+def run_binary_case(case, tmp, exe=None, env=None):
     """The two-distribution (symmetric_lb) step: lb_collision_binary with
     27-point gradients, lb_halo and lb_propagation of both distributions.
     Arrays (2*nvel, nall) are n-major: [0:nvel] density, [nvel:] order
     parameter."""
     name, nvel, n, a, b, kappa, mob, eta, zeta, fx, nsteps = case
-    exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
+    if exe is None:
+        exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
     prefix = os.path.join(tmp, name)
     subprocess.run([exe, "binary", prefix, *map(str, n), repr(a), repr(b),
                     repr(kappa), repr(mob), repr(eta), repr(zeta), repr(fx),
-                    str(nsteps)], check=True)
+                    str(nsteps)], check=True, env=env)
     meta = json.load(open(prefix + ".json"))
     meta["name"] = name
     nall = tuple(meta["nall"])

@@ -482,6 +482,11 @@ static int run_binary(int argc, char ** argv) {
     FILE * fp = NULL;
 
     dump(prefix, "f0", lb->f, nf);
+    /* device builds (no-ops on the CPU): the state goes over, dumps come back */
+    lb_memcpy(lb, tdpMemcpyHostToDevice);
+    field_memcpy(phi, tdpMemcpyHostToDevice);
+    hydro_memcpy(hydro, tdpMemcpyHostToDevice);
+    map_memcpy(map, tdpMemcpyHostToDevice);
     for (int n = 0; n < nsteps; n++) {
       if (!relax) phi_lb_to_field(phi, lb);
       field_halo(phi);
@@ -489,6 +494,10 @@ static int run_binary(int argc, char ** argv) {
       hydro_u_zero(hydro, fzero);
       lb_collide(lb, hydro, map, noise, (fe_t *) fe, NULL);
       if (n == 0) {
+	lb_memcpy(lb, tdpMemcpyDeviceToHost);
+	field_memcpy(phi, tdpMemcpyDeviceToHost);
+	field_grad_memcpy(dphi, tdpMemcpyDeviceToHost);
+	hydro_memcpy(hydro, tdpMemcpyDeviceToHost);
 	dump(prefix, "phi", phi->data, ns);
 	dump(prefix, "grad", dphi->grad, 3*ns);
 	dump(prefix, "delsq", dphi->delsq, ns);
@@ -499,6 +508,7 @@ static int run_binary(int argc, char ** argv) {
       lb_halo(lb);
       lb_propagation(lb);
     }
+    lb_memcpy(lb, tdpMemcpyDeviceToHost);
     dump(prefix, "f_final", lb->f, nf);
 
     cs_nall(cs, nall);

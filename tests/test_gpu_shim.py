@@ -136,3 +136,37 @@ def test_shim_lb_io_write_and_read(case, tmp_path):
                    stdout=subprocess.DEVNULL)
     back = np.fromfile(os.path.join(d, "readback.f.f64"), dtype="<f8").reshape(g["f0"].shape)
     assert np.array_equal(interior(back, 1), interior(g["f0"], 1))
+
+
+def _compare_fe(out, g):
+    assert np.array_equal(interior(out["phi"], 1), interior(g["phi"], 1))
+    # gradients: valid on the interior (nextra = nhalo - 1 = 0 here)
+    assert relmax(interior(out["grad"], 1), interior(g["grad"], 1)) < 1e-12
+    assert relmax(interior(out["delsq"], 1), interior(g["delsq"], 1)) < 1e-12
+    for key in ("f_collide", "u", "f_final"):
+        assert relmax(interior(out[key], 1), interior(g[key], 1)) < 1e-12, key
+
+
+@pytest.mark.parametrize("mode", ["eager", "halo"])
+@pytest.mark.parametrize("case", mg.BINARY_CASES, ids=[c[0] for c in mg.BINARY_CASES])
+def test_shim_two_distribution_step(case, mode):
+    """free_energy symmetric_lb inside the reference: phi_lb_to_field,
+    field_halo, field_grad_compute, hydro_u_zero, lb_collide (binary), lb_halo,
+    lb_propagation -- all through the binding (halo: the propagation of both
+    distributions is folded into the next collision)."""
+    exe = _exe(case[1], shim=True)
+    env = dict(os.environ, LBMI_MODE=mode)
+    with tempfile.TemporaryDirectory() as tmp:
+        out = mg.run_binary_case(case, tmp, exe=exe, env=env)
+    _compare_fe(out, load_golden(case[0]))
+
+
+@pytest.mark.parametrize("mode", ["eager", "halo", "fused"])
+@pytest.mark.parametrize("case", mg.RELAX_CASES, ids=[c[0] for c in mg.RELAX_CASES])
+def test_shim_stress_relaxation(case, mode):
+    """lb_collide with fe->use_stress_relaxation (symmetric free energy)."""
+    exe = _exe(case[1], shim=True)
+    env = dict(os.environ, LBMI_MODE=mode)
+    with tempfile.TemporaryDirectory() as tmp:
+        out = mg.run_relax_case(case, tmp, exe=exe, env=env)
+    _compare_fe(out, load_golden(case[0]))
