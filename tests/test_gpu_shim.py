@@ -170,3 +170,81 @@ def test_shim_stress_relaxation(case, mode):
     with tempfile.TemporaryDirectory() as tmp:
         out = mg.run_relax_case(case, tmp, exe=exe, env=env)
     _compare_fe(out, load_golden(case[0]))
+
+
+# --- the application itself: the reference's main.c / ludwig.c main loop --------
+
+import json as _json                                         # noqa: E402
+import re as _re                                             # noqa: E402
+import subprocess as _sp                                     # noqa: E402
+
+INPUTS = os.path.join(HERE, "golden", "inputs")
+
+
+def _ludwig(inp, mode, shim=True):
+    exe = os.path.join(REF, "ludwig_hip_d3q19" + ("_shim" if shim else ""))
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/%s not built (make -C oracle hip)" % os.path.basename(exe))
+    env = dict(os.environ, LBMI_MODE=mode)
+    import shutil
+    with tempfile.TemporaryDirectory() as tmp:
+        # main.c: the input file is "input" in the working directory
+        shutil.copy(os.path.join(INPUTS, inp), os.path.join(tmp, "input"))
+        r = _sp.run([exe], cwd=tmp, env=env, check=True,
+                    capture_output=True, text=True, timeout=600)
+    assert "Ludwig finished normally." in r.stdout
+    return r.stdout
+
+
+def _floats(line):
+    return [float(x) for x in _re.findall(r"[-+]?\d+\.\d+(?:[eE][-+]?\d+)?", line)]
+
+
+def _last(log, tag):
+    lines = [l for l in log.splitlines() if l.startswith(tag)]
+    assert lines, tag
+    return _floats(lines[-1])
+
+
+@pytest.mark.parametrize("mode", ["eager", "halo", "fused"])
+@pytest.mark.parametrize("name", ["dist_1dp", "dist_3du"])
+def test_ludwig_application_with_the_binding(name, mode):
+    """The reference's executable (main.c, ludwig.c main loop, its input
+    parser, initialisation and statistics) built for gfx950 with the binding:
+    ten steps of the regression serial-dist-1dp / -3du; the statistics it
+    prints are those of the reference's own log, digit for digit."""
+    ref = _json.load(open(os.path.join(HERE, "golden", "regression_d3q19_short.json")))
+    ref = ref["serial-dist-" + name[-3:]]["final"]
+    log = _ludwig(name + ".inp", mode)
+    rho = _last(log, "[rho]")
+    assert rho[0] == ref["rho_total"] and rho[1] == ref["rho_mean"]
+    assert abs(rho[2] - ref["rho_var"]) <= 1e-7 * abs(ref["rho_var"]) + 1e-20
+    assert abs(rho[3] - ref["rho_min"]) < 2e-11 and abs(rho[4] - ref["rho_max"]) < 2e-11
+    g = _last(log, "[total   ]")
+    for a, b in zip(g, ref["momentum"]):
+        assert abs(a - b) <= 1e-7 * abs(b) + 1e-12
+    for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
+        if key not in ref:
+            continue
+        for a, b in zip(_last(log, tag), ref[key]):
+            assert abs(a - b) <= 2e-8 * abs(b) + 1e-16
+
+
+@pytest.mark.parametrize("mode", ["eager", "halo", "fused"])
+def test_ludwig_binary_fluid_droplet_with_the_binding(mode):
+    """free_energy symmetric (finite difference, 27-point gradients, second
+    order advection): one step of the relaxing droplet serial-symm-dr1. The
+    LB step, hydro_u_zero / hydro_f_zero, field_halo and field_grad_compute
+    run through the binding, the force and the Cahn-Hilliard update are the
+    reference's own kernels."""
+    ref = _json.load(open(os.path.join(HERE, "golden", "regression_symmetric_drop.json")))
+    ref = ref["serial-symm-dr1"]["reports"]["1"]
+    log = _ludwig("symm_dr1.inp", mode)
+    rho = _last(log, "[rho]")
+    assert rho[0] == ref["rho_total"]
+    assert abs(rho[3] - ref["rho_min"]) < 2e-11 and abs(rho[4] - ref["rho_max"]) < 2e-11
+    phi = _last(log, "[phi]")
+    assert abs(phi[0] - ref["phi_total"]) < 0.02 and abs(phi[2] - ref["phi_var"]) < 2e-8
+    for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
+        for a, b in zip(_last(log, tag), ref[key]):
+            assert abs(a - b) <= 2e-8 * abs(b) + 1e-16
