@@ -149,6 +149,30 @@ def cpu_baseline(args):
             "kind": "port", "sample": sample + " (oracle/lb_oracle.c, OpenMP)"}
 
 
+def reference_gpu(args):
+    """The reference's OWN HIP back end (its TargetDP kernels, built for gfx950
+    by `make -C oracle hip` into oracle/_ref) on this GPU, same lattice, same
+    three calls per step: a reported comparator like cpu_baseline, measured
+    after the timed region in a child process. None if the binary is absent or
+    the scheme is not M10 (on a device the reference relaxes every scheme as
+    M10, tests/test_gpu_shim.py)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver_hip_d3q%d" % args.nvel)
+    if not os.path.exists(exe) or args.scheme != "m10" or args.fe != "none":
+        return None
+    try:
+        out = subprocess.run([exe, "time", *map(str, args.size), "m10", "0.1",
+                              "0.3", "10"], check=True, capture_output=True,
+                             text=True, timeout=300).stdout
+        r = json.loads(out.strip().splitlines()[-1])
+    except Exception as e:
+        sys.stderr.write("reference_gpu: %r\n" % e)
+        return None
+    return {"value": round(r["mlups"], 1), "unit": "MLUPS",
+            "kind": "the reference's HIP target (target_hip.c + its kernels), "
+                    "this GPU, 10 steps after 1 warm-up",
+            "ms_per_step": round(1e3 * r["t_total"] / r["steps"], 4)}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -432,6 +456,7 @@ def main():
         }
         if args.cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
+            out["reference_gpu"] = reference_gpu(args)
         else:
             out["cpu_baseline"] = None
         result = json.dumps(out)
