@@ -248,3 +248,30 @@ def test_ludwig_binary_fluid_droplet_with_the_binding(mode):
     for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
         for a, b in zip(_last(log, tag), ref[key]):
             assert abs(a - b) <= 2e-8 * abs(b) + 1e-16
+
+
+@pytest.mark.parametrize("mode", ["eager", "halo"])
+@pytest.mark.parametrize("name", ["spin_lb1", "symm_dr2"])
+def test_ludwig_application_more_regressions(name, mode):
+    """spin_lb1: free_energy symmetric_lb (two distributions, ghost modes
+    off), ten steps of a spinodal quench -- phi_lb_to_field, the binary
+    collision, halo and propagation of both distributions through the
+    binding. symm_dr2: the droplet with an Arrhenius viscosity model -- the
+    collision takes its relaxation times from hydro->eta. Statistics of the
+    reference's logs serial-spin-lb1.log / serial-symm-dr2.log."""
+    ref = _json.load(open(os.path.join(HERE, "golden", "regression_app_extra.json")))[name]
+    log = _ludwig(name + ".inp", mode)
+    rho = _last(log, "[rho]")
+    assert rho[0] == ref["rho"][0]
+    # (the variance is a difference of nearly equal sums: absolute, as the
+    # reference's own comparison, tests/awk-fp-diff.sh)
+    assert abs(rho[2] - ref["rho"][2]) <= 1e-12
+    assert abs(rho[3] - ref["rho"][3]) < 2e-11 and abs(rho[4] - ref["rho"][4]) < 2e-11
+    phi = _last(log, "[phi]")
+    for a, b in zip(phi, ref["phi"]):
+        assert abs(a - b) <= 2e-7 * abs(b) + 1e-12
+    fed = _last(log, "[fed]")
+    assert abs(fed[-1] - ref["fed"]) <= 1e-9 * abs(ref["fed"])
+    for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
+        for a, b in zip(_last(log, tag), ref[key]):
+            assert abs(a - b) <= 2e-7 * abs(b) + 1e-16
