@@ -275,3 +275,24 @@ def test_ludwig_application_more_regressions(name, mode):
     for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
         for a, b in zip(_last(log, tag), ref[key]):
             assert abs(a - b) <= 2e-7 * abs(b) + 1e-16
+
+
+@pytest.mark.parametrize("mode", ["eager", "halo"])
+def test_ludwig_duct_flow_between_walls(mode):
+    """serial-rect-ct1: a 1 x 62 x 30 duct with walls in y and z, driven by a
+    body force, 100 steps: lb_collide, lb_halo, wall_bbl (on the reference's
+    link arrays, momentum into wall->target->fnet) and lb_propagation through
+    the binding; fluid and wall momentum and the velocity extrema of the
+    reference's log."""
+    ref = _json.load(open(os.path.join(HERE, "golden", "regression_app_extra.json")))["rect_ct1"]
+    log = _ludwig("rect_ct1.inp", mode)
+    rho = _last(log, "[rho]")
+    assert rho[0] == ref["rho"][0]
+    assert abs(rho[3] - ref["rho"][3]) < 2e-11 and abs(rho[4] - ref["rho"][4]) < 2e-11
+    for tag, key in (("[total   ]", "momentum_total"), ("[fluid   ]", "momentum_fluid"),
+                     ("[walls   ]", "momentum_walls")):
+        a, b = _last(log, tag)[0], ref[key][0]          # x: the driven direction
+        assert abs(a - b) <= 2e-7 * abs(b), tag
+    for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
+        for a, b in zip(_last(log, tag), ref[key]):
+            assert abs(a - b) <= 2e-7 * abs(b) + 1e-14
