@@ -296,3 +296,25 @@ def test_ludwig_duct_flow_between_walls(mode):
     for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
         for a, b in zip(_last(log, tag), ref[key]):
             assert abs(a - b) <= 2e-7 * abs(b) + 1e-14
+
+
+@pytest.mark.parametrize("mode", ["eager", "halo", "fused"])
+def test_ludwig_droplet_twenty_coupled_steps(mode):
+    """d3q19-io/iodrop-mpi1-io1: twenty coupled steps of the relaxing droplet
+    (the free-energy force and the Cahn-Hilliard update are the reference's
+    kernels; the LB step, the field halos, the gradients and the hydro
+    housekeeping go through the binding): the report after step 20."""
+    ref = _json.load(open(os.path.join(HERE, "golden", "regression_symmetric_drop.json")))
+    ref = ref["iodrop-mpi1-io1"]["reports"]["20"]
+    log = _ludwig("iodrop.inp", mode)
+    rho = _last(log, "[rho]")
+    assert rho[0] == ref["rho_total"]
+    assert abs(rho[2] - ref["rho_var"]) <= 1e-12
+    assert abs(rho[3] - ref["rho_min"]) < 2e-11 and abs(rho[4] - ref["rho_max"]) < 2e-11
+    phi = _last(log, "[phi]")
+    assert abs(phi[2] - ref["phi_var"]) <= 2e-7 * ref["phi_var"]
+    assert abs(phi[3] - ref["phi_min"]) <= 2e-7 and abs(phi[4] - ref["phi_max"]) <= 2e-7
+    assert abs(_last(log, "[fed]")[-1] - ref["fed"]) <= 1e-9 * abs(ref["fed"])
+    for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
+        for a, b in zip(_last(log, tag), ref[key]):
+            assert abs(a - b) <= 2e-7 * abs(b) + 1e-16
