@@ -16,7 +16,11 @@ N > 1: strong scaling, the 256^3 box is cut into N slabs along X (the
 reference's `grid N_1_1`), X halo planes travel over RCCL (ncclSend/ncclRecv)
 on a second stream overlapped with the interior planes.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0. At N = 1 it carries, beside "roofline"
+(HIP events around the sampled launches of the step's kernel), two reported
+comparators measured after the timed region: "cpu_baseline" (the reference's
+CPU build, oracle/_ref, on this host's cores) and "reference_gpu" (the
+reference's own HIP back end, oracle/_ref/ref_driver_hip_*, on this GPU).
 """
 
 import argparse
