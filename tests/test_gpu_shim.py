@@ -318,3 +318,19 @@ def test_ludwig_droplet_twenty_coupled_steps(mode):
     for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
         for a, b in zip(_last(log, tag), ref[key]):
             assert abs(a - b) <= 2e-7 * abs(b) + 1e-16
+
+
+@pytest.mark.parametrize("mode", ["eager", "halo", "fused"])
+def test_ludwig_two_dimensional_lattice(mode):
+    """serial-dist-2kh: a 64 x 64 x 1 lattice (one site, three with the halo,
+    along the contiguous direction): Kelvin-Helmholtz initial condition, ten
+    steps."""
+    ref = _json.load(open(os.path.join(HERE, "golden", "regression_app_extra.json")))["dist_2kh"]
+    log = _ludwig("dist_2kh.inp", mode)
+    rho = _last(log, "[rho]")
+    assert rho[0] == ref["rho"][0]
+    assert abs(rho[2] - ref["rho"][2]) <= 1e-12
+    assert abs(rho[3] - ref["rho"][3]) < 2e-11 and abs(rho[4] - ref["rho"][4]) < 2e-11
+    for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
+        for a, b in zip(_last(log, tag), ref[key]):
+            assert abs(a - b) <= 2e-7 * abs(b) + 1e-16
