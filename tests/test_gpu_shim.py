@@ -251,14 +251,16 @@ def test_ludwig_binary_fluid_droplet_with_the_binding(mode):
 
 
 @pytest.mark.parametrize("mode", ["eager", "halo"])
-@pytest.mark.parametrize("name", ["spin_lb1", "symm_dr2"])
+@pytest.mark.parametrize("name", ["spin_lb1", "symm_dr2", "spin_fd1", "symm_pat"])
 def test_ludwig_application_more_regressions(name, mode):
     """spin_lb1: free_energy symmetric_lb (two distributions, ghost modes
     off), ten steps of a spinodal quench -- phi_lb_to_field, the binary
     collision, halo and propagation of both distributions through the
     binding. symm_dr2: the droplet with an Arrhenius viscosity model -- the
-    collision takes its relaxation times from hydro->eta. Statistics of the
-    reference's logs serial-spin-lb1.log / serial-symm-dr2.log."""
+    collision takes its relaxation times from hydro->eta. spin_fd1: spinodal
+    quench with the finite-difference order parameter, ten steps, ghost modes
+    off. symm_pat: one step from a patchy phi (steep gradients, large forces).
+    Statistics of the reference's logs serial-<name>.log."""
     ref = _json.load(open(os.path.join(HERE, "golden", "regression_app_extra.json")))[name]
     log = _ludwig(name + ".inp", mode)
     rho = _last(log, "[rho]")
