@@ -242,6 +242,9 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro);  /* lb_collide */
 int lbmi_lb_halo(lbmi_t * lb);                                 /* lb_halo    */
 int lbmi_lb_propagation(lbmi_t * lb);                          /* lb_propagation */
 int lbmi_lb_flush(lbmi_t * lb);
+/* Another lbmi_mode_t for an existing handle, at any point of the step: a
+ * flush, then the calls that follow run in the new mode. */
+int lbmi_lb_mode_set(lbmi_t * lb, int mode);
 /* nsteps x (lbmi_lb_collide, lbmi_lb_halo, lbmi_lb_propagation): the LB part
  * of the reference's main loop for callers that have nothing to do in
  * between (a host language with expensive foreign calls, a benchmark). */
@@ -299,12 +302,28 @@ int lbmi_wall_velocity_set(lbmi_t * lb, const double ubot[3],
 int lbmi_wall_bbl(lbmi_t * lb);
 /* The same on DEVICE link arrays the caller owns (the reference's
  * wall->target->linki, linkj, linkp, linku), fnet = 3 doubles on the device
- * that the momentum is added to (wall->target->fnet). */
+ * that the momentum is added to (wall->target->fnet). The kernels skip a
+ * record that would address outside the distributions and report it:
+ * LBMI_ERR_ARGUMENT from the first call that sees given arrays (that call
+ * waits for its kernel), or from the call after the launch that met it. */
 int lbmi_wall_bbl_arrays(lbmi_t * lb, int nlink, const int * linki,
 			 const int * linkj, const int * linkp,
 			 const int * linku, const double ubot[3],
 			 const double utop[3], double * fnet);
 int lbmi_wall_momentum(lbmi_t * lb, double fnet[3]);
+/* Links made by the caller: HOST arrays of nlink ints as wall_init_boundaries
+ * and wall_init_uw leave them in wall->linki, linkj, linkp, linku (wall.c:
+ * 399-451, 864-890). Every record is checked on the host (0 <= i < nsite,
+ * 1 <= p < nvel, j = i + c_p inside the array, u in {0, 1, 2};
+ * LBMI_ERR_ARGUMENT names the first bad one) and copied: lbmi_wall_bbl then
+ * works on device arrays the handle owns, whatever becomes of the caller's. */
+int lbmi_wall_links_set(lbmi_t * lb, int nlink, const int * linki,
+			const int * linkj, const int * linkp,
+			const int * linku);
+/* Where lbmi_wall_bbl adds the momentum: 3 doubles on the DEVICE that the
+ * caller owns (wall->target->fnet), or NULL = the handle's accumulator
+ * (lbmi_wall_momentum). The pointer is kept. */
+int lbmi_wall_fnet_bind(lbmi_t * lb, double * fnet);
 /* map->target->status (DEVICE, nsite chars) for the MAP_COLLOID test of the
  * bounce-back kernels (wall.c:1046-1061, 1146-1161): a link whose fluid site a
  * colloid covers is left to the colloid's own bounce-back and only enters the
@@ -333,6 +352,13 @@ int lbmi_wall_status_set(lbmi_t * lb, const char * status);
 int lbmi_wall_slip_set(lbmi_t * lb, const char * status,
 		       const double sbot[3], const double stop[3]);
 int lbmi_wall_slip_links(lbmi_t * lb, int * linkk, int * linkq, int * links);
+/* Slip records made by the caller (HOST arrays wall->linkk, linkq, links in
+ * the reference's types, stab = wall->param->slip.s) for the links of
+ * lbmi_wall_links_set / _build: checked (0 <= k < nsite, 0 <= q < nvel,
+ * 0 <= s < 19), copied, and lbmi_wall_bbl takes the slip kernel from then on. */
+int lbmi_wall_slip_links_set(lbmi_t * lb, const int * linkk,
+			     const signed char * linkq,
+			     const signed char * links, const double stab[19]);
 int lbmi_wall_bbl_slip_arrays(lbmi_t * lb, int nlink, const int * linki,
 			      const int * linkj, const int * linkp,
 			      const int * linkk, const signed char * linkq,

@@ -17,7 +17,12 @@
  *      phi_lb_to_field() phi_lb_coupler.h  (replaces phi_lb_coupler.c:39-64)
  *      hydro_u_zero(), hydro_f_zero()  hydro.h:64-65 (hydro.c:279-330)
  *      field_halo()      field.h:96        (field.c; FIELD_HALO_TARGET only)
- *      field_grad_compute() field_grad.h:49 (3d_7pt_fluid / 3d_27pt_fluid d2)
+  *      field_grad_compute() field_grad.h:49 (3d_7pt_fluid / 3d_27pt_fluid d2)
+ *      wall_set_wall_distributions() wall.h:100, bounce_back_on_links()
+ *                        bbl.h:26: the originals, after making sure that the
+ *                        distributions they work on are the reference's
+ *      lb_free(), field_free(), map_free(), wall_free(): the originals, after
+ *                        forgetting what this file remembers of the object
  *
  *  by unpacking lb_t / hydro_t / map_t and calling the C-ABI of
  *  include/lbmi.h. The other contents of collision.c / model.c /
@@ -29,11 +34,16 @@
  *      -Dlb_memcpy=lb_memcpy_ref -Dlb_io_write=lb_io_write_ref
  *      -Dlb_io_read=lb_io_read_ref
  *
- *  (and wall.c with -Dwall_bbl=wall_bbl_ref, phi_lb_coupler.c with
+  *      -Dlb_free=lb_free_ref
+ *
+ *  (and wall.c with -Dwall_bbl=wall_bbl_ref -Dwall_set_wall_distributions=
+ *  wall_set_wall_distributions_ref -Dwall_free=wall_free_ref, bbl.c with
+ *  -Dbounce_back_on_links=bounce_back_on_links_ref, map.c with -Dmap_free=
+ *  map_free_ref, phi_lb_coupler.c with
  *  -Dphi_lb_to_field=phi_lb_to_field_ref, hydro.c with -Dhydro_u_zero=
  *  hydro_u_zero_ref -Dhydro_f_zero=hydro_f_zero_ref, field.c with -Dfield_halo=
- *  field_halo_ref, field_grad.c with -Dfield_grad_compute=
- *  field_grad_compute_ref) so that their originals remain
+ *  field_halo_ref -Dfield_free=field_free_ref, field_grad.c with
+ *  -Dfield_grad_compute=field_grad_compute_ref) so that their originals remain
  *  available as fall-backs (colloids, Lees-Edwards, host halo
  *  schemes, noise), and this file is compiled
  *  with the same -D_D3Q19_|-D_D3Q27_ -DADDR_SOA as the rest of libludwig.a
@@ -50,6 +60,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "pe.h"
 #include "coords.h"
@@ -69,6 +80,8 @@
 #include "gradient_3d_7pt_fluid.h"
 #include "gradient_3d_27pt_fluid.h"
 #include "leesedwards.h"
+#include "bbl.h"
+#include "colloids.h"
 
 #include "lbmi.h"
 
@@ -81,6 +94,13 @@ int lb_memcpy_ref(lb_t * lb, tdpMemcpyKind flag);
 int lb_io_write_ref(lb_t * lb, int timestep, io_event_t * event);
 int lb_io_read_ref(lb_t * lb, int timestep, io_event_t * event);
 int wall_bbl_ref(wall_t * wall);
+int wall_set_wall_distributions_ref(wall_t * wall);
+int wall_free_ref(wall_t * wall);
+int bounce_back_on_links_ref(bbl_t * bbl, lb_t * lb, wall_t * wall,
+			     colloids_info_t * cinfo);
+int lb_free_ref(lb_t * lb);
+int field_free_ref(field_t * obj);
+int map_free_ref(map_t * obj);
 int phi_lb_to_field_ref(field_t * phi, lb_t * lb);
 int hydro_u_zero_ref(hydro_t * hydro, const double uzero[3]);
 int hydro_f_zero_ref(hydro_t * hydro, const double fzero[3]);
@@ -93,9 +113,13 @@ typedef struct shim_s {
   lb_t * lb;
   lbmi_t * h;
   int mode;                       /* lbmi_mode_t in use */
+  wall_t * wall;                  /* whose links the handle holds a copy of */
+  int wall_nlink;
+  int param_valid;                /* param_committed is what the device has */
+  lb_collide_param_t param_committed;
 } shim_t;
 
-static shim_t shim_ = {NULL, NULL, LBMI_MODE_EAGER};
+static shim_t shim_;              /* zero: no handle, LBMI_MODE_EAGER */
 
 #define SHIM_CHECK(lb, call)						\
   do {									\
@@ -131,8 +155,7 @@ static void shim_device_f(lb_t * lb, double ** f, double ** fprime) {
 }
 
 /* Device data pointers are fixed once an object exists, and every fetch is a
- * blocking copy that drains the stream: remember them (objects of these
- * types live as long as the run). */
+ * blocking copy that drains the stream: remember them ... */
 
 #define SHIM_NCACHE 32
 static struct { const void * obj; void * data; } shim_cache_[SHIM_NCACHE];
@@ -151,6 +174,22 @@ static void * shim_cached(const void * obj, const void * device_member,
     shim_ncache_ += 1;
   }
   return data;
+}
+
+/* ... and forgotten when the object goes (lb_free, field_free, map_free
+ * below): a later object at the same address has other device arrays */
+
+static void shim_forget(const void * obj) {
+  int n = 0;
+  while (n < shim_ncache_) {
+    if (shim_cache_[n].obj == obj) {
+      shim_cache_[n] = shim_cache_[shim_ncache_ - 1];
+      shim_ncache_ -= 1;
+    }
+    else {
+      n += 1;
+    }
+  }
 }
 
 static double * shim_field_data(field_t * field) {
@@ -187,11 +226,16 @@ static lbmi_t * shim_handle(lb_t * lb) {
     int cartsz[3], coords[3];
     double * f = NULL;
     double * fprime = NULL;
-    /* LBMI_MODE = eager (default: f as the reference after every call),
-     * halo (collision and halo as observable as in eager, propagation
-     * deferred: walls and colloids are fine) or fused (halo swap and
-     * propagation deferred: nothing may touch f between lb_collide and
-     * lb_propagation) */
+        /* LBMI_MODE = halo (the default: after lb_collide and lb_halo f is the
+     * reference's, so walls, colloids and anything else that acts between
+     * lb_halo and lb_propagation find what they expect; only the propagation
+     * is deferred into the next collision, and every reader this file knows
+     * of -- lb_memcpy, the statistics, lb_io_write, phi_lb_to_field -- flushes
+     * it first), eager (f as the reference after every call, three passes
+     * over f per step) or fused (halo swap and propagation both deferred:
+     * nothing may touch f between lb_collide and lb_propagation; a run that
+     * turns out to have wall links or colloids drops to halo at the first
+     * wall_set_wall_distributions / bounce_back_on_links that would see it) */
     const char * mode = getenv("LBMI_MODE");
 
     lbmi_options_default(&opts);
@@ -205,17 +249,23 @@ static lbmi_t * shim_handle(lb_t * lb) {
     opts.cartrank = coords[X];
     opts.device = -1;                            /* ludwig.c:467-492 chose it */
     opts.halo_scheme = LBMI_HALO_FULL;           /* halo_swap_packed semantics */
-    opts.mode = LBMI_MODE_EAGER;
+        opts.mode = LBMI_MODE_FUSED_HALO;              /* ndist 1 or 2 */
+    if (mode && mode[0] == 'e') opts.mode = LBMI_MODE_EAGER;
     if (mode && mode[0] == 'f' && lb->ndist == 1) opts.mode = LBMI_MODE_FUSED;
-    if (mode && mode[0] == 'h') opts.mode = LBMI_MODE_FUSED_HALO;  /* ndist 1 or 2 */
+    if (mode && mode[0] != 'e' && mode[0] != 'f' && mode[0] != 'h') {
+      pe_fatal(lb->pe, "liblbmi: LBMI_MODE=%s (halo, eager or fused)\n", mode);
+    }
 
     SHIM_CHECK(lb, lbmi_create(&opts, &shim_.h));
     /* Ludwig launches all its kernels on the default stream
      * (tdpLaunchKernel(..., 0, 0, ...)): run ours there too, so that the
      * kernels on either side of each call are ordered without extra syncs */
     SHIM_CHECK(lb, lbmi_set_stream(shim_.h, NULL));
-    shim_.lb = lb;
+        shim_.lb = lb;
     shim_.mode = opts.mode;
+        shim_.wall = NULL;
+    shim_.wall_nlink = 0;
+    shim_.param_valid = 0;
 
     shim_device_f(lb, &f, &fprime);
     SHIM_CHECK(lb, lbmi_lb_bind(shim_.h, f, fprime));
@@ -236,6 +286,38 @@ static lbmi_t * shim_handle(lb_t * lb) {
   }
 
   return shim_.h;
+}
+
+/* lb_collide_param_commit (model.c:342-349) is the reference's only upload of
+ * lb->param to the device copy that lb->target->param points at, and the
+ * original lb_collide is its only caller (collision.c:157). Foreign kernels
+ * read it: wall_setu_kernel takes nvel, wv, cv, rho0 from it every step
+ * (wall.c:943-945), and with a zero nvel its lb_f_set lands up to
+ * 18 nsite doubles BEFORE f. So the bound lb_collide commits as the original
+ * does -- when the host struct has changed, not every step: the copy to the
+ * symbol is a blocking one. */
+
+static void shim_param_commit(lb_t * lb) {
+  if (shim_.param_valid &&
+      memcmp(&shim_.param_committed, lb->param, sizeof(lb_collide_param_t)) == 0) {
+    return;
+  }
+  lb_collide_param_commit(lb);
+  memcpy(&shim_.param_committed, lb->param, sizeof(lb_collide_param_t));
+  if (!shim_.param_valid) {
+    /* once: what the device sees through lb->target->param is the model */
+    lb_collide_param_t * pdev = NULL;
+    int nvel_dev = -1;
+    tdpAssert(tdpMemcpy(&pdev, &lb->target->param, sizeof(lb_collide_param_t *),
+			tdpMemcpyDeviceToHost));
+    tdpAssert(tdpMemcpy(&nvel_dev, &pdev->nvel, sizeof(int),
+			tdpMemcpyDeviceToHost));
+    if (nvel_dev != lb->model.nvel) {
+      pe_fatal(lb->pe, "liblbmi: lb->target->param->nvel = %d on the device, "
+	       "model nvel = %d\n", nvel_dev, lb->model.nvel);
+    }
+  }
+  shim_.param_valid = 1;
 }
 
 /*****************************************************************************
@@ -293,7 +375,8 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
     }
     if (lb->nrelax == LB_RELAXATION_BGK) scheme = LBMI_RELAXATION_BGK;
     if (lb->nrelax == LB_RELAXATION_TRT) scheme = LBMI_RELAXATION_TRT;
-    lb_collision_relaxation_times_set(lb);       /* keeps lb->param current */
+        lb_collision_relaxation_times_set(lb);       /* lb->param, host (collision.c:155) */
+    shim_param_commit(lb);                       /* ... and device (collision.c:157) */
     SHIM_CHECK(lb, lbmi_set_relaxation(h, scheme, rho0, eta, zeta));
     SHIM_CHECK(lb, lbmi_set_body_force(h, fbody));
 
@@ -358,12 +441,56 @@ int phi_lb_to_field(field_t * phi, lb_t * lb) {
 
 /*****************************************************************************
  *
- *  wall_bbl  (wall.c:960-989): bounce-back on the reference's own links
+ *  wall_bbl  (wall.c:960-989): bounce-back on the reference's links
  *
- *  The link arrays and the momentum accumulator are members of the DEVICE
- *  copy of wall_t; the kernel works on them where they are.
+ *  The links are taken from the HOST arrays wall->linki, linkj, linkp, linku
+ *  (and linkk, linkq, links with slip) that wall_init_boundaries, wall_init_uw
+ *  and wall_init_boundaries_slip fill (wall.c:399-451, 864-890, 489-593):
+ *  liblbmi checks every record and keeps its own device copies, once per
+ *  wall_t. It does not rely on wall->target->link*, whose device allocation
+ *  goes through "int tmp; tdpMalloc((void **) &tmp, ...)" (wall.c:412-426,
+ *  516-528). The momentum goes where the reference's kernel puts it,
+ *  wall->target->fnet, so wall_momentum() works unchanged.
  *
  *****************************************************************************/
+
+static void shim_wall_links(wall_t * wall, lbmi_t * h) {
+
+  if (shim_.wall == wall && shim_.wall_nlink == wall->nlink) return;
+
+  SHIM_CHECK(wall->lb, lbmi_wall_links_set(h, wall->nlink, wall->linki,
+					   wall->linkj, wall->linkp,
+					   wall->linku));
+  if (wall->param->slip.active) {                         /* wall.c:971 */
+    SHIM_CHECK(wall->lb,
+	       lbmi_wall_slip_links_set(h, wall->linkk,
+					(const signed char *) wall->linkq,
+					(const signed char *) wall->links,
+					wall->param->slip.s));
+  }
+  SHIM_CHECK(wall->lb,
+	     lbmi_wall_fnet_bind(h, (double *) ((char *) wall->target
+						+ offsetof(wall_t, fnet))));
+  shim_.wall = wall;
+  shim_.wall_nlink = wall->nlink;
+}
+
+/* Kernels of the reference that read or write lb->target->f between
+ * lb_collide and lb_propagation (wall_setu_kernel wall.c:930-950, the
+ * colloid bounce-back bbl.c:272-360) need the post-collision state with its
+ * halo in the reference's order: EAGER and FUSED_HALO have exactly that,
+ * FUSED has not (halo swap deferred, blocked order). A run in LBMI_MODE=fused
+ * that gets here with work to do continues in FUSED_HALO. */
+
+static void shim_needs_canonical_f(lb_t * lb, const char * who) {
+  if (shim_.h == NULL || shim_.lb != lb) return;
+  if (shim_.mode != LBMI_MODE_FUSED) return;
+  pe_info(lb->pe, "liblbmi: %s acts on the distributions between lb_halo and "
+	  "lb_propagation: LBMI_MODE=fused -> halo\n", who);
+  SHIM_CHECK(lb, lbmi_lb_mode_set(shim_.h, LBMI_MODE_FUSED_HALO));
+  shim_.mode = LBMI_MODE_FUSED_HALO;
+  shim_sync_pointers(lb, shim_.h);
+}
 
 int wall_bbl(wall_t * wall) {
 
@@ -375,57 +502,91 @@ int wall_bbl(wall_t * wall) {
   if (!shim_supported(wall->lb)) {
     return wall_bbl_ref(wall);
   }
-  if (shim_.mode == LBMI_MODE_FUSED) {
-    pe_fatal(wall->pe, "liblbmi: LBMI_MODE=fused cannot be used with walls "
-	     "(bounce-back acts between lb_halo and lb_propagation): use "
-	     "LBMI_MODE=halo\n");
-  }
 
   {
-    int * link[4] = {NULL, NULL, NULL, NULL};
-    double * fnet = (double *) ((char *) wall->target + offsetof(wall_t, fnet));
-    tdpAssert(tdpMemcpy(&link[0], &wall->target->linki, sizeof(int *),
-			tdpMemcpyDeviceToHost));
-    tdpAssert(tdpMemcpy(&link[1], &wall->target->linkj, sizeof(int *),
-			tdpMemcpyDeviceToHost));
-    tdpAssert(tdpMemcpy(&link[2], &wall->target->linkp, sizeof(int *),
-			tdpMemcpyDeviceToHost));
-    tdpAssert(tdpMemcpy(&link[3], &wall->target->linku, sizeof(int *),
-			tdpMemcpyDeviceToHost));
-    {
-      /* the kernels test map->status[i] for MAP_COLLOID (wall.c:1046, 1146) */
-      char * status = NULL;
-      tdpAssert(tdpMemcpy(&status, &wall->map->target->status, sizeof(char *),
-			  tdpMemcpyDeviceToHost));
-      SHIM_CHECK(wall->lb, lbmi_wall_status_set(shim_handle(wall->lb), status));
-    }
-    if (wall->param->slip.active) {                       /* wall.c:971 */
-      int * linkk = NULL;
-      int8_t * linkq = NULL;
-      int8_t * links = NULL;
-      tdpAssert(tdpMemcpy(&linkk, &wall->target->linkk, sizeof(int *),
-			  tdpMemcpyDeviceToHost));
-      tdpAssert(tdpMemcpy(&linkq, &wall->target->linkq, sizeof(int8_t *),
-			  tdpMemcpyDeviceToHost));
-      tdpAssert(tdpMemcpy(&links, &wall->target->links, sizeof(int8_t *),
-			  tdpMemcpyDeviceToHost));
-      SHIM_CHECK(wall->lb,
-		 lbmi_wall_bbl_slip_arrays(shim_handle(wall->lb), wall->nlink,
-					   link[0], link[1], link[2], linkk,
-					   (const signed char *) linkq,
-					   (const signed char *) links,
-					   wall->param->slip.s, fnet));
-    }
-    else {
-      SHIM_CHECK(wall->lb, lbmi_wall_bbl_arrays(shim_handle(wall->lb),
-						 wall->nlink, link[0], link[1],
-						 link[2], link[3],
-						 wall->param->ubot,
-						 wall->param->utop, fnet));
-    }
+    lbmi_t * h = shim_handle(wall->lb);
+    char * status = NULL;
+
+    shim_needs_canonical_f(wall->lb, "wall_bbl");
+    shim_wall_links(wall, h);
+    /* the kernels test map->status[i] for MAP_COLLOID (wall.c:1046, 1146) */
+    status = (char *) shim_cached(wall->map, &wall->map->target->status,
+				  sizeof(char *));
+    SHIM_CHECK(wall->lb, lbmi_wall_status_set(h, status));
+    SHIM_CHECK(wall->lb, lbmi_wall_velocity_set(h, wall->param->ubot,
+						wall->param->utop));
+    SHIM_CHECK(wall->lb, lbmi_wall_bbl(h));
   }
 
   return 0;
+}
+
+/*****************************************************************************
+ *
+ *  wall_set_wall_distributions (wall.c:900-950), bounce_back_on_links
+ *  (bbl.c:147-200): the originals, on distributions that are what they expect
+ *
+ *****************************************************************************/
+
+int wall_set_wall_distributions(wall_t * wall) {
+
+  assert(wall);
+
+  if (wall->nlink == 0) return 0;                /* wall.c:907 */
+  shim_needs_canonical_f(wall->lb, "wall_set_wall_distributions");
+
+  return wall_set_wall_distributions_ref(wall);
+}
+
+int bounce_back_on_links(bbl_t * bbl, lb_t * lb, wall_t * wall,
+			 colloids_info_t * cinfo) {
+  int ntotal = 0;
+
+  assert(lb);
+  assert(cinfo);
+
+  colloids_info_ntotal(cinfo, &ntotal);
+  if (ntotal > 0) shim_needs_canonical_f(lb, "bounce_back_on_links");
+
+  return bounce_back_on_links_ref(bbl, lb, wall, cinfo);
+}
+
+/*****************************************************************************
+ *
+ *  lb_free, field_free, map_free, wall_free: the originals, after dropping
+ *  what this file remembers under the object's address
+ *
+ *****************************************************************************/
+
+int lb_free(lb_t * lb) {
+  assert(lb);
+  if (shim_.lb == lb) {
+    /* the handle borrows lb->target->f / fprime: it goes first */
+    if (shim_.h) lbmi_free(shim_.h);
+    memset(&shim_, 0, sizeof(shim_));
+    last_f = NULL;
+    last_fprime = NULL;
+  }
+  return lb_free_ref(lb);
+}
+
+int field_free(field_t * obj) {
+  shim_forget(obj);
+  return field_free_ref(obj);
+}
+
+int map_free(map_t * obj) {
+  shim_forget(obj);
+  return map_free_ref(obj);
+}
+
+int wall_free(wall_t * wall) {
+  if (shim_.wall == wall) {
+    if (shim_.h) lbmi_wall_links_set(shim_.h, 0, NULL, NULL, NULL, NULL);
+    shim_.wall = NULL;
+    shim_.wall_nlink = 0;
+  }
+  return wall_free_ref(wall);
 }
 
 /*****************************************************************************

@@ -89,6 +89,11 @@ struct lbmi_s {
   double wall_ubot[3];
   double wall_utop[3];
   const char * wall_status;          /* device map for the MAP_COLLOID test */
+  double * wall_fnet_ext;            /* lbmi_wall_fnet_bind: the caller's accumulator */
+  int * wall_err;                    /* pinned, mapped: index + 1 of a link record
+					the kernels refused (0: none) */
+  const void * wall_seen[2];         /* caller-owned link arrays already checked */
+  int wall_seen_nlink;
   /* lbmi_lb_run: two steady-state steps captured in a hipGraph */
   int use_graph;
   hipGraphExec_t run_graph;
@@ -380,6 +385,11 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
     lbmi_free(lb);
     return lbmi_fail(LBMI_ERR_HIP, "hipMalloc (moments workspace) failed");
   }
+  if (hipHostMalloc((void **) &lb->wall_err, sizeof(int), hipHostMallocMapped) != hipSuccess) {
+    lbmi_free(lb);
+    return lbmi_fail(LBMI_ERR_HIP, "hipHostMalloc (link error flag) failed");
+  }
+  *lb->wall_err = 0;
 
   *handle = lb;
 
@@ -413,6 +423,7 @@ int lbmi_free(lbmi_t * lb) {
   if (lb->mom_work) hipFree(lb->mom_work);
   if (lb->mom_out) hipFree(lb->mom_out);
   lbmi_wall_release(lb);
+  if (lb->wall_err) hipHostFree(lb->wall_err);
   lbmi_run_graph_release(lb);
   if (lb->ev_graph) hipEventDestroy(lb->ev_graph);
   if (lb->ev_created) {
@@ -1223,8 +1234,14 @@ static void lbmi_wall_release(lbmi_t * lb) {
   lb->wall_part = NULL;
   lb->wall_part_nblk = 0;
   lb->wall_fnet = NULL;
+  lb->wall_fnet_ext = NULL;
+  lb->wall_seen[0] = NULL;
+  lb->wall_seen[1] = NULL;
+  lb->wall_seen_nlink = 0;
   lb->nlink = 0;
 }
+
+static int lbmi_wall_upload(lbmi_t * lb, int nlink);
 
 static int lbmi_wall_args(const lbmi_t * lb, const int isboundary[3]) {
   if (lb == NULL || isboundary == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
@@ -1269,6 +1286,26 @@ int lbmi_wall_map(lbmi_t * lb, const int isboundary[3], char * status) {
     return lbmi_fail(LBMI_ERR_HIP, "wall map: host to device");
   }
   free(host);
+  return 0;
+}
+
+/* link_host -> link_dev, and the momentum accumulator */
+
+static int lbmi_wall_upload(lbmi_t * lb, int nlink) {
+  for (int k = 0; k < 4; k++) {
+    size_t sz = sizeof(int)*(size_t) (nlink > 0 ? nlink : 1);
+    if (hipMalloc((void **) &lb->link_dev[k], sz) != hipSuccess ||
+	hipMemcpy(lb->link_dev[k], lb->link_host[k], sz, hipMemcpyHostToDevice) != hipSuccess) {
+      lbmi_wall_release(lb);
+      return lbmi_fail(LBMI_ERR_HIP, "wall links: device arrays");
+    }
+  }
+  if (hipMalloc((void **) &lb->wall_fnet, 3*sizeof(double)) != hipSuccess ||
+      hipMemset(lb->wall_fnet, 0, 3*sizeof(double)) != hipSuccess) {
+    lbmi_wall_release(lb);
+    return lbmi_fail(LBMI_ERR_HIP, "wall momentum workspace");
+  }
+  lb->nlink = nlink;
   return 0;
 }
 
@@ -1338,22 +1375,55 @@ int lbmi_wall_links_build(lbmi_t * lb, const char * status,
     return ifail;
   }
 
-  for (int k = 0; k < 4; k++) {
-    size_t sz = sizeof(int)*(size_t) (nlink > 0 ? nlink : 1);
-    if (hipMalloc((void **) &lb->link_dev[k], sz) != hipSuccess ||
-	hipMemcpy(lb->link_dev[k], lb->link_host[k], sz, hipMemcpyHostToDevice) != hipSuccess) {
-      lbmi_wall_release(lb);
-      return lbmi_fail(LBMI_ERR_HIP, "wall links: device arrays");
-    }
-  }
-  if (hipMalloc((void **) &lb->wall_fnet, 3*sizeof(double)) != hipSuccess ||
-      hipMemset(lb->wall_fnet, 0, 3*sizeof(double)) != hipSuccess) {
-    lbmi_wall_release(lb);
-    return lbmi_fail(LBMI_ERR_HIP, "wall momentum workspace");
-  }
-  lb->nlink = nlink;
+    ifail = lbmi_wall_upload(lb, nlink);
+  if (ifail) return ifail;
   if (nlink_out) *nlink_out = nlink;
   return 0;
+}
+
+/* wall_init_boundaries done by the caller (the reference keeps the result in
+ * the HOST arrays wall->linki, linkj, linkp, linku, wall.c:399-451): every
+ * record is checked here, on the host, before a kernel can see it, and the
+ * device copies belong to the handle. */
+
+int lbmi_wall_links_set(lbmi_t * lb, int nlink, const int * linki,
+			const int * linkj, const int * linkp,
+			const int * linku) {
+  const int * in[4] = {linki, linkj, linkp, linku};
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (nlink < 0 || (nlink > 0 && (!linki || !linkj || !linkp || !linku))) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_wall_links_set: bad argument");
+  }
+  for (int n = 0; n < nlink; n++) {
+    const int p = linkp[n];
+    long long j;
+    if (p < 1 || p >= lb->kp.nvel || linki[n] < 0 ||
+	(long long) linki[n] >= lb->kp.nsite || linku[n] < 0 || linku[n] > 2) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "link %d of %d: (i, j, p, u) = (%d, "
+		       "%d, %d, %d) is not a link of this lattice (nsite %lld, "
+		       "nvel %d)", n, nlink, linki[n], linkj[n], p, linku[n],
+		       lb->kp.nsite, lb->kp.nvel);
+    }
+    j = (long long) linki[n] + lb->cv[p][X]*(long long) lb->kp.strx
+      + lb->cv[p][Y]*(long long) lb->kp.stry + lb->cv[p][Z];
+    if ((long long) linkj[n] != j || j < 0 || j >= lb->kp.nsite) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "link %d of %d: j = %d is not "
+		       "i + c_p = %lld (i %d, p %d)", n, nlink, linkj[n], j,
+		       linki[n], p);
+    }
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  HIPCHECK(hipStreamSynchronize(lb->stream));
+  lbmi_wall_release(lb);
+  for (int k = 0; k < 4; k++) {
+    lb->link_host[k] = (int *) calloc((size_t) (nlink > 0 ? nlink : 1), sizeof(int));
+    if (lb->link_host[k] == NULL) {
+      lbmi_wall_release(lb);
+      return lbmi_fail(LBMI_ERR_HIP, "wall links");
+    }
+    if (nlink > 0) memcpy(lb->link_host[k], in[k], sizeof(int)*(size_t) nlink);
+  }
+  return lbmi_wall_upload(lb, nlink);
 }
 
 int lbmi_wall_links(lbmi_t * lb, int * linki, int * linkj, int * linkp,
@@ -1382,6 +1452,43 @@ int lbmi_wall_velocity_set(lbmi_t * lb, const double ubot[3],
 int lbmi_wall_status_set(lbmi_t * lb, const char * status) {
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   lb->wall_status = status;
+  return 0;
+}
+
+/* The bounce-back kernels never dereference a record that would address
+ * outside f: they skip it and leave its index + 1 in lb->wall_err (pinned
+ * host memory the device writes). Arrays of the handle were checked on the
+ * host when they were made; arrays the caller owns are checked the first time
+ * they are seen (one synchronisation), and from then on whatever an earlier
+ * launch left is reported by the next call, without waiting. */
+
+static int lbmi_wall_err_report(lbmi_t * lb) {
+  if (lb->wall_err != NULL && *lb->wall_err != 0) {
+    const int n = *lb->wall_err - 1;
+    *lb->wall_err = 0;
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "bounce-back: link record %d would "
+		     "address outside the distributions (it was skipped; need "
+		     "0 <= i, j < nsite, 1 <= p < nvel, u in {0, 1, 2})", n);
+  }
+  return 0;
+}
+
+static int lbmi_wall_after_launch(lbmi_t * lb, const void * a, const void * b,
+				  int nlink) {
+  if (a == (const void *) lb->link_dev[0]) return 0;      /* host-checked */
+  if (a != lb->wall_seen[0] || b != lb->wall_seen[1] ||
+      nlink != lb->wall_seen_nlink) {
+    HIPCHECK(hipStreamSynchronize(lb->stream));
+    lb->wall_seen[0] = a;
+    lb->wall_seen[1] = b;
+    lb->wall_seen_nlink = nlink;
+  }
+  return lbmi_wall_err_report(lb);
+}
+
+int lbmi_wall_fnet_bind(lbmi_t * lb, double * fnet) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  lb->wall_fnet_ext = fnet;
   return 0;
 }
 
@@ -1428,10 +1535,10 @@ int lbmi_wall_bbl_arrays(lbmi_t * lb, int nlink, const int * linki,
     tab.uw[1][ia] = utop[ia];
     tab.uw[2][ia] = ubot[ia];
   }
-  KCHECK(lbmi_k_wall_bbl(&lb->kp, &tab, lb->f, nlink, linki, linkj, linkp,
+    KCHECK(lbmi_k_wall_bbl(&lb->kp, &tab, lb->f, nlink, linki, linkj, linkp,
 			 linku, lb->wall_status, lb->wall_part, fnet,
-			 lb->stream));
-  return 0;
+			 lb->wall_err, lb->stream));
+  return lbmi_wall_after_launch(lb, linki, linku, nlink);
 }
 
 /* wall_slip (wall.c:285-316): faces, then the 12 edges XB_YB XB_YT XB_ZB
@@ -1583,6 +1690,62 @@ int lbmi_wall_slip_links(lbmi_t * lb, int * linkk, int * linkq, int * links) {
   return 0;
 }
 
+/* wall_init_boundaries_slip done by the caller (HOST arrays wall->linkk,
+ * linkq, links in the reference's types, wall.h:79-81, and the table
+ * wall->param->slip.s): checked here, copied, owned by the handle. */
+
+int lbmi_wall_slip_links_set(lbmi_t * lb, const int * linkk,
+			     const signed char * linkq,
+			     const signed char * links, const double stab[19]) {
+  size_t n1;
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->link_host[0] == NULL) return lbmi_fail(LBMI_ERR_STATE, "no links built");
+  if (!linkk || !linkq || !links || !stab) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_wall_slip_links_set: NULL");
+  }
+  for (int n = 0; n < lb->nlink; n++) {
+    if (linkk[n] < 0 || (long long) linkk[n] >= lb->kp.nsite || linkq[n] < 0 ||
+	linkq[n] >= lb->kp.nvel || links[n] < 0 || links[n] >= 19) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "slip link %d of %d: (k, q, s) = "
+		       "(%d, %d, %d) out of range", n, lb->nlink, linkk[n],
+		       (int) linkq[n], (int) links[n]);
+    }
+  }
+  for (int n = 0; n < 19; n++) {
+    if (!(stab[n] >= 0.0 && stab[n] <= 1.0)) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "slip fractions must lie in [0, 1]");
+    }
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  HIPCHECK(hipStreamSynchronize(lb->stream));
+  lbmi_slip_release(lb);
+  n1 = (size_t) lb->nlink + 1;
+  for (int k = 0; k < 3; k++) {
+    lb->slip_host[k] = (int *) calloc(n1, sizeof(int));
+    if (lb->slip_host[k] == NULL) {
+      lbmi_slip_release(lb);
+      return lbmi_fail(LBMI_ERR_HIP, "slip links");
+    }
+  }
+  for (int n = 0; n < lb->nlink; n++) {
+    lb->slip_host[0][n] = linkk[n];
+    lb->slip_host[1][n] = linkq[n];
+    lb->slip_host[2][n] = links[n];
+  }
+  if (hipMalloc((void **) &lb->slip_k_dev, n1*sizeof(int)) != hipSuccess ||
+      hipMalloc((void **) &lb->slip_q_dev, n1) != hipSuccess ||
+      hipMalloc((void **) &lb->slip_s_dev, n1) != hipSuccess ||
+      hipMemcpy(lb->slip_k_dev, linkk, (n1 - 1)*sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(lb->slip_q_dev, linkq, n1 - 1, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(lb->slip_s_dev, links, n1 - 1, hipMemcpyHostToDevice) != hipSuccess) {
+    lbmi_slip_release(lb);
+    return lbmi_fail(LBMI_ERR_HIP, "slip links: device arrays");
+  }
+  memcpy(lb->slip_s, stab, 19*sizeof(double));
+  lb->slip_active = 1;
+  return 0;
+}
+
 int lbmi_wall_bbl_slip_arrays(lbmi_t * lb, int nlink, const int * linki,
 			      const int * linkj, const int * linkp,
 			      const int * linkk, const signed char * linkq,
@@ -1621,25 +1784,28 @@ int lbmi_wall_bbl_slip_arrays(lbmi_t * lb, int nlink, const int * linki,
   for (int n = 0; n < 19; n++) tab.slip[n] = stab[n];
   KCHECK(lbmi_k_wall_bbl_slip(&lb->kp, &tab, lb->f, nlink, linki, linkj, linkp,
 			      linkk, (const int8_t *) linkq,
-			      (const int8_t *) links, lb->wall_status,
-			      lb->wall_part, fnet, lb->stream));
-  return 0;
+			      				      (const int8_t *) links, lb->wall_status,
+				      lb->wall_part, fnet, lb->wall_err,
+				      lb->stream));
+  return lbmi_wall_after_launch(lb, linki, linkk, nlink);
 }
 
 int lbmi_wall_bbl(lbmi_t * lb) {
+  double * fnet = NULL;
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
-  if (lb->link_host[0] == NULL) return lbmi_fail(LBMI_ERR_STATE, "no links built");
+    if (lb->link_host[0] == NULL) return lbmi_fail(LBMI_ERR_STATE, "no links built");
+  fnet = lb->wall_fnet_ext ? lb->wall_fnet_ext : lb->wall_fnet;
   if (lb->slip_active) {                                     /* wall.c:971 */
     return lbmi_wall_bbl_slip_arrays(lb, lb->nlink, lb->link_dev[0],
 				     lb->link_dev[1], lb->link_dev[2],
 				     lb->slip_k_dev,
 				     (const signed char *) lb->slip_q_dev,
-				     (const signed char *) lb->slip_s_dev,
-				     lb->slip_s, lb->wall_fnet);
+				     					     (const signed char *) lb->slip_s_dev,
+					     lb->slip_s, fnet);
   }
   return lbmi_wall_bbl_arrays(lb, lb->nlink, lb->link_dev[0], lb->link_dev[1],
 			      lb->link_dev[2], lb->link_dev[3], lb->wall_ubot,
-			      lb->wall_utop, lb->wall_fnet);
+			      lb->wall_utop, fnet);
 }
 
 int lbmi_wall_momentum(lbmi_t * lb, double fnet[3]) {
@@ -1891,6 +2057,30 @@ int lbmi_lb_flush(lbmi_t * lb) {
     lb->pending_prop = 0;
   }
 
+  return 0;
+}
+
+/* Change the execution mode of an existing handle, at any call point: what is
+ * deferred is materialised first (lbmi_lb_flush), so the new mode starts
+ * from the state the reference holds there. */
+
+int lbmi_lb_mode_set(lbmi_t * lb, int mode) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (mode != LBMI_MODE_EAGER && mode != LBMI_MODE_FUSED &&
+      mode != LBMI_MODE_INPLACE && mode != LBMI_MODE_FUSED_HALO) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "mode = %d", mode);
+  }
+  if (lb->opts.ndist == 2 && mode != LBMI_MODE_EAGER &&
+      mode != LBMI_MODE_FUSED_HALO) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = 2 needs LBMI_MODE_EAGER or LBMI_MODE_FUSED_HALO");
+  }
+  if (mode == lb->opts.mode) return 0;
+  if (lb->f != NULL) {
+    int ifail = lbmi_lb_flush(lb);
+    if (ifail) return ifail;
+  }
+  lbmi_run_graph_release(lb);
+  lb->opts.mode = mode;
   return 0;
 }
 

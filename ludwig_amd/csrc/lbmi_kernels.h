@@ -169,7 +169,9 @@ int lbmi_k_collide_binary(const lbmi_kparam_t * kp, const double * src,
 /* Bounce-back on links (wall_bbl_kernel, wall.c:996-1107). Tables travel by
  * value; part: nblk*3 doubles of per-block momentum, added to fnet[3] (device)
  * by a one-thread epilogue in block order (deterministic). status (or NULL):
- * links whose fluid site is MAP_COLLOID only enter the accounting. */
+ * links whose fluid site is MAP_COLLOID only enter the accounting. err: one
+ * int the host can read (pinned, mapped): a record that would address outside
+ * f is skipped and its index + 1 stored there. */
 typedef struct lbmi_wall_tab_s {
   int nvel;
   int ndist;
@@ -184,7 +186,7 @@ int lbmi_k_wall_bbl(const lbmi_kparam_t * kp, const lbmi_wall_tab_t * tab,
 		    double * f, int nlink, const int * linki,
 		    const int * linkj, const int * linkp, const int * linku,
 		    const char * status, double * part, double * fnet,
-		    void * stream);
+		    int * err, void * stream);
 
 /* wall_bbl_slip_kernel (wall.c:1118-1205): linkk, linkq, links as the
  * reference keeps them (int, int8_t, int8_t) */
@@ -193,7 +195,8 @@ int lbmi_k_wall_bbl_slip(const lbmi_kparam_t * kp, const lbmi_wall_tab_t * tab,
 			 const int * linkj, const int * linkp,
 			 const int * linkk, const int8_t * linkq,
 			 const int8_t * links, const char * status,
-			 double * part, double * fnet, void * stream);
+			 double * part, double * fnet, int * err,
+			 void * stream);
 
 /* Moments: partial (nblk x 12 doubles workspace) then final (out_dev[9]) */
 int lbmi_k_moments_nblk(void);

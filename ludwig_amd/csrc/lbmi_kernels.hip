@@ -2276,12 +2276,21 @@ __device__ __forceinline__ void wall_block_sum(double fx, double fy, double fz,
   }
 }
 
+/* A link record is usable if both sites lie inside the arrays and p is a
+ * moving direction (wall.c:440-451 stores p = 1 .. nvel - 1) */
+__device__ __forceinline__ bool wall_link_ok(size_t ns, int nvel, int i, int j,
+					     int p) {
+  return (size_t) (unsigned) i < ns && (size_t) (unsigned) j < ns &&
+    p >= 1 && p < nvel;
+}
+
 __global__ __launch_bounds__(WALL_BLOCK)
 void k_wall_bbl(lbmi_kparam_t kp, lbmi_wall_tab_t tab, double * __restrict__ f,
 		int nlink, const int * __restrict__ linki,
 		const int * __restrict__ linkj, const int * __restrict__ linkp,
 		const int * __restrict__ linku,
-		const char * __restrict__ status, double * __restrict__ part) {
+		const char * __restrict__ status, double * __restrict__ part,
+		int * __restrict__ err) {
 
   const size_t ns = (size_t) kp.nsite;
   const double rcs2 = 3.0;
@@ -2291,6 +2300,12 @@ void k_wall_bbl(lbmi_kparam_t kp, lbmi_wall_tab_t tab, double * __restrict__ f,
        n += gridDim.x*WALL_BLOCK) {
     const int i = linki[n], j = linkj[n];
     const int ij = linkp[n], ji = tab.nvel - ij, ia = linku[n];
+    /* a record that would address outside f (link arrays the caller owns may
+     * hold anything) is never dereferenced: sticky error, read by the host */
+    if (!wall_link_ok(ns, tab.nvel, i, j, ij) || (unsigned) ia > 2u) {
+      *err = n + 1;
+      continue;
+    }
     const double cx = tab.cv[ij][0], cy = tab.cv[ij][1], cz = tab.cv[ij][2];
     const double cdotu = cx*tab.uw[ia][0] + cy*tab.uw[ia][1] + cz*tab.uw[ia][2];
     const double wall = 2.0*rcs2*tab.wv[ij]*tab.rho0*cdotu;
@@ -2334,7 +2349,7 @@ void k_wall_bbl_slip(lbmi_kparam_t kp, lbmi_wall_tab_t tab,
 		     const int8_t * __restrict__ linkq,
 		     const int8_t * __restrict__ links,
 		     const char * __restrict__ status,
-		     double * __restrict__ part) {
+		     double * __restrict__ part, int * __restrict__ err) {
 
   const size_t ns = (size_t) kp.nsite;
   double fsum[3] = {0.0, 0.0, 0.0};
@@ -2343,7 +2358,13 @@ void k_wall_bbl_slip(lbmi_kparam_t kp, lbmi_wall_tab_t tab,
        n += gridDim.x*WALL_BLOCK) {
     const int i = linki[n], j = linkj[n], k = linkk[n];
     const int ij = linkp[n], ji = tab.nvel - ij, q = linkq[n];
-    const double s = tab.slip[links[n]];
+    const int is = links[n];
+    if (!wall_link_ok(ns, tab.nvel, i, j, ij) || (size_t) (unsigned) k >= ns ||
+	(unsigned) q >= (unsigned) tab.nvel || (unsigned) is >= 19u) {
+      *err = n + 1;
+      continue;
+    }
+    const double s = tab.slip[is];
     const double fi = f[ns*ij + i];
     const double fk = f[ns*q + k];
     if (status != nullptr && status[i] == MAP_COLLOID) {     /* wall.c:1148-1161 */
@@ -2894,12 +2915,14 @@ extern "C" int lbmi_k_wall_bbl(const lbmi_kparam_t * kp,
 			       int nlink, const int * linki,
 			       const int * linkj, const int * linkp,
 			       const int * linku, const char * status,
-			       double * part, double * fnet, void * stream) {
+			       double * part, double * fnet, int * err,
+			       void * stream) {
   hipStream_t st = (hipStream_t) stream;
   int nblk = lbmi_k_wall_nblk(nlink);
   if (nlink <= 0) return 0;
   hipLaunchKernelGGL(k_wall_bbl, dim3(nblk), dim3(WALL_BLOCK), 0, st, *kp,
-		     *tab, f, nlink, linki, linkj, linkp, linku, status, part);
+		     *tab, f, nlink, linki, linkj, linkp, linku, status, part,
+		     err);
   hipLaunchKernelGGL(k_wall_fnet, dim3(1), dim3(64), 0, st, nblk, part, fnet);
   return (int) hipGetLastError();
 }
@@ -2910,13 +2933,14 @@ extern "C" int lbmi_k_wall_bbl_slip(const lbmi_kparam_t * kp,
 				    const int * linkj, const int * linkp,
 				    const int * linkk, const int8_t * linkq,
 				    const int8_t * links, const char * status,
-				    double * part, double * fnet, void * stream) {
+				    double * part, double * fnet, int * err,
+				    void * stream) {
   hipStream_t st = (hipStream_t) stream;
   int nblk = lbmi_k_wall_nblk(nlink);
   if (nlink <= 0) return 0;
   hipLaunchKernelGGL(k_wall_bbl_slip, dim3(nblk), dim3(WALL_BLOCK), 0, st, *kp,
 		     *tab, f, nlink, linki, linkj, linkp, linkk, linkq, links,
-		     status, part);
+		     status, part, err);
   hipLaunchKernelGGL(k_wall_fnet, dim3(1), dim3(64), 0, st, nblk, part, fnet);
   return (int) hipGetLastError();
 }

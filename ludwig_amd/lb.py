@@ -385,6 +385,50 @@ class LB:
             self._h, *[a.ctypes.data_as(ctypes.c_void_p) for a in arr]))
         return tuple(a[:self.nlink] for a in arr)
 
+    def wall_links_set(self, linki, linkj, linkp, linku):
+        """Links made by the caller (host arrays, wall.c:399-451): checked
+        record by record on the host, copied, owned by the handle."""
+        arr = [np.ascontiguousarray(a, dtype=np.int32)
+               for a in (linki, linkj, linkp, linku)]
+        n = len(arr[0])
+        assert all(len(a) == n for a in arr)
+        _l.check(self._lib.lbmi_wall_links_set(
+            self._h, n, *[a.ctypes.data_as(ctypes.c_void_p) for a in arr]))
+        self.nlink = n
+
+    def wall_slip_links_set(self, linkk, linkq, links, stab):
+        """Slip records made by the caller, in the reference's types (int,
+        int8, int8) and its table of 19 fractions."""
+        k = np.ascontiguousarray(linkk, dtype=np.int32)
+        q = np.ascontiguousarray(linkq, dtype=np.int8)
+        s = np.ascontiguousarray(links, dtype=np.int8)
+        assert len(k) == len(q) == len(s) == self.nlink
+        t = (ctypes.c_double * 19)(*[float(x) for x in stab])
+        _l.check(self._lib.lbmi_wall_slip_links_set(
+            self._h, k.ctypes.data_as(ctypes.c_void_p),
+            q.ctypes.data_as(ctypes.c_void_p),
+            s.ctypes.data_as(ctypes.c_void_p), t))
+
+    def wall_fnet_bind(self, fnet):
+        """Momentum of lbmi_wall_bbl into 3 doubles on the device owned by
+        the caller (None: the handle's accumulator)."""
+        self._wall_fnet = fnet
+        _l.check(self._lib.lbmi_wall_fnet_bind(
+            self._h, None if fnet is None else _ptr(fnet)))
+
+    def wall_bbl_arrays(self, linki, linkj, linkp, linku, ubot, utop, fnet):
+        """wall_bbl on DEVICE link arrays the caller owns (int32 tensors)."""
+        ub = (ctypes.c_double * 3)(*[float(x) for x in ubot])
+        ut = (ctypes.c_double * 3)(*[float(x) for x in utop])
+        _l.check(self._lib.lbmi_wall_bbl_arrays(
+            self._h, int(linki.numel()), _ptr(linki), _ptr(linkj), _ptr(linkp),
+            _ptr(linku), ub, ut, _ptr(fnet)))
+
+    def mode_set(self, mode):
+        """lbmi_lb_mode_set: flush, then continue in another execution mode."""
+        _l.check(self._lib.lbmi_lb_mode_set(self._h, int(mode)))
+        self.mode = int(mode)
+
     def wall_velocity_set(self, ubot, utop):
         ub = (ctypes.c_double * 3)(*[float(x) for x in ubot])
         ut = (ctypes.c_double * 3)(*[float(x) for x in utop])

@@ -85,6 +85,7 @@ SYMBOLS = [
     ("lbmi_lb_halo", _i, [_vp]),
     ("lbmi_lb_propagation", _i, [_vp]),
     ("lbmi_lb_flush", _i, [_vp]),
+    ("lbmi_lb_mode_set", _i, [_vp, _i]),
     ("lbmi_lb_run", _i, [_vp, ctypes.POINTER(HydroPtrs), _i]),
     ("lbmi_lb_state", _i, [_vp, ctypes.POINTER(_i)]),
     ("lbmi_wall_map", _i, [_vp, ctypes.POINTER(_i), _vp]),
@@ -95,6 +96,9 @@ SYMBOLS = [
     ("lbmi_wall_bbl", _i, [_vp]),
     ("lbmi_wall_bbl_arrays", _i, [_vp, _i, _vp, _vp, _vp, _vp, _pd, _pd, _vp]),
     ("lbmi_wall_momentum", _i, [_vp, _pd]),
+    ("lbmi_wall_links_set", _i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    ("lbmi_wall_fnet_bind", _i, [_vp, _vp]),
+    ("lbmi_wall_slip_links_set", _i, [_vp, _vp, _vp, _vp, _pd]),
     ("lbmi_wall_status_set", _i, [_vp, _vp]),
     ("lbmi_wall_slip_set", _i, [_vp, _vp, _pd, _pd]),
     ("lbmi_wall_slip_links", _i, [_vp, _vp, _vp, _vp]),

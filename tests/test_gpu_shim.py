@@ -182,17 +182,33 @@ INPUTS = os.path.join(HERE, "golden", "inputs")
 
 
 def _ludwig(inp, mode, shim=True):
+    """Run the reference's executable on an input of tests/golden/inputs.
+    mode = None leaves LBMI_MODE unset (the binding's default). Whatever the
+    child wrote is kept when it fails (a GPU fault must leave evidence): in
+    gpurun_out/ (merged back from the GPU box) and in the assertion message."""
     exe = os.path.join(REF, "ludwig_hip_d3q19" + ("_shim" if shim else ""))
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/%s not built (make -C oracle hip)" % os.path.basename(exe))
-    env = dict(os.environ, LBMI_MODE=mode)
+    env = dict(os.environ)
+    env.pop("LBMI_MODE", None)
+    if mode is not None:
+        env["LBMI_MODE"] = mode
     import shutil
     with tempfile.TemporaryDirectory() as tmp:
         # main.c: the input file is "input" in the working directory
         shutil.copy(os.path.join(INPUTS, inp), os.path.join(tmp, "input"))
-        r = _sp.run([exe], cwd=tmp, env=env, check=True,
-                    capture_output=True, text=True, timeout=600)
-    assert "Ludwig finished normally." in r.stdout
+        r = _sp.run([exe], cwd=tmp, env=env, capture_output=True, text=True,
+                    timeout=600)
+    if r.returncode != 0 or "Ludwig finished normally." not in r.stdout:
+        tail = "exit code %d\n--- stdout (tail) ---\n%s\n--- stderr (tail) ---\n%s" % (
+            r.returncode, r.stdout[-3000:], r.stderr[-3000:])
+        keep = os.path.join(HERE, "..", "gpurun_out")
+        os.makedirs(keep, exist_ok=True)
+        if os.path.isdir(keep):
+            with open(os.path.join(keep, "ludwig_failed_%s_%s.log" % (inp, mode)), "w") as fh:
+                fh.write("exit code %d\n--- stdout ---\n%s\n--- stderr ---\n%s"
+                         % (r.returncode, r.stdout, r.stderr))
+        pytest.fail("%s (LBMI_MODE=%s) did not finish: %s" % (inp, mode, tail))
     return r.stdout
 
 
@@ -279,19 +295,22 @@ def test_ludwig_application_more_regressions(name, mode):
             assert abs(a - b) <= 2e-7 * abs(b) + 1e-16
 
 
-@pytest.mark.skip(reason="OPEN ISSUE (DESIGN.md, section 8): passed in both modes when run alone, but one run "
-                         "inside the full suite ended with 'Memory access fault by GPU' in halo mode, at an address "
-                         "just past a buffer of the size of f. A fault is not something to provoke again: the cause "
-                         "has to be found by reading first; until then this case does not run.")
-@pytest.mark.parametrize("mode", ["eager", "halo"])
+@pytest.mark.parametrize("mode", ["eager", "halo", None, "fused"])
 def test_ludwig_duct_flow_between_walls(mode):
     """serial-rect-ct1: a 1 x 62 x 30 duct with walls in y and z, driven by a
-    body force, 100 steps: lb_collide, lb_halo, wall_bbl (on the reference's
-    link arrays, momentum into wall->target->fnet) and lb_propagation through
-    the binding; fluid and wall momentum and the velocity extrema of the
-    reference's log."""
+    body force, 100 steps: lb_collide, lb_halo, wall_bbl (on copies of the
+    reference's host link arrays, momentum into wall->target->fnet) and
+    lb_propagation through the binding, the reference's own
+    wall_set_wall_distributions in between; fluid and wall momentum and the
+    velocity extrema of the reference's log. None: LBMI_MODE unset (= halo).
+    fused: the binding notices the wall links at the first
+    wall_set_wall_distributions and continues in halo mode.
+    (Round 1 skipped this case after one GPU memory fault; the cause --
+    lb->target->param never uploaded, so wall_setu_kernel wrote in front of
+    f -- is in DESIGN.md section 8 and tests/test_duct_fault_replay.py.)"""
     ref = _json.load(open(os.path.join(HERE, "golden", "regression_app_extra.json")))["rect_ct1"]
     log = _ludwig("rect_ct1.inp", mode)
+    assert ("LBMI_MODE=fused -> halo" in log) == (mode == "fused")
     rho = _last(log, "[rho]")
     assert rho[0] == ref["rho"][0]
     assert abs(rho[3] - ref["rho"][3]) < 2e-11 and abs(rho[4] - ref["rho"][4]) < 2e-11

@@ -367,3 +367,136 @@ def test_slip_channel_flow(s):
         assert np.allclose(ux, ux[::-1], rtol=0, atol=1e-12)
     assert abs(lb.moments()[1] - n[0] * n[1] * n[2]) < 1e-9
     lb.free()
+
+
+# --- links made by the caller: checked before a kernel can see them -------------
+
+@pytest.mark.parametrize("mode", [0, 3], ids=["eager", "fused_halo"])
+@pytest.mark.parametrize("name", golden_wall_names())
+def test_links_set_from_host_arrays(name, mode):
+    """lbmi_wall_links_set with the reference's host link arrays (what the
+    binding passes: wall->linki, linkj, linkp, linku) and the momentum into an
+    accumulator the caller owns: the steps of the fixture."""
+    import torch
+    g = load_golden(name)
+    lb, hy, meta = _setup(g, mode)
+    lb.wall_map(meta["isboundary"], hy.status)
+    lb.wall_links_set(g["linki"], g["linkj"], g["linkp"], g["linku"])
+    assert lb.nlink == meta["nlink"]
+    fnet = torch.zeros(3, dtype=torch.float64, device=hy.status.device)
+    lb.wall_fnet_bind(fnet)
+    lb.wall_velocity_set(meta["ubot"], meta["utop"])
+    if meta["solid"] == 2:
+        _mark_colloids(lb, hy, g)
+    lb.lb_memcpy_h2d(g["f0"])
+    for n in range(meta["nsteps"]):
+        lb.lb_collide(hy)
+        lb.lb_halo()
+        lb.wall_bbl()
+        lb.lb_propagation()
+    f = lb.lb_memcpy_d2h()
+    fl = (g["status"] == 0)[1:-1, 1:-1, 1:-1]
+    assert relmax(interior(f, 1)[:, fl], interior(g["f_final"], 1)[:, fl]) < 1e-12
+    ref = np.array(meta["fnet"])
+    assert np.max(np.abs(fnet.cpu().numpy() - ref)) < 1e-12 * max(1.0, np.abs(ref).max())
+    assert np.all(lb.wall_momentum() == 0.0)        # nothing went to the handle's own
+    lb.free()
+
+
+def test_links_set_refuses_bad_records():
+    """A record that is not a link of this lattice never reaches the device:
+    p = 0 (the all-zero record of an array that was never filled), p = nvel,
+    sites outside the array, j != i + c_p, a wall-velocity id out of range."""
+    import ludwig_amd
+    from ludwig_amd.lib import LbmiError
+    g = load_golden("wall_q19_x")
+    lb, hy, meta = _setup(g)
+    li, lj, lp, lu = (g[k].copy() for k in ("linki", "linkj", "linkp", "linku"))
+    nsite = int(np.prod(lb.nall))
+    n = len(li) // 2
+    for what, arr, val in (("p = 0", lp, 0), ("p = nvel", lp, meta["nvel"]),
+                           ("i < 0", li, -1), ("i = nsite", li, nsite),
+                           ("j elsewhere", lj, int(lj[n]) + 1), ("u = 3", lu, 3)):
+        keep = arr[n]
+        arr[n] = val
+        with pytest.raises(LbmiError, match="link %d" % n):
+            lb.wall_links_set(li, lj, lp, lu)
+        arr[n] = keep
+    lb.wall_links_set(np.zeros(0, np.int32), np.zeros(0, np.int32),
+                      np.zeros(0, np.int32), np.zeros(0, np.int32))
+    lb.wall_links_set(li, lj, lp, lu)                 # and the intact set is taken
+    assert lb.nlink == len(li)
+    lb.free()
+
+
+def test_foreign_device_arrays_are_range_checked():
+    """lbmi_wall_bbl_arrays on device arrays the caller owns: the kernel skips
+    a record that would address outside f -- the all-zero record would touch
+    f[nsite*nvel], one element past the end -- and the call that first sees
+    the arrays reports it; the other links are bounced as usual."""
+    import torch
+    from ludwig_amd.lib import LbmiError
+    g = load_golden("wall_q19_x")
+    lb, hy, meta = _setup(g)
+    nv = meta["nvel"]
+    lb.wall_map(meta["isboundary"], hy.status)
+    lb.lb_memcpy_h2d(g["f0"])
+    lb.lb_collide(hy)
+    lb.lb_halo()
+    dev = hy.status.device
+    bad = len(g["linki"]) // 3
+    arrs = []
+    for k in ("linki", "linkj", "linkp", "linku"):
+        a = g[k].astype(np.int32).copy()
+        a[bad] = 0
+        arrs.append(torch.tensor(a, device=dev))
+    fnet = torch.zeros(3, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    with pytest.raises(LbmiError, match="link record %d" % bad):
+        lb.wall_bbl_arrays(*arrs, meta["ubot"], meta["utop"], fnet)
+    f = lb.lb_memcpy_d2h().reshape(nv, -1)
+    ref = g["f_bbl"].reshape(nv, -1)
+    ok = np.arange(len(g["linki"])) != bad
+    q, j = (nv - g["linkp"])[ok], g["linkj"][ok]
+    assert np.max(np.abs(f[q, j] - ref[q, j])) < 1e-15
+    # the same arrays again, repaired in place: accepted without a new check
+    arrs[2][bad] = int(g["linkp"][bad])
+    arrs[0][bad] = int(g["linki"][bad])
+    arrs[1][bad] = int(g["linkj"][bad])
+    torch.cuda.synchronize()
+    lb.wall_bbl_arrays(*arrs, meta["ubot"], meta["utop"], fnet)
+    lb.synchronize()
+    lb.free()
+
+
+def test_mode_set_at_every_call_point():
+    """lbmi_lb_mode_set between any two calls of a step: the run continues in
+    the new mode from the state the reference holds there (what the binding
+    does when a run in LBMI_MODE=fused turns out to have wall links)."""
+    import ludwig_amd
+    nvel, nlocal = 19, (6, 5, 7)
+    p = lbo.make_param(nvel, nlocal, 1, "m10", 0.1, 0.3, 1.0, (1e-6, 2e-6, 0.0))
+    f0 = lbo.init_synthetic(p)
+    f, fp = f0.copy(), np.zeros_like(f0)
+    for _ in range(4):
+        f, fp = lbo.step(p, f, fp)
+    for point in range(3):
+        for first, then in ((1, 3), (3, 0), (2, 1), (0, 1)):
+            lb = ludwig_amd.LB(nvel, nlocal, 1, mode=first)
+            lb.relaxation_set("m10", 0.1, 0.3)
+            lb.body_force_set((1e-6, 2e-6, 0.0))
+            hy = ludwig_amd.Hydro(lb.nall, lb.device)
+            lb.lb_memcpy_h2d(f0)
+            for n in range(4):
+                lb.lb_collide(hy)
+                if n == 2 and point == 0:
+                    lb.mode_set(then)
+                lb.lb_halo()
+                if n == 2 and point == 1:
+                    lb.mode_set(then)
+                lb.lb_propagation()
+                if n == 2 and point == 2:
+                    lb.mode_set(then)
+            out = lb.lb_memcpy_d2h()
+            assert relmax(interior(out, 1), interior(f, 1)) < 1e-12, (point, first, then)
+            lb.free()
