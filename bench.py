@@ -12,15 +12,28 @@ FUSED mode the three calls execute as ONE kernel (pull-propagation with
 periodic index wrap + collision); --mode eager runs the reference's three
 separate stages. Inputs are resident in HBM before the timed region.
 
-N > 1: strong scaling, the 256^3 box is cut into N slabs along X (the
-reference's `grid N_1_1`), X halo planes travel over RCCL (ncclSend/ncclRecv)
-on a second stream overlapped with the interior planes.
+The hydro arrays lb_collide borrows (force, rho, u) are there in every
+default run. --hydro lazy (default): the force field has been zeroed through
+the library (hydro_f_zero), which therefore does not read it, and rho, u of
+the last collision are formed when asked for (lbmi_lb_hydro_sync, INSIDE the
+timed region, once, as a run that prints statistics at its end would);
+--hydro 1: read and stored by every collision, as the reference does. The
+second is also measured in every default run, after the timed region, and
+reported under "hydro_every_step".
 
-Prints ONE JSON line on rank 0. At N = 1 it carries, beside "roofline"
-(HIP events around the sampled launches of the step's kernel), two reported
-comparators measured after the timed region: "cpu_baseline" (the reference's
-CPU build, oracle/_ref, on this host's cores) and "reference_gpu" (the
-reference's own HIP back end, oracle/_ref/ref_driver_hip_*, on this GPU).
+N > 1: `python bench.py --gpus N` starts its own N ranks (torch.distributed.run
+on 127.0.0.1, before anything touches a GPU); under an existing launcher it
+just takes its rank. Strong scaling by default: the 256^3 box is cut into N
+slabs along X (the reference's `grid N_1_1`), X halo planes travel over RCCL
+(ncclSend/ncclRecv) on a second stream overlapped with the interior planes.
+--config 5 is the weak-scaling D3Q27 case (64x512x256 per GPU).
+
+Prints ONE JSON line on rank 0. "roofline" follows SURVEY.md 8(d): achieved =
+2*Q*8 bytes per lattice update (304 B for D3Q19) over the average launch time
+of the step's kernel (HIP events around sampled launches, on the library's
+stream). At N = 1 two reported comparators are measured after the timed
+region: "cpu_baseline" (the reference's CPU build, oracle/_ref, on this host's
+cores) and "reference_gpu" (the reference's own HIP back end on this GPU).
 """
 
 import argparse
@@ -60,9 +73,19 @@ def parse():
                     help="fused (default): on one GPU the deferred state is "
                     "kept in the block-contiguous order; fused_soa: in the "
                     "reference's SoA order")
-    ap.add_argument("--hydro", type=int, default=1,
-                    help="1: lb_collide reads hydro->force and writes "
-                    "hydro->rho,u as the reference does; 0: NULL hydro arrays")
+    ap.add_argument("--hydro", default="lazy", choices=["lazy", "1", "0"],
+                    help="lazy: hydro arrays present, force zeroed through "
+                    "the library (not read), rho,u on demand; 1: lb_collide "
+                    "reads hydro->force and writes hydro->rho,u every step "
+                    "as the reference does; 0: NULL hydro arrays")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+                    help="a BASELINE.json configuration (1-based): 1 = D3Q19 "
+                    "BGK 64^3; 2, 3 = D3Q19 M10 256^3 (the default; 3 with "
+                    "--gpus 8); 4 = D3Q19 + symmetric free energy 128^3; "
+                    "5 = D3Q27 M10 64x512x256 per GPU, weak scaling")
+    ap.add_argument("--dry-run", type=int, default=0,
+                    help="1: ranks, decomposition and the X exchange schedule "
+                    "only (gloo on the CPU, no device call)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="weak: --size is the per-GPU box, stacked along X")
     ap.add_argument("--nhalo", type=int, default=1)
@@ -88,15 +111,47 @@ def parse():
                     "ring (exercises the N>1 step path: pack, send/recv, "
                     "unpack, interior/boundary split)")
     ap.add_argument("--tune", default="", help="key=value,... (lbmi_tune)")
-    ap.add_argument("--timing-period", type=int, default=8,
+    ap.add_argument("--timing-period", type=int, default=0,
                     help="HIP-event timing of every k-th kernel launch inside "
-                    "the timed region (1 = all)")
+                    "the timed region (1 = all; 0 = about 25 samples)")
     ap.add_argument("--own-stream", type=int, default=0,
                     help="1: the library's private non-blocking stream "
                     "instead of torch's current (the legacy default) stream")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=8)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config == 1:
+        args.size, args.scheme = [64, 64, 64], "bgk"
+    if args.config == 4:
+        args.size, args.fe, args.nhalo, args.hydro = [128, 128, 128], "symmetric", 2, "1"
+    if args.config == 5:
+        args.size, args.nvel, args.scaling = [64, 512, 256], 27, "weak"
+    if args.fe != "none" and args.hydro != "1":
+        args.hydro = "1"             # u is read by every step of the free-energy pass
+    if args.timing_period <= 0:
+        args.timing_period = max(1, min(8, args.steps // 24))
+    return args
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell: start N ranks under
+    torch.distributed.run on the loopback interface and pass their one JSON
+    line on. Called before torch is imported, so this process never touches a
+    GPU; the ranks are children, not replacements of it."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write(r.stdout)
+        raise SystemExit(r.returncode or 1)
+    return lines[-1]
 
 
 def cpu_baseline(args):
@@ -177,6 +232,15 @@ def reference_gpu(args):
             "ms_per_step": round(1e3 * r["t_total"] / r["steps"], 4)}
 
 
+def kernel_source_sha1():
+    import hashlib
+    h = hashlib.sha1()
+    for name in ("lbmi_kernels.hip", "lbmi_kernels.h"):
+        with open(os.path.join(ROOT, "ludwig_amd", "csrc", name), "rb") as fp:
+            h.update(fp.read())
+    return h.hexdigest()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -184,9 +248,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with "
-                             "torch.distributed.run" % args.gpus)
+            return self_launch(args)
         args.gpus = world
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
     import numpy as np
     import torch
@@ -238,10 +303,22 @@ def main():
     synthetic.fill_device(lb, m["cv"], m["wv"], ntotal,
                           xrange=(dec.noffset[0], dec.noffset[0] + dec.nlocal[0]))
     hydro = None
-    if args.hydro:
+    lazy = (args.hydro == "lazy")
+    if args.hydro != "0":
         hydro = ludwig_amd.Hydro(lb.nall, lb.device)
-        hydro.force = torch.zeros((3,) + lb.nall, dtype=torch.float64,
-                                  device=lb.device)   # hydro_f_zero
+        hydro.force = torch.empty((3,) + lb.nall, dtype=torch.float64,
+                                  device=lb.device)
+        torch.cuda.synchronize()
+        # hydro_f_zero (ludwig.c:537) through the C-ABI, as the binding does:
+        # the library then knows the array holds zeros
+        lb.hydro_field_set(hydro.force, (0.0, 0.0, 0.0))
+        lb.synchronize()
+        if lazy:
+            lb.tune("hydro_lazy", 1)
+        if args.force_field or not lazy:
+            # read by every collision: a per-site force field, or --hydro 1
+            # (the reference reads hydro->force whatever it holds)
+            lb.hydro_field_dirty(hydro.force)
         if args.force_field:
             # stands in for the thermodynamic force of config 4
             h = args.nhalo
@@ -349,6 +426,10 @@ def main():
         # the three calls of every step issued by the C loop of the library
         # (lbmi_lb_run), as ludwig.c issues them, not one by one from Python
         lb.run(hydro, args.steps)
+        if lazy:
+            # rho, u of the last collision, as a run that reports statistics
+            # at its end would ask for them: once, inside the timed region
+            lb.hydro_sync()
     else:
         for _ in range(args.steps):
             one_step()
@@ -370,57 +451,89 @@ def main():
 
     sites = ntotal[0] * ntotal[1] * ntotal[2]
     mlups = 1e-6 * sites * args.steps / dt
+    local_sites = dec.nlocal[0] * dec.nlocal[1] * dec.nlocal[2]
+    pop_bytes = 2 * args.nvel * 8
+
+    # After the timed region: the same loop with the hydro arrays read and
+    # written by EVERY collision (what the reference's lb_collide does,
+    # collision.c:329-333, 563-596): +24 B/site read, +32 B/site written.
+    every = None
+    if lazy and world == 1 and fe is None and not args.selfring:
+        lb.tune("hydro_lazy", 0)
+        lb.hydro_field_dirty(hydro.force)
+        nextra = max(10, min(40, args.steps))
+        for _ in range(3):
+            one_step()                   # past the flush of the moments
+        lb.synchronize()
+        lb.timing(1)
+        t1 = time.perf_counter()
+        lb.run(hydro, nextra)
+        lb.synchronize()
+        dt1 = time.perf_counter() - t1
+        kms1, nl1 = lb.timing_read()
+        lb.timing(False)
+        every = {
+            "value": round(1e-6 * sites * nextra / dt1, 1), "unit": "MLUPS",
+            "steps": nextra, "ms_per_step": round(1e3 * dt1 / nextra, 5),
+            "bytes_per_lup": pop_bytes + 56,
+            "avg_launch_ms": round(kms1 / max(nl1, 1), 5),
+            "achieved_GBs": round(1e-9 * (pop_bytes + 56) * local_sites
+                                  / (1e-3 * kms1 / max(nl1, 1)), 1),
+            "populations_only_GBs": round(1e-9 * pop_bytes * local_sites
+                                          / (1e-3 * kms1 / max(nl1, 1)), 1),
+        }
 
     if rank == 0:
         # Algorithmic bytes per lattice update: one read and
-        # one write of every population, 2*Q*8 B; with hydro I/O (what
-        # lb_collide does in the reference: read force[3], write rho, u[3])
-        # +24 B +32 B. The figure used is the one of the kernel as run.
-        pop_bytes = 2 * args.nvel * 8
-        algo_bytes = pop_bytes + (56 if args.hydro else 0)
-        local_sites = dec.nlocal[0] * dec.nlocal[1] * dec.nlocal[2]
+        # one write of every population, 2*Q*8 B = 304 (D3Q19) / 432 (D3Q27):
+        # THE figure of roofline.achieved and roofline.frac, whatever else the
+        # kernel moves. With --hydro 1 the force read and the rho, u stores
+        # (+56 B) are real traffic too: reported beside it, never in frac.
         roofline = None
         if nlaunch > 0 and args.mode in ("fused", "inplace", "fused_soa", "fused_halo"):
             t_launch = 1e-3 * kms / nlaunch
-            achieved = 1e-9 * algo_bytes * local_sites / t_launch
+            achieved = 1e-9 * pop_bytes * local_sites / t_launch
             roofline = {
                 "bound": "hbm", "kernel": "k_propagate_collide",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,
-                "bytes_per_lup": algo_bytes,
+                "bytes_per_lup": pop_bytes,
                 "lups_per_launch": local_sites,
                 "avg_launch_ms": round(1e3 * t_launch, 5),
                 "launches": nlaunch,
                 "launches_sampled": "every %d-th of %d" % (args.timing_period,
                                                           args.steps),
-                "achieved_populations_only": round(
-                    1e-9 * pop_bytes * local_sites / t_launch, 1),
             }
+            if args.hydro == "1":
+                roofline["achieved_with_hydro_io"] = round(
+                    1e-9 * (pop_bytes + 56) * local_sites / t_launch, 1)
+                roofline["bytes_per_lup_with_hydro_io"] = pop_bytes + 56
             # HBM bytes per launch from the PMC counters cannot be collected
             # inside this process (they need their own rocprofv3 --pmc
-            # passes): quote the committed measurement of the same kernel
-            # on the same workload, if this run is that workload
-            pmc = os.path.join(ROOT, "profiles",
-                               "r01_default_pmc_hbm_traffic.json"
-                               if order.startswith("blocked")
-                               else "r01_pmc_hbm_traffic.json")
+            # passes): quote the committed measurement of this command
+            # (tools/profile_bench.sh + tools/pmc_summary.py), and only while
+            # the kernel source it was taken with is the one that runs now
+            pmc = os.path.join(ROOT, "profiles", "r02_default_pmc_hbm_traffic.json")
             same = (args.nvel == 19 and tuple(args.size) == (256, 256, 256)
-                    and args.hydro and world == 1
-                    and args.mode in ("fused", "fused_soa")
-                    and args.scheme == "m10" and args.fe == "none")
+                    and lazy and world == 1 and args.mode == "fused"
+                    and args.scheme == "m10" and args.fe == "none"
+                    and not args.selfring and not args.tune)
             if same and os.path.exists(pmc):
                 with open(pmc) as fp:
                     t = json.load(fp)["summary"]
-                roofline["traffic"] = int(t["traffic_bytes"])
-                roofline["traffic_unit"] = "bytes per launch"
-                roofline["traffic_source"] = (
-                    "profiles/%s: separate rocprofv3 "
-                    "--pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                    "FETCH_SIZE x2 (gfx950); algorithmic = %d"
-                    % (os.path.basename(pmc),
-                       t.get("algorithmic_bytes",
-                             t.get("algorithmic_bytes_360_per_lup"))))
+                if t.get("kernel_source_sha1") == kernel_source_sha1():
+                    roofline["traffic"] = int(t["traffic_bytes"])
+                    roofline["traffic_unit"] = "bytes per launch"
+                    roofline["traffic_source"] = (
+                        "profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / "
+                        "WRITE_SIZE passes of this command, FETCH_SIZE x2 "
+                        "(gfx950); algorithmic = %d"
+                        % (os.path.basename(pmc), t["algorithmic_bytes"]))
+                else:
+                    roofline["traffic_source"] = (
+                        "profiles/%s was taken with another kernel source: "
+                        "not quoted" % os.path.basename(pmc))
         out = {
             "metric": "MLUPS (million lattice updates/sec) D3Q%d %dx%dx%d"
                       % (args.nvel, *ntotal),
@@ -442,7 +555,11 @@ def main():
                             % (args.nvel, args.scheme.upper(), *ntotal),
                 "mode": args.mode,
                 "order": order,
-                "hydro_io": bool(args.hydro),
+                                "hydro_io": {"lazy": "arrays present; force zeroed through the "
+                             "library (not read); rho,u formed on demand, once, "
+                             "inside the timed region",
+                             "1": "force read and rho,u stored by every collision",
+                             "0": "no hydro arrays"}[args.hydro],
                 "free_energy": args.fe if args.fe == "none" else
                 "%s (%d-point gradients, advection order %d, from %s%s)"
                 % (args.fe, args.fe_grad, args.fe_order, args.fe_route,
@@ -452,7 +569,8 @@ def main():
                                  + (" (1-rank RCCL ring)" if args.selfring else ""),
                 "halo": "index wrap (1 GPU); reduced X planes over RCCL (N>1)",
             },
-            "roofline": roofline,
+                        "roofline": roofline,
+            "hydro_every_step": every,
             "check": {
                 "mass_drift_rel": float(abs(mom1[0] - mom0[0]) / mom0[0]),
                 "momentum_drift_abs": float(np.max(np.abs(mom1[1:] - mom0[1:]))),

@@ -395,12 +395,40 @@ int lbmi_lb_memcpy_h2d(lbmi_t * lb, const double * f_host);
 int lbmi_lb_memcpy_d2h(lbmi_t * lb, double * f_host);
 int lbmi_lb_moments(lbmi_t * lb, const char * status, double out[9]);
 
+/* hydro->rho and hydro->u on demand (lbmi_tune "hydro_lazy", 1; FUSED and
+ * FUSED_HALO): lbmi_lb_collide then does not store them (32 B/site per step)
+ * but remembers the arrays it was given, and lbmi_lb_hydro_sync -- or
+ * anything in this library that reads u or is about to change the
+ * post-collision state: lbmi_lb_flush and what calls it, a propagation that
+ * runs at once, lbmi_lb_memcpy_h2d, the free-energy calls given that u --
+ * forms them from the post-collision distributions: rho = sum f'_p,
+ * u = (sum f'_p c_p - F/2)/rho, the values the collision used (collision.c:
+ * 376-382) to rounding. The next lbmi_lb_collide supersedes what is still
+ * owed, exactly as it would overwrite the arrays. The arrays of the last
+ * collision (rho, u, force, status) must stay valid, and the force unchanged
+ * by others, until then. Readers of rho / u outside this library call
+ * lbmi_lb_hydro_sync first (the binding: INTEGRATION.md). */
+int lbmi_lb_hydro_sync(lbmi_t * lb);
+int lbmi_hydro_field_dirty(lbmi_t * lb, const double * field);
+
 /* ---- rows "next" of the scope table ----------------------- */
 
 /* hydro_u_zero / hydro_f_zero / hydro_rho0 (hydro.c:279-370, kernel
  * hydro_field_set): every site (halo included) of an SoA device field of
  * ncomp = 1..3 components is set to values[]. hydro_u_halo (hydro.c:190)
- * is lbmi_field_halo(lb, 3, u). */
+ * is lbmi_field_halo(lb, 3, u).
+ *
+ * An array set to zeros here is remembered as holding zeros until a call of
+ * this library writes to it (a collision its rho / u, the free-energy calls
+ * their force) or the caller reports a write of its own with
+ * lbmi_hydro_field_dirty. While it is: setting it to zeros again launches
+ * nothing, and lbmi_lb_collide given it as hydro->force does not read it
+ * (F = the body force, bit for bit what the reference computes from
+ * force_global + 0, collision.c:329-333). In the reference's single-fluid
+ * step that is hydro_f_zero every step (ludwig.c:537) on a field nobody
+ * writes to: 24 B/site written and 24 B/site read per step, gone.
+ * ANY writer of such an array outside this library must call
+ * lbmi_hydro_field_dirty before the next lbmi_lb_collide. */
 int lbmi_hydro_field_set(lbmi_t * lb, double * field, int ncomp,
 			 const double * values);
 
@@ -552,6 +580,8 @@ int lbmi_timing_read(lbmi_t * lb, double * ms_total, int * nlaunch);
  * "x_concurrent": 1 = slabs: the two boundary planes run on a third stream
  *            beside the interior launch once the halo has arrived (default),
  *            0 = after it on the compute stream;
+  * "hydro_lazy": 1 = lbmi_lb_collide leaves hydro->rho, u to lbmi_lb_hydro_sync
+ *            (see there), 0 = stored by every collision (default);
  * "graph":   1 = lbmi_lb_run on one GPU in FUSED mode issues its steps as
  *            launches of ONE hipGraph holding two steady-state steps (for
  *            lattices whose step is as short as a launch), 0 = step by step

@@ -64,6 +64,14 @@ struct lbmi_s {
 					the blocked order (lbmi_tune "blocked") */
   int blocked;                       /* f is in the blocked order right now */
 
+    /* hydro arrays: what is known to hold zeros (lbmi_hydro_field_set), and
+   * rho, u of the last collision owed to the caller (lbmi_tune "hydro_lazy") */
+  const void * known_zero[4];
+  int hydro_lazy;
+  int hydro_stale;
+  lbmi_hydro_dev_t lazy_h;
+  double lazy_fbody[3];
+
   /* moments workspace */
   double * mom_work;
   double * mom_out;
@@ -551,6 +559,86 @@ static lbmi_hydro_dev_t lbmi_hydro_dev(const lbmi_hydro_t * hydro) {
   return h;
 }
 
+/* Arrays known to hold zeros everywhere: set by lbmi_hydro_field_set with
+ * zero values, dropped when something of this library writes to the array
+ * or the caller says so (lbmi_hydro_field_dirty). A force array on the list
+ * is not read by the collision, and zeroing it again is not a launch. */
+
+static int lbmi_known_zero(const lbmi_t * lb, const void * p) {
+  if (p == NULL) return 0;
+  for (int n = 0; n < 4; n++) {
+    if (lb->known_zero[n] == p) return 1;
+  }
+  return 0;
+}
+
+static void lbmi_known_zero_drop(lbmi_t * lb, const void * p) {
+  for (int n = 0; n < 4; n++) {
+    if (p != NULL && lb->known_zero[n] == p) lb->known_zero[n] = NULL;
+  }
+}
+
+static void lbmi_known_zero_add(lbmi_t * lb, const void * p) {
+  if (lbmi_known_zero(lb, p)) return;
+  for (int n = 0; n < 4; n++) {
+    if (lb->known_zero[n] == NULL) {
+      lb->known_zero[n] = p;
+      return;
+    }
+  }
+  lb->known_zero[0] = p;             /* full: forget the oldest entry */
+}
+
+/* hydro_lazy: the rho and u a collision would have stored are formed from the
+ * post-collision state it left, when somebody wants them (lbmi_lb_hydro_sync,
+ * or anything that is about to change that state: a flush, a propagation
+ * that runs at once, a copy into f). The next collision supersedes them. */
+
+static int lbmi_hydro_materialise(lbmi_t * lb) {
+  if (!lb->hydro_stale) return 0;
+  lb->hydro_stale = 0;
+  if (lb->f == NULL) return 0;
+  {
+    lbmi_kparam_t kp = lb->kp;
+    for (int ia = 0; ia < 3; ia++) kp.fbody[ia] = lb->lazy_fbody[ia];
+    KCHECK(lbmi_k_hydro_from_f(&kp, lb->f, &lb->lazy_h, lb->blocked, lb->stream));
+  }
+  lbmi_known_zero_drop(lb, lb->lazy_h.rho);
+  lbmi_known_zero_drop(lb, lb->lazy_h.u);
+  return 0;
+}
+
+/* A call of this library is about to read `reads` (u, rho) or overwrite
+ * `writes` (the force): what a lazy collision still owes must exist first --
+ * u for the reader, and for the writer because the owed u is formed with the
+ * force the collision used. A force array that gets written is no longer
+ * known to be zero. */
+
+static int lbmi_hydro_touch(lbmi_t * lb, const double * reads,
+			    const double * writes) {
+  if (lb->hydro_stale &&
+      ((reads != NULL && (reads == lb->lazy_h.u || reads == lb->lazy_h.rho)) ||
+       (writes != NULL && (writes == lb->lazy_h.force ||
+			   writes == lb->lazy_h.u || writes == lb->lazy_h.rho)))) {
+    int ifail = lbmi_hydro_materialise(lb);
+    if (ifail) return ifail;
+  }
+  lbmi_known_zero_drop(lb, writes);
+  return 0;
+}
+
+int lbmi_lb_hydro_sync(lbmi_t * lb) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  HIPCHECK(hipSetDevice(lb->device));
+  return lbmi_hydro_materialise(lb);
+}
+
+int lbmi_hydro_field_dirty(lbmi_t * lb, const double * field) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  lbmi_known_zero_drop(lb, field);
+  return 0;
+}
+
 /* Event-pair timing of a kernel launch on the compute stream */
 
 static int lbmi_time_begin(lbmi_t * lb) {
@@ -634,6 +722,14 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
   }
   if (strcmp(key, "nt_store") == 0) {
     lb->nt_store_mode = (value < 0) ? -1 : (value & 3);   /* bit 0: f, bit 1: rho, u */
+    return 0;
+  }
+    if (strcmp(key, "hydro_lazy") == 0) {
+    if (!value) {
+      int ifail = lbmi_hydro_materialise(lb);
+      if (ifail) return ifail;
+    }
+    lb->hydro_lazy = (value != 0);
     return 0;
   }
   if (strcmp(key, "fe_tiled") == 0) {
@@ -923,8 +1019,9 @@ int lbmi_lb_bind(lbmi_t * lb, double * f, double * fprime) {
     hipFree(lb->fprime);
     lb->owns_f = 0;
   }
-  lb->f = NULL;
+    lb->f = NULL;
   lb->fprime = NULL;
+  lb->hydro_stale = 0;
   lb->pending_halo = 0;
   lb->pending_prop = 0;
   lb->layout_swapped = 0;
@@ -1120,6 +1217,8 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
  *
  *****************************************************************************/
 
+static int lbmi_lb_collide_dev(lbmi_t * lb, const lbmi_hydro_dev_t * hp);
+
 int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
 
   lbmi_hydro_dev_t h = lbmi_hydro_dev(hydro);
@@ -1130,6 +1229,30 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
     return lbmi_fail(LBMI_ERR_STATE, "ndist = 2: lbmi_lb_collide_binary");
   }
   HIPCHECK(hipSetDevice(lb->device));
+
+  /* a force field of zeros is not read (F = the body force, bit for bit) */
+  if (lbmi_known_zero(lb, h.force)) h.force = NULL;
+  /* whatever an earlier collision still owed is superseded by this one */
+  lb->hydro_stale = 0;
+  if (lb->hydro_lazy && lbmi_deferred(lb) && !lbmi_inplace(lb) &&
+      (h.rho != NULL || h.u != NULL)) {
+    int ifail;
+    lb->lazy_h = h;
+    for (int ia = 0; ia < 3; ia++) lb->lazy_fbody[ia] = lb->kp.fbody[ia];
+    h.rho = NULL;
+    h.u = NULL;
+    ifail = lbmi_lb_collide_dev(lb, &h);
+    if (ifail == 0) lb->hydro_stale = 1;
+    return ifail;
+  }
+  lbmi_known_zero_drop(lb, h.rho);
+  lbmi_known_zero_drop(lb, h.u);
+  return lbmi_lb_collide_dev(lb, &h);
+}
+
+static int lbmi_lb_collide_dev(lbmi_t * lb, const lbmi_hydro_dev_t * hp) {
+
+  const lbmi_hydro_dev_t h = *hp;
 
   if (lbmi_inplace(lb)) {
     int ifail;
@@ -1970,9 +2093,13 @@ int lbmi_lb_propagation(lbmi_t * lb) {
       return lbmi_fail(LBMI_ERR_STATE, "two propagations without a collision");
     }
     if (!lb->pending_halo) {
-      /* A propagation that follows no halo swap (stale halos) cannot be
+            /* A propagation that follows no halo swap (stale halos) cannot be
        * deferred faithfully: run it now */
       HIPCHECK(hipSetDevice(lb->device));
+      {
+	int ifail = lbmi_hydro_materialise(lb);
+	if (ifail) return ifail;
+      }
       if (lb->layout_swapped) {
 	KCHECK(lbmi_k_aa_unswap(&lb->kp, lb->f, lb->stream));
 	lb->layout_swapped = 0;
@@ -2014,8 +2141,15 @@ int lbmi_lb_propagation(lbmi_t * lb) {
 int lbmi_lb_flush(lbmi_t * lb) {
 
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
-  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+    if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   HIPCHECK(hipSetDevice(lb->device));
+
+  /* rho, u still owed (hydro_lazy) come from the post-collision state: now,
+   * before a pending propagation turns it into the next one */
+  {
+    int ifail = lbmi_hydro_materialise(lb);
+    if (ifail) return ifail;
+  }
 
   if (lb->early_prop) {
     /* k_aa_odd has already applied P(t+1); the caller is between
@@ -2217,8 +2351,12 @@ int lbmi_lb_memcpy_h2d(lbmi_t * lb, const double * f_host) {
   if (lb == NULL || f_host == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   HIPCHECK(hipSetDevice(lb->device));
-  sz = sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel
+    sz = sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel
     *(size_t) lb->opts.ndist;
+  {
+    int ifail = lbmi_hydro_materialise(lb);     /* of the state that goes */
+    if (ifail) return ifail;
+  }
   lb->pending_halo = 0;
   lb->pending_prop = 0;
   lb->layout_swapped = 0;
@@ -2263,11 +2401,32 @@ int lbmi_hydro_field_set(lbmi_t * lb, double * field, int ncomp,
   if (lb == NULL || field == NULL || values == NULL) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   }
-  if (ncomp < 1 || ncomp > 3) {
+    if (ncomp < 1 || ncomp > 3) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "ncomp = %d (1..3)", ncomp);
   }
-  HIPCHECK(hipSetDevice(lb->device));
-  KCHECK(lbmi_k_field_set(&lb->kp, ncomp, field, values, lb->stream));
+  {
+    int zero = 1;
+    for (int n = 0; n < ncomp; n++) zero = zero && (values[n] == 0.0);
+    /* zeros over zeros: nothing to do (hydro_f_zero every step on a force
+     * field nobody has written to since) */
+    if (zero && lbmi_known_zero(lb, field)) return 0;
+    HIPCHECK(hipSetDevice(lb->device));
+        if (lb->hydro_stale) {
+      /* an array that is overwritten whole is no longer owed (hydro_u_zero
+       * before the next collision, ludwig.c:791); a force that changes would
+       * no longer be the one the collision used: settle first */
+      if (field == lb->lazy_h.u) lb->lazy_h.u = NULL;
+      if (field == lb->lazy_h.rho) lb->lazy_h.rho = NULL;
+      if (lb->lazy_h.u == NULL && lb->lazy_h.rho == NULL) lb->hydro_stale = 0;
+      if (field == lb->lazy_h.force) {
+	int ifail = lbmi_hydro_materialise(lb);
+	if (ifail) return ifail;
+      }
+    }
+    KCHECK(lbmi_k_field_set(&lb->kp, ncomp, field, values, lb->stream));
+    if (zero) lbmi_known_zero_add(lb, field);
+    else lbmi_known_zero_drop(lb, field);
+  }
   return 0;
 }
 
@@ -2371,7 +2530,11 @@ int lbmi_symmetric_force(lbmi_t * lb, double a, double b, double kappa,
   if (grad == NULL && lb->kp.nhalo < 2) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "force from phi needs nhalo >= 2");
   }
-  HIPCHECK(hipSetDevice(lb->device));
+    HIPCHECK(hipSetDevice(lb->device));
+  {
+    int ifail = lbmi_hydro_touch(lb, NULL, force);
+    if (ifail) return ifail;
+  }
   KCHECK(lbmi_k_symm_force(&lb->kp, lb->grad_npt, a, b, kappa, phi, grad,
 			   delsq, force, lb->stream));
   return 0;
@@ -2392,7 +2555,11 @@ int lbmi_cahn_hilliard(lbmi_t * lb, double a, double b, double kappa,
   if (delsq == NULL && lb->kp.nhalo < 2) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "mu from phi needs nhalo >= 2");
   }
-  HIPCHECK(hipSetDevice(lb->device));
+    HIPCHECK(hipSetDevice(lb->device));
+  {
+    int ifail = lbmi_hydro_touch(lb, u, NULL);
+    if (ifail) return ifail;
+  }
   KCHECK(lbmi_k_cahn_hilliard(&lb->kp, lb->grad_npt, lb->adv_order, a, b,
 			      kappa, mobility, phi, delsq, u, phi_out,
 			      lb->stream));
@@ -2410,6 +2577,10 @@ int lbmi_symmetric_step(lbmi_t * lb, double a, double b, double kappa,
   if (phi_out == phi) return lbmi_fail(LBMI_ERR_ARGUMENT, "phi_out aliases phi");
   if (lb->kp.nhalo < 2) return lbmi_fail(LBMI_ERR_ARGUMENT, "needs nhalo >= 2");
   HIPCHECK(hipSetDevice(lb->device));
+  {
+    int ifail = lbmi_hydro_touch(lb, u, force);
+    if (ifail) return ifail;
+  }
   KCHECK(lbmi_k_symm_fe_step(&lb->kp, lb->grad_npt, lb->adv_order, a, b,
 			     kappa, mobility, phi, NULL, NULL, u, force,
 			     phi_out, accumulate, 0, lb->stream));
@@ -2440,6 +2611,10 @@ int lbmi_symmetric_step_periodic(lbmi_t * lb, double a, double b,
     }
   }
   HIPCHECK(hipSetDevice(lb->device));
+  {
+    int ifail = lbmi_hydro_touch(lb, u, force);
+    if (ifail) return ifail;
+  }
   KCHECK(lbmi_k_symm_fe_step(&lb->kp, lb->grad_npt, lb->adv_order, a, b,
 			     kappa, mobility, phi, NULL, NULL, u, force,
 			     phi_out, accumulate, 1, lb->stream));
@@ -2457,6 +2632,10 @@ int lbmi_symmetric_step_grad(lbmi_t * lb, double a, double b, double kappa,
   if (phi_out == phi) return lbmi_fail(LBMI_ERR_ARGUMENT, "phi_out aliases phi");
   if (lb->kp.nhalo < 2) return lbmi_fail(LBMI_ERR_ARGUMENT, "needs nhalo >= 2");
   HIPCHECK(hipSetDevice(lb->device));
+  {
+    int ifail = lbmi_hydro_touch(lb, u, force);
+    if (ifail) return ifail;
+  }
   KCHECK(lbmi_k_symm_fe_step(&lb->kp, 0, lb->adv_order, a, b, kappa, mobility,
 			     phi, grad, delsq, u, force, phi_out, accumulate,
 			     0, lb->stream));
@@ -2476,6 +2655,10 @@ int lbmi_lb_records_unpack(lbmi_t * lb, const double * records) {
   if (lb == NULL || records == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   HIPCHECK(hipSetDevice(lb->device));
+    {
+    int ifail = lbmi_hydro_materialise(lb);     /* of the state that goes */
+    if (ifail) return ifail;
+  }
   /* reading a checkpoint replaces the state: nothing stays pending */
   lb->pending_halo = 0;
   lb->pending_prop = 0;
@@ -2680,7 +2863,7 @@ int lbmi_synchronize(lbmi_t * lb) {
   HIPCHECK(hipStreamSynchronize(lb->comm_stream));
   HIPCHECK(hipStreamSynchronize(lb->bnd_stream));
   HIPCHECK(hipStreamSynchronize(lb->stream));
-  return 0;
+  return lbmi_wall_err_report(lb);
 }
 
 int lbmi_set_stream(lbmi_t * lb, void * stream) {

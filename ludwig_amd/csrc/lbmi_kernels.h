@@ -80,6 +80,10 @@ int lbmi_k_propagate_collide(const lbmi_kparam_t * kp, const double * f,
 			     int wrapmask, int lay, int xlo, int xhi, int xlo2,
 			     int xhi2, void * stream);
 int lbmi_k_blocked_sites(const lbmi_kparam_t * kp);
+/* rho, u of the collision that left the post-collision state f (SoA, or the
+ * blocked order): u = (sum f'_p c_p - F/2)/rho at interior fluid sites */
+int lbmi_k_hydro_from_f(const lbmi_kparam_t * kp, const double * f,
+			const lbmi_hydro_dev_t * h, int blocked, void * stream);
 int lbmi_k_relayout(const lbmi_kparam_t * kp, const double * src,
 		    double * dst, int to_blocked, void * stream);
 

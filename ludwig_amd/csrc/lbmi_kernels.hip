@@ -724,8 +724,11 @@ void pc_pull(const lbmi_kparam_t & kp, const double * __restrict__ f,
 #endif
 }
 
-/* phase 2: collide (interior fluid sites) and store site i */
-template <int NVEL, int SCHEME, bool WB, bool NTS>
+/* phase 2: collide (interior fluid sites) and store site i. HIO = false: the
+ * step has no hydro traffic (no force field to read, rho and u not wanted
+ * now): a variant of its own, so that it is also a kernel of its own name in
+ * a profile */
+template <int NVEL, int SCHEME, bool WB, bool NTS, bool HIO>
 __device__ __forceinline__
 void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
 		      const lbmi_hydro_dev_t & h, int i,
@@ -740,15 +743,20 @@ void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
 
   if (active) {
     double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
-    if (h.force) {
-      frc[0] += h.force[i];
-      frc[1] += h.force[ns + i];
-      frc[2] += h.force[2*ns + i];
+    if constexpr (HIO) {
+      if (h.force) {
+	frc[0] += h.force[i];
+	frc[1] += h.force[ns + i];
+	frc[2] += h.force[2*ns + i];
+      }
     }
     Relax rx = site_relax<SCHEME>(kp, h, i);
     double rho, u[3];
     collide_site<NVEL, SCHEME>(ps.fl, frc, rx, rho, u);
-    if (kp.nt_store & 2) {
+    if constexpr (!HIO) {
+      /* nothing to store */
+    }
+    else if (kp.nt_store & 2) {
       /* rho and u are written once and not read again by this kernel */
       if (h.rho) __builtin_nontemporal_store(rho, &h.rho[i]);
       if (h.u) {
@@ -780,7 +788,7 @@ void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
 /* LAY & 3: 0 SoA -> SoA, 1 SoA -> blocked, 2 blocked -> blocked;
  * LAY & 4: nontemporal stores of fprime */
 
-template <int NVEL, int SCHEME, bool WRAP, int LAY>
+template <int NVEL, int SCHEME, bool WRAP, int LAY, bool HIO>
 __global__ __launch_bounds__(BLOCK, LBMI_WAVES)
 void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
 			 double * __restrict__ fp, lbmi_hydro_dev_t h,
@@ -818,7 +826,7 @@ void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
   static_for<0, SPT>([&](auto K) {
     constexpr int k = K;
     if (i[k] >= i0 && i[k] < i1) {
-      pc_collide_store<NVEL, SCHEME, ORD != 0, (LAY & 4) != 0>(kp, fp, h, i[k], ps[k]);
+      pc_collide_store<NVEL, SCHEME, ORD != 0, (LAY & 4) != 0, HIO>(kp, fp, h, i[k], ps[k]);
     }
   });
 }
@@ -839,6 +847,63 @@ void k_relayout(lbmi_kparam_t kp, const double * __restrict__ src,
   double v[NVEL];
   static_for<0, NVEL>([&](auto P) { v[P] = src[faddr<NVEL, !TO_BLK>(ns, P, i)]; });
   static_for<0, NVEL>([&](auto P) { dst[faddr<NVEL, TO_BLK>(ns, P, i)] = v[P]; });
+}
+
+/* k_hydro_from_f: hydro->rho and hydro->u of the LAST collision from the
+ * post-collision distributions it left (either order), for a caller that
+ * does not want them written every step (lbmi_tune "hydro_lazy"). The
+ * collision conserves rho and adds F to the momentum, so with g' = sum f'_p c_p
+ * the velocity it used, u = (g + F/2)/rho (collision.c:376-382), is
+ * (g' - F/2)/rho. Fluid interior sites only, as lb_collision_mrt1_site
+ * (collision.c:299-304, 571-579). The sums run in p order like the
+ * collision's; the values agree with the ones it would have stored to a few
+ * ulp (different operands: f' instead of f), well inside the 1e-12 of the
+ * parity criterion. */
+
+template <int NVEL, bool BLK>
+__global__ __launch_bounds__(BLOCK)
+void k_hydro_from_f(lbmi_kparam_t kp, const double * __restrict__ f,
+		    lbmi_hydro_dev_t h, int i0, int i1, unsigned nblk) {
+
+  using M = Model<NVEL>;
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+
+  Site s = decode(kp, i);
+  if (!s.interior) return;
+  if (h.status && h.status[i] != 0) return;
+
+  const size_t ns = (size_t) kp.nsite;
+  double fl[NVEL];
+  static_for<0, NVEL>([&](auto P) { fl[P] = f[faddr<NVEL, BLK>(ns, P, i)]; });
+
+  double rho = 0.0;
+  double g[3] = {0.0, 0.0, 0.0};
+  static_for<0, NVEL>([&](auto P) {
+    constexpr int p = P;
+    rho += fl[p];
+    static_for<0, 3>([&](auto A) {
+      constexpr int a = A;
+      if constexpr (M::c(p,a) ==  1) g[a] += fl[p];
+      if constexpr (M::c(p,a) == -1) g[a] -= fl[p];
+    });
+  });
+
+  double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
+  if (h.force) {
+    frc[0] += h.force[i];
+    frc[1] += h.force[ns + i];
+    frc[2] += h.force[2*ns + i];
+  }
+  const double rrho = 1.0/rho;
+  if (h.rho) h.rho[i] = rho;
+  if (h.u) {
+    h.u[i] = rrho*(g[0] - 0.5*frc[0]);
+    h.u[ns + i] = rrho*(g[1] - 0.5*frc[1]);
+    h.u[2*ns + i] = rrho*(g[2] - 0.5*frc[2]);
+  }
 }
 
 /* ---- in-place streaming: the AA pattern --------------------------------------
@@ -2075,8 +2140,8 @@ int launch_collide(const lbmi_kparam_t & kp, double * f,
   return (int) hipGetLastError();
 }
 
-template <int NVEL, bool WRAP, int LAY>
-int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
+template <int NVEL, bool WRAP, int LAY, bool HIO>
+int launch_pc_hio(const lbmi_kparam_t & kp, const double * f, double * fp,
 	      const lbmi_hydro_dev_t & h, int wrapmask, int i0, int i1,
 	      int j0, int j1, hipStream_t st) {
   constexpr int ALIGNV = ((LAY & 3) == 0) ? LBMI_ALIGN : LBW;
@@ -2097,10 +2162,10 @@ int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
   if (lds > 65536u) {
     /* above 64 KiB the limit must be raised per kernel */
     const void * fn = nullptr;
-    if (kp.scheme == LBMI_M10) fn = (const void *) k_propagate_collide<NVEL, LBMI_M10, WRAP, LAY>;
-    if (kp.scheme == LBMI_BGK) fn = (const void *) k_propagate_collide<NVEL, LBMI_BGK, WRAP, LAY>;
+    if (kp.scheme == LBMI_M10) fn = (const void *) k_propagate_collide<NVEL, LBMI_M10, WRAP, LAY, HIO>;
+    if (kp.scheme == LBMI_BGK) fn = (const void *) k_propagate_collide<NVEL, LBMI_BGK, WRAP, LAY, HIO>;
     if constexpr (NVEL == 19) {
-      if (kp.scheme == LBMI_TRT) fn = (const void *) k_propagate_collide<NVEL, LBMI_TRT, WRAP, LAY>;
+      if (kp.scheme == LBMI_TRT) fn = (const void *) k_propagate_collide<NVEL, LBMI_TRT, WRAP, LAY, HIO>;
     }
     if (fn) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
@@ -2109,18 +2174,18 @@ int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
   }
   switch (kp.scheme) {
   case LBMI_M10:
-    hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_M10, WRAP, LAY>), grid,
+    hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_M10, WRAP, LAY, HIO>), grid,
 		       block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk,
 		       j0, j1, nblk_first);
     break;
   case LBMI_BGK:
-    hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_BGK, WRAP, LAY>), grid,
+    hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_BGK, WRAP, LAY, HIO>), grid,
 		       block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk,
 		       j0, j1, nblk_first);
     break;
   case LBMI_TRT:
     if constexpr (NVEL == 19) {
-      hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_TRT, WRAP, LAY>), grid,
+      hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_TRT, WRAP, LAY, HIO>), grid,
 			 block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk,
 			 j0, j1, nblk_first);
       break;
@@ -2130,6 +2195,16 @@ int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
     return (int) hipErrorInvalidValue;
   }
   return (int) hipGetLastError();
+}
+
+template <int NVEL, bool WRAP, int LAY>
+int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
+	      const lbmi_hydro_dev_t & h, int wrapmask, int i0, int i1,
+	      int j0, int j1, hipStream_t st) {
+  if (h.force == nullptr && h.rho == nullptr && h.u == nullptr) {
+    return launch_pc_hio<NVEL, WRAP, LAY, false>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
+  }
+  return launch_pc_hio<NVEL, WRAP, LAY, true>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
 }
 
 template <int NVEL>
@@ -2501,6 +2576,20 @@ extern "C" int lbmi_k_propagate_collide(const lbmi_kparam_t * kp,
     return launch_pc_any<27>(*kp, f, fprime, *h, wrapmask, lay, i0, i1, j0, j1, st);
   }
   return (int) hipErrorInvalidValue;
+}
+
+extern "C" int lbmi_k_hydro_from_f(const lbmi_kparam_t * kp, const double * f,
+				   const lbmi_hydro_dev_t * h, int blocked,
+				   void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  Range1D r = interior_range(*kp);
+  dim3 grid(r.grid), block(BLOCK);
+  if (kp->nvel == 19 && !blocked) hipLaunchKernelGGL((k_hydro_from_f<19, false>), grid, block, 0, st, *kp, f, *h, r.i0, r.i1, r.nblk);
+  else if (kp->nvel == 19) hipLaunchKernelGGL((k_hydro_from_f<19, true>), grid, block, 0, st, *kp, f, *h, r.i0, r.i1, r.nblk);
+  else if (kp->nvel == 27 && !blocked) hipLaunchKernelGGL((k_hydro_from_f<27, false>), grid, block, 0, st, *kp, f, *h, r.i0, r.i1, r.nblk);
+  else if (kp->nvel == 27) hipLaunchKernelGGL((k_hydro_from_f<27, true>), grid, block, 0, st, *kp, f, *h, r.i0, r.i1, r.nblk);
+  else return (int) hipErrorInvalidValue;
+  return (int) hipGetLastError();
 }
 
 extern "C" int lbmi_k_blocked_sites(const lbmi_kparam_t * kp) {

@@ -273,6 +273,15 @@ class LB:
         a = (ctypes.c_double * 3)(*([float(v) for v in values] + [0.0] * 3)[:3])
         _l.check(self._lib.lbmi_hydro_field_set(self._h, _ptr(field), ncomp, a))
 
+    def hydro_sync(self):
+        """lbmi_lb_hydro_sync: rho, u of the last collision, if a lazy
+        collision (tune hydro_lazy) still owes them."""
+        _l.check(self._lib.lbmi_lb_hydro_sync(self._h))
+
+    def hydro_field_dirty(self, field):
+        """Somebody outside the library has written to this device field."""
+        _l.check(self._lib.lbmi_hydro_field_dirty(self._h, _ptr(field)))
+
     def field_halo_n(self, data, nswap):
         """field_halo with a swap of nswap layers (phi: 2)."""
         nel = 1 if data.dim() == 3 else data.shape[0]

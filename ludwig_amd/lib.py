@@ -112,6 +112,8 @@ SYMBOLS = [
     ("lbmi_lb_memcpy_h2d", _i, [_vp, _vp]),
     ("lbmi_lb_memcpy_d2h", _i, [_vp, _vp]),
     ("lbmi_lb_moments", _i, [_vp, _vp, _pd]),
+    ("lbmi_lb_hydro_sync", _i, [_vp]),
+    ("lbmi_hydro_field_dirty", _i, [_vp, _vp]),
     ("lbmi_hydro_field_set", _i, [_vp, _vp, _i, _pd]),
     ("lbmi_field_halo_n", _i, [_vp, _i, _i, _vp]),
     ("lbmi_fe_scheme_set", _i, [_vp, _i, _i]),

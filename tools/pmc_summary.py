@@ -23,14 +23,33 @@ def counter_avg(tag, sub, counter, kernel):
                                    "**", "*counter_collection.csv"), recursive=True)
     assert files, "no counter csv for " + sub
     vals = {}
-    for row in csv.DictReader(open(files[0])):
-        if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
+    rows = [r for r in csv.DictReader(open(files[0]))
+            if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    # several instantiations of the kernel may have run (start-up steps, the
+    # hydro-every-step leg): the one with the most dispatches is the timed loop
+    names = {}
+    for r in rows:
+        names.setdefault(r["Kernel_Name"], set()).add(r["Dispatch_Id"])
+    main_name = max(names, key=lambda k: len(names[k]))
+    for row in rows:
+        if row["Kernel_Name"] == main_name:
             key = row["Dispatch_Id"]
             vals[key] = vals.get(key, 0.0) + float(row["Counter_Value"])
     v = sorted(vals.values())
     # drop the first launches (warm-up: cold caches and page faults)
     v = list(vals.values())[2:]
     return len(v), sum(v) / len(v)
+
+
+def source_sha1():
+    """As bench.py:kernel_source_sha1: the bench quotes this file's traffic
+    only while the kernel source is the one it was measured with."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("lbmi_kernels.hip", "lbmi_kernels.h"):
+        with open(os.path.join(ROOT, "ludwig_amd", "csrc", f), "rb") as fp:
+            h.update(fp.read())
+    return h.hexdigest()
 
 
 def main():
@@ -43,10 +62,11 @@ def main():
     assert stats
     shutil.copy(stats[0], os.path.join(ROOT, "profiles", name + "_kernel_stats.csv"))
     kavg = None
+    kname = None
     for row in csv.DictReader(open(stats[0])):
-        if kernel in row["Name"]:
+        if kernel in row["Name"] and (kavg is None or int(row["Calls"]) > kavg[1]):
             kavg = (float(row["AverageNs"]) * 1e-6, int(row["Calls"]))
-            break
+            kname = row["Name"]
     nf, fetch = counter_avg(tag, "fetch", "FETCH_SIZE", kernel)
     nw, write = counter_avg(tag, "write", "WRITE_SIZE", kernel)
     rl = bench["roofline"]
@@ -66,7 +86,9 @@ def main():
         "FETCH_SIZE": {"launches": nf, "avg_counter_KiB": fetch},
         "WRITE_SIZE": {"launches": nw, "avg_counter_KiB": write},
         "summary": {
-            "kernel": kernel, "workload": bench["config"]["workload"],
+            "kernel": kernel, "kernel_instance": kname,
+            "kernel_source_sha1": source_sha1(),
+            "workload": bench["config"]["workload"],
             "mode": bench["config"]["mode"], "order": bench["config"].get("order"),
             "fetch_bytes_corrected_x2": 2.0 * fetch * 1024.0,
             "write_bytes": write * 1024.0,
