@@ -232,6 +232,51 @@ def reference_gpu(args):
             "ms_per_step": round(1e3 * r["t_total"] / r["steps"], 4)}
 
 
+def dry_run(args, rank, world):
+    """Everything of an N-rank run that needs no device: the ranks meet over
+    gloo, cut the box, and every rank's X exchange schedule (lbmi_x_schedule,
+    the list the library hands to RCCL) is checked against its neighbours':
+    each send has its receive, same length, matched in order."""
+    import torch.distributed as dist
+
+    import ludwig_amd
+
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ntotal = tuple(args.size)
+    if args.scaling == "weak":
+        ntotal = (args.size[0] * world, args.size[1], args.size[2])
+    dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, nhalo=args.nhalo)
+    mine = ludwig_amd.x_schedule(args.nvel, dec.nlocal, args.nhalo, world, rank)
+    every = [mine]
+    if world > 1:
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+    ok = True
+    for r in range(world):
+        for peer in set(op["peer"] for op in every[r]):
+            sends = [op["count"] for op in every[r]
+                     if op["kind"] == "send" and op["peer"] == peer]
+            recvs = [op["count"] for op in every[peer]
+                     if op["kind"] == "recv" and op["peer"] == r]
+            ok = ok and sends == recvs
+    out = None
+    if rank == 0:
+        out = json.dumps({
+            "dry_run": True, "n_gpus": world, "ranks_met": len(every),
+            "schedules_pair_up": ok, "scaling": args.scaling,
+            "config": {"workload": "D3Q%d %dx%dx%d, x-slab %d_1_1"
+                       % (args.nvel, *ntotal, world),
+                       "nlocal": list(dec.nlocal)},
+            "bytes_per_exchange_per_rank": 8 * sum(
+                op["count"] for op in mine if op["kind"] == "send")})
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("the X exchange schedules of the ranks do not pair up")
+    return out
+
+
 def kernel_source_sha1():
     import hashlib
     h = hashlib.sha1()
@@ -444,7 +489,21 @@ def main():
         dt = float(t[0])
 
     kms, nlaunch = lb.timing_read()
+    detail, ndetail = lb.timing_read_detail()
     lb.timing(False)
+    comm = lb.comm_info()
+    phases = None
+    if comm[0] > 0:
+        # per rank: the three parts of a slab step, each on its own stream
+        mine = {"rank": rank, "ring": comm[0],
+                "transport": {0: "none", 1: "rccl", 2: "in-process"}[comm[2]],
+                "interior_ms": round(detail[0], 5), "exchange_ms": round(detail[1], 5),
+                "boundary_ms": round(detail[2], 5), "steps_sampled": ndetail,
+                "step_ms": round(kms / max(nlaunch, 1), 5)}
+        phases = [mine]
+        if world > 1:
+            phases = [None] * world
+            dist.all_gather_object(phases, mine)
     order = {0: "soa", 1: "blocked [site/256][p][site%256] (deferred state)",
              2: "slot-swapped (AA)"}[lb.state()[2]]
     mom1 = allsum(lb.moments()[[1, 5, 6, 7]])
@@ -571,6 +630,8 @@ def main():
             },
                         "roofline": roofline,
             "hydro_every_step": every,
+            "rccl_ranks": comm[0] if comm[2] == 1 else 0,
+            "slab_step": phases,
             "check": {
                 "mass_drift_rel": float(abs(mom1[0] - mom0[0]) / mom0[0]),
                 "momentum_drift_abs": float(np.max(np.abs(mom1[1:] - mom0[1:]))),

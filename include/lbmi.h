@@ -59,6 +59,7 @@ extern "C" {
 #define LBMI_VERSION_MINOR 1
 
 typedef struct lbmi_s lbmi_t;           /* opaque handle ~ lb_t + halo_swap_t */
+typedef struct lbmi_ring_s lbmi_ring_t; /* a ring of handles inside one process */
 
 typedef enum lbmi_error_e {
   LBMI_SUCCESS         =  0,
@@ -566,6 +567,11 @@ int lbmi_set_stream(lbmi_t * lb, void * stream);
  * time and the number of launches that were timed. */
 int lbmi_timing(lbmi_t * lb, int on);
 int lbmi_timing_read(lbmi_t * lb, double * ms_total, int * nlaunch);
+/* The sampled steps of a slab (the first 256 of them) in detail: average
+ * milliseconds of ms[0] the interior launch, ms[1] the exchange (pack if any,
+ * messages, unpack if any), ms[2] the boundary launch, each measured on the
+ * stream it runs on. Resets the samples. */
+int lbmi_timing_read_detail(lbmi_t * lb, double ms[3], int * nsample);
 
 /* Launch tuning of the fused step; results do not depend on it.
  * "xcd_group": blocks per XCD interleave group (0 = one chunk per XCD; 32);
@@ -577,10 +583,15 @@ int lbmi_timing_read(lbmi_t * lb, double * ms_total, int * nlaunch);
  *            fprime together exceed the 256 MiB Infinity Cache;
  * "x_packed": 1 = RCCL X exchange through packed staging buffers, one message
  *            per direction (default), 0 = zero-copy sends of the planes;
+ * "x_direct": 1 = slabs, FUSED: the boundary launch takes the populations
+ *            that cross the X faces straight from the receive buffers and
+ *            leaves those the next exchange sends in the send buffers: no pack
+ *            and no unpack kernel in a steady-state step (default; needs
+ *            x_packed), 0 = pack, messages, unpack into the halo planes;
  * "x_concurrent": 1 = slabs: the two boundary planes run on a third stream
  *            beside the interior launch once the halo has arrived (default),
  *            0 = after it on the compute stream;
-  * "hydro_lazy": 1 = lbmi_lb_collide leaves hydro->rho, u to lbmi_lb_hydro_sync
+ * "hydro_lazy": 1 = lbmi_lb_collide leaves hydro->rho, u to lbmi_lb_hydro_sync
  *            (see there), 0 = stored by every collision (default);
  * "graph":   1 = lbmi_lb_run on one GPU in FUSED mode issues its steps as
  *            launches of ONE hipGraph holding two steady-state steps (for
@@ -597,6 +608,51 @@ int lbmi_comm_unique_id(void * id);
 /* ncclCommInitRank over the cartsz ranks given at lbmi_create() */
 int lbmi_comm_init(lbmi_t * lb, const void * id);
 int lbmi_comm_free(lbmi_t * lb);
+/* What the handle exchanges over: the number of ranks of its ring, its own
+ * rank there, and the transport (0 none, 1 RCCL, 2 in-process ring) */
+int lbmi_comm_info(lbmi_t * lb, int * nranks, int * rank, int * transport);
+
+/* The point-to-point operations of ONE X exchange of a rank, in the order
+ * they are issued -- what replaces halo_swap.c:762-881 (MPI_Irecv / pack /
+ * copy to the host / MPI_Isend / MPI_Waitall / copy back / unpack). A pure
+ * host function of the decomposition (no device, no handle): the product
+ * executes exactly this list with ncclSend / ncclRecv inside one group, and
+ * a test can execute it with any other transport that, like RCCL, matches
+ * the k-th send towards a peer with the k-th receive from it.
+ *   packed != 0: one message per direction through staging buffers laid out
+ *     [k][plane site] (k-th component of the selection, strx doubles each):
+ *     SENDHI = last interior plane, components that fill a LOW halo
+ *     (reduced: c_x = +1) -> next rank's RECVLO; SENDLO = first interior
+ *     plane, components that fill a HIGH halo -> previous rank's RECVHI.
+ *   packed == 0: one message per component straight between the planes of
+ *     the array (buffer LBMI_XBUF_DATA, offset in doubles from its start). */
+enum {LBMI_XOP_SEND = 0, LBMI_XOP_RECV = 1};
+enum {LBMI_XBUF_SENDLO = 0, LBMI_XBUF_SENDHI = 1, LBMI_XBUF_RECVLO = 2,
+      LBMI_XBUF_RECVHI = 3, LBMI_XBUF_DATA = 4};
+typedef struct lbmi_xop_s {
+  int kind;                 /* LBMI_XOP_SEND | LBMI_XOP_RECV */
+  int peer;                 /* rank along X */
+  int buffer;               /* LBMI_XBUF_* */
+  long long offset;         /* doubles from the start of that buffer */
+  long long count;          /* doubles */
+} lbmi_xop_t;
+int lbmi_x_schedule(const lbmi_options_t * opts, int scheme, int packed,
+		    lbmi_xop_t * ops, int maxops, int * nops);
+
+/* A ring of cartsz handles inside ONE process, all on one device, each
+ * driven by a thread of its own: the slab path -- kernels, schedule, streams,
+ * overlap -- with device-to-device copies in place of RCCL, for tests and
+ * rehearsals on a single GPU (RCCL refuses two ranks on one device).
+ * lbmi_ring_create once, lbmi_comm_init_ring on every handle in place of
+ * lbmi_comm_init, lbmi_comm_free / lbmi_free on every handle, lbmi_ring_free.
+ * An exchange waits for the neighbours' posts: with more than one rank the
+ * handles must step concurrently (one thread each). */
+int lbmi_ring_create(int nranks, lbmi_ring_t ** ring);
+int lbmi_comm_init_ring(lbmi_t * lb, lbmi_ring_t * ring);
+int lbmi_ring_free(lbmi_ring_t * ring);
+/* A rank whose driver has failed: exchanges of the others stop waiting and
+ * return LBMI_ERR_STATE from now on. */
+int lbmi_ring_abort(lbmi_ring_t * ring);
 
 #ifdef __cplusplus
 }

@@ -115,6 +115,7 @@ typedef struct shim_s {
   int mode;                       /* lbmi_mode_t in use */
   wall_t * wall;                  /* whose links the handle holds a copy of */
   int wall_nlink;
+  int colloids;                   /* bounce_back_on_links has seen colloids */
   int param_valid;                /* param_committed is what the device has */
   lb_collide_param_t param_committed;
 } shim_t;
@@ -389,6 +390,18 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
      * (collision.c:386-404, 1947) */
     hy.eta    = visc ? shim_field_data(hydro->eta) : NULL;
 
+    /* hydro_f_zero below tells the library that hydro->force holds zeros,
+     * and a force field of zeros is not read. That holds until somebody
+     * writes to it, and everybody who does inside the reference --
+     * phi_force_calculation, fe_lc_droplet_bodyforce, psi_force_*,
+     * nernst_planck_driver (all need a free energy, ludwig.c:643-738) and
+     * subgrid_force_from_particles (colloids, ludwig.c:2071, 2149) -- is
+     * outside the library: with a free energy or colloids the force is taken
+     * to have been written every step. */
+    if (fe != NULL || shim_.colloids) {
+      SHIM_CHECK(lb, lbmi_hydro_field_dirty(h, hy.force));
+    }
+
     if (lb->ndist == 2 || (fe && fe->use_stress_relaxation)) {
       /* lb_collision_binary (collision.c:610-1027), or the single-fluid
        * collision with the symmetric stress relaxed (:413-429) */
@@ -546,7 +559,10 @@ int bounce_back_on_links(bbl_t * bbl, lb_t * lb, wall_t * wall,
   assert(cinfo);
 
   colloids_info_ntotal(cinfo, &ntotal);
-  if (ntotal > 0) shim_needs_canonical_f(lb, "bounce_back_on_links");
+  if (ntotal > 0) {
+    shim_.colloids = 1;
+    shim_needs_canonical_f(lb, "bounce_back_on_links");
+  }
 
   return bounce_back_on_links_ref(bbl, lb, wall, cinfo);
 }

@@ -16,6 +16,7 @@
 
 #include <errno.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,7 +30,8 @@
 #include "lbmi_kernels.h"
 
 enum {X = 0, Y = 1, Z = 2};
-enum {LBMI_NEVENT = 4096};
+enum {LBMI_NEVENT = 4096, LBMI_NDETAIL = 256};
+enum {LBMI_XOPS_MAX = 4*LBMI_NVEL_MAX};
 
 struct lbmi_s {
   lbmi_options_t opts;
@@ -76,12 +78,19 @@ struct lbmi_s {
   double * mom_work;
   double * mom_out;
 
-  /* RCCL ring (X slabs) */
+  /* the ring of X slabs: RCCL (one process per GPU), or an in-process ring
+   * of handles on one device (lbmi_ring_t: tests, rehearsals) */
   ncclComm_t comm;
+  lbmi_ring_t * ring;
   int have_comm;
-  double * sendlo, * sendhi, * recvlo, * recvhi;   /* device buffers */
+  double * sendlo, * sendhi, * recvlo, * recvhi;   /* staging, any halo swap */
   size_t xbuf_doubles;
   int x_packed;                      /* 1: pack/unpack through buffers */
+  /* FUSED step: buffers of its own (a field halo between two steps must not
+   * disturb what the boundary launch left for the next exchange) */
+  double * fx[4];                    /* sendlo, sendhi, recvlo, recvhi */
+  int x_direct;                      /* boundary launch works on fx directly */
+  int xsend_valid;                   /* fx send buffers hold the planes of f */
 
   /* free-energy sector: gradient stencil (7 | 27), advection order (1..4) */
   int grad_npt;
@@ -132,6 +141,9 @@ struct lbmi_s {
   int ev_created;
   double ms_accum;
   int launches_accum;
+  /* slab step in detail: interior launch, exchange, boundary launch */
+  hipEvent_t evd[6][LBMI_NDETAIL];
+  int nd;
 };
 
 static __thread char lbmi_errbuf[512] = "no error";
@@ -358,6 +370,7 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   lb->kp.xcd_group = 32;
   lb->kp.lds_cap = 65536;
   lb->x_packed = 1;
+  lb->x_direct = 1;
   lb->x_concurrent = 1;
   lb->use_blocked = 1;               /* profiles/r01_blocked_order.txt */
   lb->kp.fe_tiled = 1;
@@ -438,6 +451,11 @@ int lbmi_free(lbmi_t * lb) {
     for (int n = 0; n < LBMI_NEVENT; n++) {
       if (lb->ev0[n]) hipEventDestroy(lb->ev0[n]);
       if (lb->ev1[n]) hipEventDestroy(lb->ev1[n]);
+    }
+    for (int k = 0; k < 6; k++) {
+      for (int n = 0; n < LBMI_NDETAIL; n++) {
+	if (lb->evd[k][n]) hipEventDestroy(lb->evd[k][n]);
+      }
     }
   }
   if (lb->ev_ready) hipEventDestroy(lb->ev_ready);
@@ -677,11 +695,15 @@ int lbmi_timing(lbmi_t * lb, int on) {
       HIPCHECK(hipEventCreate(&lb->ev0[n]));
       HIPCHECK(hipEventCreate(&lb->ev1[n]));
     }
+    for (int k = 0; k < 6; k++) {
+      for (int n = 0; n < LBMI_NDETAIL; n++) HIPCHECK(hipEventCreate(&lb->evd[k][n]));
+    }
   }
   lb->timing = (on > 0) ? on : 0;
   lb->timing_count = 0;
   lb->timing_now = 0;
   lb->nev = 0;
+  lb->nd = 0;
   lb->ms_accum = 0.0;
   lb->launches_accum = 0;
   return 0;
@@ -706,6 +728,35 @@ int lbmi_timing_read(lbmi_t * lb, double * ms_total, int * nlaunch) {
     *ms_total = ms;
     *nlaunch = n;
   }
+  return 0;
+}
+
+/* The sampled slab steps (cartsz > 1 or a ring; the first LBMI_NDETAIL of
+ * them) in detail: average milliseconds of the interior launch, of the
+ * exchange (pack if any, messages, unpack if any) and of the boundary
+ * launch, each on its own stream. Resets the samples. */
+
+int lbmi_timing_read_detail(lbmi_t * lb, double ms[3], int * nsample) {
+  if (lb == NULL || ms == NULL || nsample == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  HIPCHECK(hipSetDevice(lb->device));
+  HIPCHECK(hipStreamSynchronize(lb->comm_stream));
+  HIPCHECK(hipStreamSynchronize(lb->bnd_stream));
+  HIPCHECK(hipStreamSynchronize(lb->stream));
+  ms[0] = ms[1] = ms[2] = 0.0;
+  *nsample = lb->nd;
+  for (int n = 0; n < lb->nd; n++) {
+    for (int k = 0; k < 3; k++) {
+      float t = 0.0f;
+      /* an empty interior launch (one or two planes per slab) records both
+       * events back to back */
+      HIPCHECK(hipEventElapsedTime(&t, lb->evd[2*k][n], lb->evd[2*k + 1][n]));
+      ms[k] += t;
+    }
+  }
+  if (lb->nd > 0) {
+    for (int k = 0; k < 3; k++) ms[k] /= lb->nd;
+  }
+  lb->nd = 0;
   return 0;
 }
 
@@ -734,6 +785,11 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
   }
   if (strcmp(key, "fe_tiled") == 0) {
     lb->kp.fe_tiled = (value != 0);
+    return 0;
+  }
+  if (strcmp(key, "x_direct") == 0) {
+    lb->x_direct = (value != 0);
+    lb->xsend_valid = 0;
     return 0;
   }
   if (strcmp(key, "x_concurrent") == 0) {
@@ -800,7 +856,7 @@ int lbmi_propagate_collide(lbmi_t * lb, const double * f, double * fprime,
   KCHECK(lbmi_k_propagate_collide(&lb->kp, f, fprime, &h,
 				  wrap ? lbmi_wrapmask(lb) : 0, 0,
 				  lb->kp.nhalo,
-				  lb->kp.nhalo + lb->kp.nlocal[X] - 1, 0, -1,
+				  lb->kp.nhalo + lb->kp.nlocal[X] - 1, 0, -1, NULL,
 				  lb->stream));
   return lbmi_time_end(lb);
 }
@@ -818,74 +874,332 @@ int lbmi_propagate_collide(lbmi_t * lb, const double * f, double * fprime,
  *
  *****************************************************************************/
 
-static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
-			   double * data, int blocked, int layer,
-			   hipStream_t st) {
+/* The point-to-point operations of ONE X exchange of this rank, in the
+ * order they are issued. Pure host arithmetic: the product path
+ * (lbmi_x_sendrecv below) and lbmi_x_schedule (what tests drive with another
+ * transport) both execute exactly this list.
+ *
+ * Towards one peer the order is the same on both sides -- what leaves
+ * upwards (the "lo" components: they fill a LOW halo) before what leaves
+ * downwards -- and that is what matches sends to receives, also when
+ * prev == next (2 ranks: my 1st send, sendhi, meets the peer's 1st receive,
+ * recvlo) or prev == next == self (1 rank).
+ *
+ * packed: one message per direction through staging buffers ([k][plane
+ * site]): sendhi = last interior plane, components lo -> next's recvlo;
+ * sendlo = first interior plane, components hi -> prev's recvhi.
+ * Zero-copy: X is the slowest index, so the boundary plane of ONE component
+ * is a contiguous run of strx doubles of the array itself. */
 
-  size_t psz = (size_t) lb->kp.strx;
-  size_t ns = (size_t) lb->kp.nsite;
-  int nh = lb->kp.nhalo;
-  int prev = (lb->opts.cartrank + lb->opts.cartsz - 1) % lb->opts.cartsz;
-  int next = (lb->opts.cartrank + 1) % lb->opts.cartsz;
+static int lbmi_x_ops(int cartsz, int cartrank, const lbmi_halo_sel_t * sel,
+		      long long psz, long long ns, int nh, int nlocalx,
+		      int packed, int layer, lbmi_xop_t * ops) {
+  const int prev = (cartrank + cartsz - 1) % cartsz;
+  const int next = (cartrank + 1) % cartsz;
+  int n = 0;
+
+  if (packed) {
+    const long long nlo = psz*sel->nlo;      /* arrives in / leaves for low halos */
+    const long long nhi = psz*sel->nhi;
+    const lbmi_xop_t four[4] = {
+      {LBMI_XOP_SEND, next, LBMI_XBUF_SENDHI, 0, nlo},
+      {LBMI_XOP_RECV, prev, LBMI_XBUF_RECVLO, 0, nlo},
+      {LBMI_XOP_SEND, prev, LBMI_XBUF_SENDLO, 0, nhi},
+      {LBMI_XOP_RECV, next, LBMI_XBUF_RECVHI, 0, nhi}};
+    for (int k = 0; k < 4; k++) {
+      if (four[k].count > 0) ops[n++] = four[k];
+    }
+    return n;
+  }
+
+  {
+    const long long last = (long long) (nh + nlocalx - 1 - layer)*psz;
+    const long long first = (long long) (nh + layer)*psz;
+    const long long halo_lo = (long long) (nh - 1 - layer)*psz;
+    const long long halo_hi = (long long) (nh + nlocalx + layer)*psz;
+    for (int k = 0; k < sel->nlo; k++) {
+      const long long c = ns*sel->lo[k];
+      const lbmi_xop_t snd = {LBMI_XOP_SEND, next, LBMI_XBUF_DATA, c + last, psz};
+      const lbmi_xop_t rcv = {LBMI_XOP_RECV, prev, LBMI_XBUF_DATA, c + halo_lo, psz};
+      ops[n++] = snd;
+      ops[n++] = rcv;
+    }
+    for (int k = 0; k < sel->nhi; k++) {
+      const long long c = ns*sel->hi[k];
+      const lbmi_xop_t snd = {LBMI_XOP_SEND, prev, LBMI_XBUF_DATA, c + first, psz};
+      const lbmi_xop_t rcv = {LBMI_XOP_RECV, next, LBMI_XBUF_DATA, c + halo_hi, psz};
+      ops[n++] = snd;
+      ops[n++] = rcv;
+    }
+  }
+  return n;
+}
+
+static void lbmi_sel_make(const int8_t cv[][3], int nvel, int reduced,
+			  lbmi_halo_sel_t * sx) {
+  memset(sx, 0, sizeof(*sx));
+  for (int p = 0; p < nvel; p++) {
+    if (!reduced || cv[p][X] == +1) sx->lo[sx->nlo++] = (int8_t) p;
+    if (!reduced || cv[p][X] == -1) sx->hi[sx->nhi++] = (int8_t) p;
+  }
+}
+
+int lbmi_x_schedule(const lbmi_options_t * opts, int scheme, int packed,
+		    lbmi_xop_t * ops, int maxops, int * nops) {
+  int8_t cv[LBMI_NVEL_MAX][3];
+  double wv[LBMI_NVEL_MAX], na[LBMI_NVEL_MAX];
+  double * ma = NULL;
+  lbmi_halo_sel_t sx;
+  lbmi_xop_t tmp[LBMI_XOPS_MAX];
+  long long psz, ns;
+  int n;
+
+  if (opts == NULL || ops == NULL || nops == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (opts->nvel != 19 && opts->nvel != 27) return lbmi_fail(LBMI_ERR_UNSUPPORTED, "nvel = %d", opts->nvel);
+  if (scheme != LBMI_HALO_FULL && scheme != LBMI_HALO_REDUCED) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
+  }
+  if (opts->cartsz < 1 || opts->cartrank < 0 || opts->cartrank >= opts->cartsz ||
+      opts->nhalo < 1 || opts->nlocal[X] < 1 || opts->nlocal[Y] < 1 || opts->nlocal[Z] < 1) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_x_schedule: bad options");
+  }
+  ma = (double *) malloc(sizeof(double)*LBMI_NVEL_MAX*LBMI_NVEL_MAX);
+  if (ma == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "malloc");
+  lbmi_k_model(opts->nvel, &cv[0][0], wv, na, ma);
+  free(ma);
+  lbmi_sel_make(cv, opts->nvel, scheme == LBMI_HALO_REDUCED, &sx);
+  psz = (long long) (opts->nlocal[Y] + 2*opts->nhalo)*(opts->nlocal[Z] + 2*opts->nhalo);
+  ns = psz*(opts->nlocal[X] + 2*opts->nhalo);
+  n = lbmi_x_ops(opts->cartsz, opts->cartrank, &sx, psz, ns, opts->nhalo,
+		 opts->nlocal[X], packed, 0, tmp);
+  if (n > maxops) return lbmi_fail(LBMI_ERR_ARGUMENT, "%d operations, room for %d", n, maxops);
+  memcpy(ops, tmp, sizeof(lbmi_xop_t)*(size_t) n);
+  *nops = n;
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  In-process ring: N handles on ONE device in ONE process, one thread per
+ *  handle, stand in for N ranks. A send posts (pointer, count, "data ready"
+ *  event) into the FIFO of its directed pair; the matching receive -- the
+ *  next one issued towards that peer, RCCL's rule -- waits for the post,
+ *  makes its stream wait for the event and copies device to device; the end
+ *  of the group makes the sender's stream wait until its buffers have been
+ *  read. Everything else of a slab step (kernels, schedule, overlap, streams)
+ *  is the code that runs over RCCL.
+ *
+ *****************************************************************************/
+
+enum {RING_SLOTS = 128};
+enum {RING_FREE = 0, RING_POSTED = 1, RING_CONSUMED = 2};
+
+typedef struct ring_msg_s {
+  const double * ptr;
+  size_t count;
+  hipEvent_t ready;                  /* recorded by the sender: data complete */
+  hipEvent_t done;                   /* recorded by the receiver: data read */
+  int state;
+} ring_msg_t;
+
+typedef struct ring_fifo_s {
+  ring_msg_t slot[RING_SLOTS];
+  unsigned posted;                   /* messages posted so far (sender) */
+  unsigned taken;                    /* messages consumed so far (receiver) */
+  unsigned released;                 /* messages released so far (sender) */
+} ring_fifo_t;
+
+struct lbmi_ring_s {
+  int nranks;
+  int nattached;
+  int failed;
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  ring_fifo_t * fifo;                /* [src*nranks + dst] */
+};
+
+int lbmi_ring_create(int nranks, lbmi_ring_t ** ring) {
+  lbmi_ring_t * r = NULL;
+  if (ring == NULL || nranks < 1) return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_ring_create");
+  *ring = NULL;
+  r = (lbmi_ring_t *) calloc(1, sizeof(lbmi_ring_t));
+  if (r == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "calloc");
+  r->nranks = nranks;
+  r->fifo = (ring_fifo_t *) calloc((size_t) nranks*nranks, sizeof(ring_fifo_t));
+  if (r->fifo == NULL) { free(r); return lbmi_fail(LBMI_ERR_ARGUMENT, "calloc"); }
+  pthread_mutex_init(&r->mu, NULL);
+  pthread_cond_init(&r->cv, NULL);
+  *ring = r;
+  return 0;
+}
+
+int lbmi_ring_free(lbmi_ring_t * r) {
+  if (r == NULL) return 0;
+  if (r->nattached > 0) return lbmi_fail(LBMI_ERR_STATE, "%d handles still use the ring", r->nattached);
+  for (int n = 0; n < r->nranks*r->nranks; n++) {
+    for (int k = 0; k < RING_SLOTS; k++) {
+      if (r->fifo[n].slot[k].ready) hipEventDestroy(r->fifo[n].slot[k].ready);
+      if (r->fifo[n].slot[k].done) hipEventDestroy(r->fifo[n].slot[k].done);
+    }
+  }
+  pthread_cond_destroy(&r->cv);
+  pthread_mutex_destroy(&r->mu);
+  free(r->fifo);
+  free(r);
+  return 0;
+}
+
+/* A rank that gives up outside an exchange (its driver failed) releases the
+ * others: their exchanges return LBMI_ERR_STATE from then on */
+
+int lbmi_ring_abort(lbmi_ring_t * r) {
+  if (r == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  pthread_mutex_lock(&r->mu);
+  r->failed = 1;
+  pthread_cond_broadcast(&r->cv);
+  pthread_mutex_unlock(&r->mu);
+  return 0;
+}
+
+/* A rank that fails inside an exchange must not leave the others waiting */
+
+static int ring_fail(lbmi_ring_t * r, int code, const char * what) {
+  r->failed = 1;
+  pthread_cond_broadcast(&r->cv);
+  pthread_mutex_unlock(&r->mu);
+  return lbmi_fail(code, "in-process ring: %s", what);
+}
+
+static int ring_sendrecv(lbmi_ring_t * r, int me, const lbmi_xop_t * ops,
+			 int nops, double * const base[5], hipStream_t st) {
+  unsigned first_mine[LBMI_XOPS_MAX];   /* per op: index of my send in its fifo */
+
+  pthread_mutex_lock(&r->mu);
+  /* sends never wait for the peer */
+  for (int n = 0; n < nops; n++) {
+    ring_fifo_t * q;
+    ring_msg_t * m;
+    if (ops[n].kind != LBMI_XOP_SEND) continue;
+    q = &r->fifo[me*r->nranks + ops[n].peer];
+    if (q->posted - q->released >= RING_SLOTS) return ring_fail(r, LBMI_ERR_STATE, "too many sends in flight");
+    m = &q->slot[q->posted % RING_SLOTS];
+    if (m->ready == NULL &&
+	(hipEventCreateWithFlags(&m->ready, hipEventDisableTiming) != hipSuccess ||
+	 hipEventCreateWithFlags(&m->done, hipEventDisableTiming) != hipSuccess)) {
+      return ring_fail(r, LBMI_ERR_HIP, "hipEventCreate");
+    }
+    m->ptr = base[ops[n].buffer] + ops[n].offset;
+    m->count = (size_t) ops[n].count;
+    if (hipEventRecord(m->ready, st) != hipSuccess) return ring_fail(r, LBMI_ERR_HIP, "hipEventRecord");
+    m->state = RING_POSTED;
+    first_mine[n] = q->posted;
+    q->posted += 1;
+  }
+  pthread_cond_broadcast(&r->cv);
+
+  /* receives: the k-th from a peer takes the k-th message that peer posted */
+  for (int n = 0; n < nops; n++) {
+    ring_fifo_t * q;
+    ring_msg_t * m;
+    if (ops[n].kind != LBMI_XOP_RECV) continue;
+    q = &r->fifo[ops[n].peer*r->nranks + me];
+    while (q->posted == q->taken && !r->failed) pthread_cond_wait(&r->cv, &r->mu);
+    if (r->failed) { pthread_mutex_unlock(&r->mu); return lbmi_fail(LBMI_ERR_STATE, "in-process ring: another rank failed"); }
+    m = &q->slot[q->taken % RING_SLOTS];
+    if (m->count != (size_t) ops[n].count) return ring_fail(r, LBMI_ERR_STATE, "a receive met a send of another length");
+    if (hipStreamWaitEvent(st, m->ready, 0) != hipSuccess ||
+	hipMemcpyAsync(base[ops[n].buffer] + ops[n].offset, m->ptr,
+		       sizeof(double)*m->count, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+	hipEventRecord(m->done, st) != hipSuccess) {
+      return ring_fail(r, LBMI_ERR_HIP, "device-to-device copy");
+    }
+    m->state = RING_CONSUMED;
+    q->taken += 1;
+    pthread_cond_broadcast(&r->cv);
+  }
+
+  /* the send buffers may be reused in stream order once they have been read */
+  for (int n = 0; n < nops; n++) {
+    ring_fifo_t * q;
+    ring_msg_t * m;
+    if (ops[n].kind != LBMI_XOP_SEND) continue;
+    q = &r->fifo[me*r->nranks + ops[n].peer];
+    while (q->taken <= first_mine[n] && !r->failed) pthread_cond_wait(&r->cv, &r->mu);
+    if (r->failed) { pthread_mutex_unlock(&r->mu); return lbmi_fail(LBMI_ERR_STATE, "in-process ring: another rank failed"); }
+    m = &q->slot[first_mine[n] % RING_SLOTS];
+    if (hipStreamWaitEvent(st, m->done, 0) != hipSuccess) return ring_fail(r, LBMI_ERR_HIP, "hipStreamWaitEvent");
+    m->state = RING_FREE;
+    q->released += 1;
+  }
+  pthread_mutex_unlock(&r->mu);
+  return 0;
+}
+
+/* Execute a schedule: RCCL (ncclSend/ncclRecv in one group, on st) or the
+ * in-process ring. base: sendlo, sendhi, recvlo, recvhi, the array. */
+
+static int lbmi_x_sendrecv(lbmi_t * lb, const lbmi_xop_t * ops, int nops,
+			   double * const base[5], hipStream_t st) {
+  if (lb->ring) {
+    return ring_sendrecv(lb->ring, lb->opts.cartrank, ops, nops, base, st);
+  }
+  NCCLCHECK(ncclGroupStart());
+  for (int n = 0; n < nops; n++) {
+    double * p = base[ops[n].buffer] + ops[n].offset;
+    if (ops[n].kind == LBMI_XOP_SEND) {
+      NCCLCHECK(ncclSend(p, (size_t) ops[n].count, ncclDouble, ops[n].peer, lb->comm, st));
+    }
+    else {
+      NCCLCHECK(ncclRecv(p, (size_t) ops[n].count, ncclDouble, ops[n].peer, lb->comm, st));
+    }
+  }
+  NCCLCHECK(ncclGroupEnd());
+  return 0;
+}
+
+/* One X exchange of `data` (nswap layer `layer`): the reference's pinned-host
+ * staging + MPI (halo_swap.c:762-881) as device-to-device messages.
+ * buf: the four staging buffers to use. unpack = 0 leaves what arrived in
+ * the receive buffers; packed_already: the send buffers are up to date. */
+
+static int lbmi_x_exchange_buf(lbmi_t * lb, const lbmi_halo_sel_t * sel,
+			       double * data, int blocked, int layer,
+			       double * const buf[4], int packed_already,
+			       int unpack, hipStream_t st) {
+  lbmi_xop_t ops[LBMI_XOPS_MAX];
+  double * base[5] = {buf[0], buf[1], buf[2], buf[3], data};
+  const int packed = (lb->x_packed || blocked || !unpack || packed_already);
+  int nops, ifail;
 
   if (!lb->have_comm) {
     return lbmi_fail(LBMI_ERR_STATE, "cartsz = %d but lbmi_comm_init() has "
 		     "not been called", lb->opts.cartsz);
   }
-
-  if (!lb->x_packed && !blocked) {
-    /* Zero-copy: X is the slowest index, so the boundary plane of ONE
-     * component is a contiguous run of strx doubles. Every component goes
-     * straight from the interior plane of this rank into the halo plane of
-     * the neighbour: no pack/unpack kernels, no staging buffers. The order
-     * of the operations towards one peer is the same on both sides (lo
-     * components first, then hi), which is what matches sends to receives,
-     * also when prev == next (2 ranks) or prev == next == self (1 rank). */
-    size_t last = (size_t) (nh + lb->kp.nlocal[X] - 1 - layer)*psz;
-    size_t first = (size_t) (nh + layer)*psz;
-    size_t halo_lo = (size_t) (nh - 1 - layer)*psz;
-    size_t halo_hi = (size_t) (nh + lb->kp.nlocal[X] + layer)*psz;
-    NCCLCHECK(ncclGroupStart());
-    for (int k = 0; k < sel->nlo; k++) {
-      double * d = data + ns*(size_t) sel->lo[k];
-      NCCLCHECK(ncclSend(d + last, psz, ncclDouble, next, lb->comm, st));
-      NCCLCHECK(ncclRecv(d + halo_lo, psz, ncclDouble, prev, lb->comm, st));
-    }
-    for (int k = 0; k < sel->nhi; k++) {
-      double * d = data + ns*(size_t) sel->hi[k];
-      NCCLCHECK(ncclSend(d + first, psz, ncclDouble, prev, lb->comm, st));
-      NCCLCHECK(ncclRecv(d + halo_hi, psz, ncclDouble, next, lb->comm, st));
-    }
-    NCCLCHECK(ncclGroupEnd());
-    return 0;
+  if (packed && ((size_t) lb->kp.strx*(size_t) sel->nlo > lb->xbuf_doubles ||
+		 (size_t) lb->kp.strx*(size_t) sel->nhi > lb->xbuf_doubles)) {
+    return lbmi_fail(LBMI_ERR_STATE, "halo buffers too small");
   }
-
-  /* Packed variant: one message per direction through staging buffers */
-  {
-    size_t nlo = psz*(size_t) sel->nlo;   /* arrives in / leaves for low halos */
-    size_t nhi = psz*(size_t) sel->nhi;
-
-    if (nlo > lb->xbuf_doubles || nhi > lb->xbuf_doubles) {
-      return lbmi_fail(LBMI_ERR_STATE, "halo buffers too small");
-    }
-
-    /* sendlo: first interior plane, components sel->hi -> prev's high halo
-     * sendhi: last interior plane, components sel->lo  -> next's low halo */
-    KCHECK(lbmi_k_halo_pack_x(&lb->kp, sel, data, lb->sendlo, lb->sendhi, blocked,
+  nops = lbmi_x_ops(lb->opts.cartsz, lb->opts.cartrank, sel, lb->kp.strx,
+		    lb->kp.nsite, lb->kp.nhalo, lb->kp.nlocal[X], packed, layer,
+		    ops);
+  if (packed && !packed_already) {
+    KCHECK(lbmi_k_halo_pack_x(&lb->kp, sel, data, buf[0], buf[1], blocked,
 			      layer, st));
-
-    NCCLCHECK(ncclGroupStart());
-    NCCLCHECK(ncclSend(lb->sendhi, nlo, ncclDouble, next, lb->comm, st));
-    NCCLCHECK(ncclRecv(lb->recvlo, nlo, ncclDouble, prev, lb->comm, st));
-    NCCLCHECK(ncclSend(lb->sendlo, nhi, ncclDouble, prev, lb->comm, st));
-    NCCLCHECK(ncclRecv(lb->recvhi, nhi, ncclDouble, next, lb->comm, st));
-    NCCLCHECK(ncclGroupEnd());
-
-    KCHECK(lbmi_k_halo_unpack_x(&lb->kp, sel, data, lb->recvlo, lb->recvhi, blocked,
+  }
+  ifail = lbmi_x_sendrecv(lb, ops, nops, base, st);
+  if (ifail) return ifail;
+  if (packed && unpack) {
+    KCHECK(lbmi_k_halo_unpack_x(&lb->kp, sel, data, buf[2], buf[3], blocked,
 				layer, st));
   }
-
   return 0;
+}
+
+static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
+			   double * data, int blocked, int layer,
+			   hipStream_t st) {
+  double * const buf[4] = {lb->sendlo, lb->sendhi, lb->recvlo, lb->recvhi};
+  return lbmi_x_exchange_buf(lb, sel, data, blocked, layer, buf, 0, 1, st);
 }
 
 static int lbmi_halo_generic(lbmi_t * lb, const lbmi_halo_sel_t sel[3],
@@ -1022,6 +1336,7 @@ int lbmi_lb_bind(lbmi_t * lb, double * f, double * fprime) {
     lb->f = NULL;
   lb->fprime = NULL;
   lb->hydro_stale = 0;
+  lb->xsend_valid = 0;
   lb->pending_halo = 0;
   lb->pending_prop = 0;
   lb->layout_swapped = 0;
@@ -1062,6 +1377,10 @@ static void lbmi_swapf(lbmi_t * lb) {        /* lb_model_swapf */
   double * tmp = lb->f;
   lb->f = lb->fprime;
   lb->fprime = tmp;
+  /* another array is current: what the last boundary launch of a slab left
+   * in the send buffers belongs to the old one (lbmi_fused_step sets the
+   * flag again after its own swap) */
+  lb->xsend_valid = 0;
 }
 
 /* INPLACE is honoured on a single rank without a communicator; with slabs
@@ -1116,6 +1435,7 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
   const int xlo = nh;
   const int xhi = nh + lb->kp.nlocal[X] - 1;
   const int wrapmask = lbmi_wrapmask(lb);
+  int xsend = 0;
   int ifail;
 
   ifail = lbmi_time_begin(lb);
@@ -1125,7 +1445,7 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
     /* the halo swap has been done (and anything may have bounced back into
      * it): pull from the array as it is, halo sites included */
     KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, 0, 0,
-				    xlo, xhi, 0, -1, lb->stream));
+				    xlo, xhi, 0, -1, NULL, lb->stream));
   }
   else if (lb->opts.cartsz == 1 && !lb->have_comm) {
     /* lay: 0 SoA -> SoA; 1 SoA -> blocked; 2 blocked -> blocked */
@@ -1145,7 +1465,7 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
       lb->kp.nt_store = (bytes > ((size_t) 256 << 20)) ? 1 : 0;
     }
     KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				    lay, xlo, xhi, 0, -1, lb->stream));
+				    lay, xlo, xhi, 0, -1, NULL, lb->stream));
     lb->blocked = (lay != 0);
   }
   else {
@@ -1167,38 +1487,57 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
       size_t bytes = 2*sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel;
       lb->kp.nt_store = (bytes > ((size_t) 256 << 20)) ? 1 : 0;
     }
-    HIPCHECK(hipEventRecord(lb->ev_ready, lb->stream));
-    KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				    lay, xlo + 1, xhi - 1, 0, -1, lb->stream));
+    {
+      /* x_direct (default): the boundary launch reads what arrived straight
+       * from the receive buffers and leaves what the NEXT exchange sends in
+       * the send buffers, so a steady-state step is: interior launch beside
+       * (messages, then ONE boundary launch) -- no pack, no unpack kernel.
+       * Otherwise: pack, messages, unpack into the halo planes of f. */
+      const int direct = (lb->x_direct && lb->x_packed);
+      const int detail = (lb->timing_now && lb->nd < LBMI_NDETAIL);
+      const lbmi_xbuf_t xbuf = {lb->fx[2], lb->fx[3], lb->fx[0], lb->fx[1]};
+      const lbmi_xbuf_t * xb = direct ? &xbuf : NULL;
+      hipStream_t bst = lb->x_concurrent ? lb->bnd_stream : lb->stream;
 
-    /* comm stream: exchange the boundary planes into the x halo planes */
-    HIPCHECK(hipStreamWaitEvent(lb->comm_stream, lb->ev_ready, 0));
-    ifail = lbmi_x_exchange(lb, &lb->sel_reduced[X], lb->f, lb->blocked, 0,
-			    lb->comm_stream);
-    if (ifail) return ifail;
-    HIPCHECK(hipEventRecord(lb->ev_halo, lb->comm_stream));
-
-    if (lb->x_concurrent) {
-      /* The two boundary planes depend on the state of the previous step
-       * (complete at ev_ready) and on the halo, not on the interior launch
-       * of THIS step (they write other planes of fprime): run them on a
-       * third stream beside it, so that a step costs the interior kernel,
-       * not interior + boundary + two stream hand-overs. The compute stream
-       * joins at the end: whatever follows sees the whole of fprime. */
-      HIPCHECK(hipStreamWaitEvent(lb->bnd_stream, lb->ev_ready, 0));
-      HIPCHECK(hipStreamWaitEvent(lb->bnd_stream, lb->ev_halo, 0));
+      HIPCHECK(hipEventRecord(lb->ev_ready, lb->stream));
+      if (detail) HIPCHECK(hipEventRecord(lb->evd[0][lb->nd], lb->stream));
       KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				      lay, xlo, xlo, xhi, (xhi > xlo) ? xhi : xhi - 1,
-				      lb->bnd_stream));
-      HIPCHECK(hipEventRecord(lb->ev_bnd, lb->bnd_stream));
-      HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_bnd, 0));
-    }
-    else {
-      /* both boundary planes in one launch, after the halo has arrived */
-      HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_halo, 0));
-      KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
-				      lay, xlo, xlo, xhi, (xhi > xlo) ? xhi : xhi - 1,
+				      lay, xlo + 1, xhi - 1, 0, -1, NULL,
 				      lb->stream));
+      if (detail) HIPCHECK(hipEventRecord(lb->evd[1][lb->nd], lb->stream));
+
+      /* comm stream: the boundary planes of f are final at ev_ready */
+      HIPCHECK(hipStreamWaitEvent(lb->comm_stream, lb->ev_ready, 0));
+      if (detail) HIPCHECK(hipEventRecord(lb->evd[2][lb->nd], lb->comm_stream));
+      ifail = lbmi_x_exchange_buf(lb, &lb->sel_reduced[X], lb->f, lb->blocked,
+				  0, lb->fx, direct && lb->xsend_valid,
+				  !direct, lb->comm_stream);
+      if (ifail) return ifail;
+      if (detail) HIPCHECK(hipEventRecord(lb->evd[3][lb->nd], lb->comm_stream));
+      HIPCHECK(hipEventRecord(lb->ev_halo, lb->comm_stream));
+
+      /* The two boundary planes depend on the state of the previous step
+       * (complete at ev_ready) and on what arrived, not on the interior
+       * launch of THIS step (they write other planes of fprime): with
+       * x_concurrent they run on a third stream beside it, so that a step
+       * costs the interior kernel, not interior + boundary + two stream
+       * hand-overs. The compute stream joins at the end: whatever follows
+       * sees the whole of fprime. */
+      if (lb->x_concurrent) HIPCHECK(hipStreamWaitEvent(bst, lb->ev_ready, 0));
+      HIPCHECK(hipStreamWaitEvent(bst, lb->ev_halo, 0));
+      if (detail) HIPCHECK(hipEventRecord(lb->evd[4][lb->nd], bst));
+      KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
+				      lay, xlo, xlo, xhi, (xhi > xlo) ? xhi : xhi - 1,
+				      xb, bst));
+      if (detail) {
+	HIPCHECK(hipEventRecord(lb->evd[5][lb->nd], bst));
+	lb->nd += 1;
+      }
+      if (lb->x_concurrent) {
+	HIPCHECK(hipEventRecord(lb->ev_bnd, lb->bnd_stream));
+	HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_bnd, 0));
+      }
+      xsend = direct;            /* of fprime, which becomes f below */
     }
     lb->blocked = (lay != 0);
   }
@@ -1207,6 +1546,7 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
   if (ifail) return ifail;
 
   lbmi_swapf(lb);
+  lb->xsend_valid = xsend;
 
   return 0;
 }
@@ -1317,6 +1657,7 @@ static int lbmi_lb_collide_dev(lbmi_t * lb, const lbmi_hydro_dev_t * hp) {
     int ifail = lbmi_unblock(lb);
     if (ifail) return ifail;
   }
+  lb->xsend_valid = 0;               /* f changes in place */
   KCHECK(lbmi_k_collide(&lb->kp, lb->f, &h, lb->stream));
 
   return 0;
@@ -1975,6 +2316,7 @@ int lbmi_lb_collide_fe(lbmi_t * lb, const lbmi_hydro_t * hydro,
   }
   ifail = lbmi_lb_flush(lb);
   if (ifail) return ifail;
+  lb->xsend_valid = 0;
   KCHECK(lbmi_k_collide_fe(&lb->kp, lb->f, &h, fe->a, fe->b, fe->kappa,
 			   fe->phi, fe->grad, fe->delsq, lb->stream));
   return 0;
@@ -2364,6 +2706,7 @@ int lbmi_lb_memcpy_h2d(lbmi_t * lb, const double * f_host) {
   lb->halo_seen = 0;
   lb->halo_done = 0;
   lb->blocked = 0;
+  lb->xsend_valid = 0;
   HIPCHECK(hipMemcpyAsync(lb->f, f_host, sz, hipMemcpyHostToDevice, lb->stream));
   HIPCHECK(hipStreamSynchronize(lb->stream));
   return 0;
@@ -2666,6 +3009,7 @@ int lbmi_lb_records_unpack(lbmi_t * lb, const double * records) {
   lb->halo_seen = 0;
   lb->halo_done = 0;
   lb->blocked = 0;
+  lb->xsend_valid = 0;
   if (lb->layout_swapped) {
     lb->layout_swapped = 0;
   }
@@ -2903,10 +3247,37 @@ int lbmi_comm_unique_id(void * id) {
   return 0;
 }
 
+/* The buffers of the X exchange: four plane buffers large enough for every
+ * component (full scheme, or a generic field of up to LBMI_NVEL_MAX
+ * components), and the four of the FUSED step (reduced selection) */
+
+static int lbmi_comm_buffers(lbmi_t * lb) {
+  size_t bytes;
+  int nred = lb->sel_reduced[X].nlo > lb->sel_reduced[X].nhi
+    ? lb->sel_reduced[X].nlo : lb->sel_reduced[X].nhi;
+  lb->xbuf_doubles = (size_t) lb->kp.strx*LBMI_NVEL_MAX;
+  bytes = sizeof(double)*lb->xbuf_doubles;
+  if (hipMalloc((void **) &lb->sendlo, bytes) != hipSuccess ||
+      hipMalloc((void **) &lb->sendhi, bytes) != hipSuccess ||
+      hipMalloc((void **) &lb->recvlo, bytes) != hipSuccess ||
+      hipMalloc((void **) &lb->recvhi, bytes) != hipSuccess) {
+    return lbmi_fail(LBMI_ERR_HIP, "hipMalloc (halo staging buffers) failed");
+  }
+  bytes = sizeof(double)*(size_t) lb->kp.strx*(size_t) nred;
+  for (int k = 0; k < 4; k++) {
+    if (hipMalloc((void **) &lb->fx[k], bytes) != hipSuccess ||
+	hipMemset(lb->fx[k], 0, bytes) != hipSuccess) {
+      return lbmi_fail(LBMI_ERR_HIP, "hipMalloc (exchange buffers of the fused step) failed");
+    }
+  }
+  lb->xsend_valid = 0;
+  return 0;
+}
+
 int lbmi_comm_init(lbmi_t * lb, const void * id) {
 
   ncclUniqueId nid;
-  size_t bytes;
+  int ifail;
 
   if (lb == NULL || id == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (lb->have_comm) return lbmi_fail(LBMI_ERR_STATE, "communicator exists");
@@ -2917,18 +3288,62 @@ int lbmi_comm_init(lbmi_t * lb, const void * id) {
 			     lb->opts.cartrank));
   lb->have_comm = 1;
 
-  /* four plane buffers large enough for every component (full scheme,
-   * or a generic field of up to LBMI_NVEL_MAX components) */
-  lb->xbuf_doubles = (size_t) lb->kp.strx*LBMI_NVEL_MAX;
-  bytes = sizeof(double)*lb->xbuf_doubles;
-  if (hipMalloc((void **) &lb->sendlo, bytes) != hipSuccess ||
-      hipMalloc((void **) &lb->sendhi, bytes) != hipSuccess ||
-      hipMalloc((void **) &lb->recvlo, bytes) != hipSuccess ||
-      hipMalloc((void **) &lb->recvhi, bytes) != hipSuccess) {
-    lbmi_comm_free(lb);
-    return lbmi_fail(LBMI_ERR_HIP, "hipMalloc (halo staging buffers) failed");
-  }
+  ifail = lbmi_comm_buffers(lb);
+  if (ifail) lbmi_comm_free(lb);
+  return ifail;
+}
 
+/* The same ring inside one process: every handle of it on one device, driven
+ * by a thread of its own (an exchange waits for the neighbours' posts) */
+
+int lbmi_comm_init_ring(lbmi_t * lb, lbmi_ring_t * ring) {
+  int ifail;
+  if (lb == NULL || ring == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->have_comm) return lbmi_fail(LBMI_ERR_STATE, "communicator exists");
+  if (ring->nranks != lb->opts.cartsz) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "a ring of %d for cartsz = %d",
+		     ring->nranks, lb->opts.cartsz);
+  }
+  if (ring->nranks > 1 && lb->stream != lb->own_stream) {
+    /* on a stream shared by the ranks, the work of one queues up behind the
+     * waits of another for data that one has yet to send */
+    return lbmi_fail(LBMI_ERR_STATE, "a ring of several handles in one "
+		     "process needs each on its own stream (lbmi_set_stream "
+		     "has given this one the caller's)");
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  pthread_mutex_lock(&ring->mu);
+  ring->nattached += 1;
+  pthread_mutex_unlock(&ring->mu);
+  lb->ring = ring;
+  lb->have_comm = 1;
+  ifail = lbmi_comm_buffers(lb);
+  if (ifail) lbmi_comm_free(lb);
+  return ifail;
+}
+
+/* Ranks of the ring this handle exchanges with, and the transport */
+
+int lbmi_comm_info(lbmi_t * lb, int * nranks, int * rank, int * transport) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (nranks) *nranks = 0;
+  if (rank) *rank = -1;
+  if (transport) *transport = 0;
+  if (!lb->have_comm) return 0;
+  if (lb->ring) {
+    if (nranks) *nranks = lb->ring->nranks;
+    if (rank) *rank = lb->opts.cartrank;
+    if (transport) *transport = 2;
+    return 0;
+  }
+  {
+    int n = 0, r = -1;
+    NCCLCHECK(ncclCommCount(lb->comm, &n));
+    NCCLCHECK(ncclCommUserRank(lb->comm, &r));
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (transport) *transport = 1;
+  }
   return 0;
 }
 
@@ -2940,7 +3355,20 @@ int lbmi_comm_free(lbmi_t * lb) {
     if (lb->recvlo) hipFree(lb->recvlo);
     if (lb->recvhi) hipFree(lb->recvhi);
     lb->sendlo = lb->sendhi = lb->recvlo = lb->recvhi = NULL;
-    ncclCommDestroy(lb->comm);
+    for (int k = 0; k < 4; k++) {
+      if (lb->fx[k]) hipFree(lb->fx[k]);
+      lb->fx[k] = NULL;
+    }
+    lb->xsend_valid = 0;
+    if (lb->ring) {
+      pthread_mutex_lock(&lb->ring->mu);
+      lb->ring->nattached -= 1;
+      pthread_mutex_unlock(&lb->ring->mu);
+      lb->ring = NULL;
+    }
+    else {
+      ncclCommDestroy(lb->comm);
+    }
     lb->have_comm = 0;
   }
   return 0;

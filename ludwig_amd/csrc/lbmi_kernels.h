@@ -61,6 +61,17 @@ typedef struct lbmi_halo_sel_s {
   int8_t hi[LBMI_NVEL_MAX];   /* components wanted in the high halo plane */
 } lbmi_halo_sel_t;
 
+/* The buffers of the X exchange of a slab, as the boundary launch of a FUSED
+ * step uses them: [k][plane site] of strx doubles per component, k-th
+ * population with c_x = +1 (recvlo, sendhi) or c_x = -1 (recvhi, sendlo) */
+
+typedef struct lbmi_xbuf_s {
+  const double * recvlo;     /* from the lower neighbour: its last interior plane */
+  const double * recvhi;     /* from the upper neighbour: its first interior plane */
+  double * sendlo;           /* our first interior plane -> lower neighbour */
+  double * sendhi;           /* our last interior plane -> upper neighbour */
+} lbmi_xbuf_t;
+
 /* All launchers return hipError_t as int (0 = hipSuccess) */
 
 int lbmi_k_collide(const lbmi_kparam_t * kp, double * f,
@@ -74,11 +85,15 @@ int lbmi_k_propagate(const lbmi_kparam_t * kp, const double * f,
  * wrapmask: bit d set = wrap direction d by index arithmetic. */
 /* lay: 0 SoA -> SoA; 1 SoA -> blocked; 2 blocked -> blocked (the blocked
  * order [site/256][p][site%256] needs wrapmask != 0 in every direction that
- * is pulled across: single GPU) */
+ * is pulled across: single GPU).
+ * xb != NULL (slabs; the planes launched are the first and/or last interior
+ * plane): populations that cross the X faces come from xb->recvlo / recvhi
+ * instead of the halo planes of f, and those the next exchange sends are
+ * stored into xb->sendlo / sendhi as well. */
 int lbmi_k_propagate_collide(const lbmi_kparam_t * kp, const double * f,
 			     double * fprime, const lbmi_hydro_dev_t * h,
 			     int wrapmask, int lay, int xlo, int xhi, int xlo2,
-			     int xhi2, void * stream);
+			     int xhi2, const lbmi_xbuf_t * xb, void * stream);
 int lbmi_k_blocked_sites(const lbmi_kparam_t * kp);
 /* rho, u of the collision that left the post-collision state f (SoA, or the
  * blocked order): u = (sum f'_p c_p - F/2)/rho at interior fluid sites */

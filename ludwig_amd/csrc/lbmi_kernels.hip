@@ -654,6 +654,22 @@ __device__ __forceinline__ size_t faddr(size_t ns, int p, int i) {
   }
 }
 
+/* Slabs: the boundary launch of a FUSED step takes the populations that
+ * cross the X faces straight from the receive buffers of the exchange
+ * ([k][plane site], k-th population with c_x = +1 from the lower neighbour,
+ * c_x = -1 from the upper one, in p order: the reduced selection of
+ * model.c:1192-1219) instead of from halo planes somebody has unpacked them
+ * into, and leaves the populations the NEXT exchange will send in the send
+ * buffers instead of having a pack kernel collect them. */
+
+template <int NVEL> __host__ __device__ constexpr int xrank(int p, int cx) {
+  int k = 0;
+  for (int q = 0; q < p; q++) {
+    if (Model<NVEL>::c(q, 0) == cx) k += 1;
+  }
+  return k;
+}
+
 template <int NVEL>
 struct PulledSite {
   double fl[NVEL];
@@ -661,10 +677,11 @@ struct PulledSite {
 };
 
 /* phase 1: issue the NVEL pulls of site i */
-template <int NVEL, bool WRAP, bool RB>
+template <int NVEL, bool WRAP, bool RB, bool XB>
 __device__ __forceinline__
 void pc_pull(const lbmi_kparam_t & kp, const double * __restrict__ f,
-	     int wrapmask, int i, PulledSite<NVEL> & ps) {
+	     int wrapmask, int i, PulledSite<NVEL> & ps,
+	     const lbmi_xbuf_t & xb) {
 
   using M = Model<NVEL>;
   ps.s = decode(kp, i);
@@ -718,6 +735,21 @@ void pc_pull(const lbmi_kparam_t & kp, const double * __restrict__ f,
 	if constexpr (cz ==  1) off -= wlo[2];
 	if constexpr (cz == -1) off -= whi[2];
       }
+      if constexpr (XB && cx == 1) {
+	/* first interior plane: i - off lies in the low halo plane */
+	if (s.x == kp.nhalo) {
+	  constexpr int k = xrank<NVEL>(p, 1);
+	  ps.fl[p] = xb.recvlo[(size_t) k*kp.strx + (i - off - (kp.nhalo - 1)*kp.strx)];
+	  return;
+	}
+      }
+      if constexpr (XB && cx == -1) {
+	if (s.x == kp.nhalo + kp.nlocal[0] - 1) {
+	  constexpr int k = xrank<NVEL>(p, -1);
+	  ps.fl[p] = xb.recvhi[(size_t) k*kp.strx + (i - off - (kp.nhalo + kp.nlocal[0])*kp.strx)];
+	  return;
+	}
+      }
       ps.fl[p] = ldf(&f[faddr<NVEL, RB>(ns, p, i - off)]);
     });
   }
@@ -728,11 +760,11 @@ void pc_pull(const lbmi_kparam_t & kp, const double * __restrict__ f,
  * step has no hydro traffic (no force field to read, rho and u not wanted
  * now): a variant of its own, so that it is also a kernel of its own name in
  * a profile */
-template <int NVEL, int SCHEME, bool WB, bool NTS, bool HIO>
+template <int NVEL, int SCHEME, bool WB, bool NTS, bool HIO, bool XB>
 __device__ __forceinline__
 void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
 		      const lbmi_hydro_dev_t & h, int i,
-		      PulledSite<NVEL> & ps) {
+		      PulledSite<NVEL> & ps, const lbmi_xbuf_t & xb) {
 
   const size_t ns = (size_t) kp.nsite;
   bool active = ps.s.interior;
@@ -783,17 +815,45 @@ void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
       stf(&fp[faddr<NVEL, WB>(ns, P, i)], ps.fl[P]);
     }
   });
+
+  if constexpr (XB) {
+    /* what the next exchange sends: of the first interior plane the
+     * populations that leave downwards (-> the lower neighbour's recvhi), of
+     * the last one those that leave upwards; whole planes, y/z halo lanes
+     * included (nobody reads those entries: y and z wrap by index) */
+    using M = Model<NVEL>;
+    if (ps.s.x == kp.nhalo) {
+      const int j = i - kp.nhalo*kp.strx;
+      static_for<0, NVEL>([&](auto P) {
+	constexpr int p = P;
+	if constexpr (M::c(p,0) == -1) {
+	  constexpr int k = xrank<NVEL>(p, -1);
+	  xb.sendlo[(size_t) k*kp.strx + j] = ps.fl[p];
+	}
+      });
+    }
+    if (ps.s.x == kp.nhalo + kp.nlocal[0] - 1) {
+      const int j = i - (kp.nhalo + kp.nlocal[0] - 1)*kp.strx;
+      static_for<0, NVEL>([&](auto P) {
+	constexpr int p = P;
+	if constexpr (M::c(p,0) == 1) {
+	  constexpr int k = xrank<NVEL>(p, 1);
+	  xb.sendhi[(size_t) k*kp.strx + j] = ps.fl[p];
+	}
+      });
+    }
+  }
 }
 
 /* LAY & 3: 0 SoA -> SoA, 1 SoA -> blocked, 2 blocked -> blocked;
  * LAY & 4: nontemporal stores of fprime */
 
-template <int NVEL, int SCHEME, bool WRAP, int LAY, bool HIO>
+template <int NVEL, int SCHEME, bool WRAP, int LAY, bool HIO, bool XB>
 __global__ __launch_bounds__(BLOCK, LBMI_WAVES)
 void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
 			 double * __restrict__ fp, lbmi_hydro_dev_t h,
 			 int wrapmask, int i0, int i1, unsigned nblk,
-			 int j0, int j1, unsigned nblk_first) {
+			 int j0, int j1, unsigned nblk_first, lbmi_xbuf_t xb) {
 
   unsigned lb;
   if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
@@ -820,13 +880,13 @@ void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
     constexpr int k = K;
     i[k] = i0a + (int) (lb*(BLOCK*SPT) + k*BLOCK + threadIdx.x);
     if (i[k] >= i0 && i[k] < i1) {
-      pc_pull<NVEL, WRAP, ORD == 2>(kp, f, wrapmask, i[k], ps[k]);
+      pc_pull<NVEL, WRAP, ORD == 2, XB>(kp, f, wrapmask, i[k], ps[k], xb);
     }
   });
   static_for<0, SPT>([&](auto K) {
     constexpr int k = K;
     if (i[k] >= i0 && i[k] < i1) {
-      pc_collide_store<NVEL, SCHEME, ORD != 0, (LAY & 4) != 0, HIO>(kp, fp, h, i[k], ps[k]);
+      pc_collide_store<NVEL, SCHEME, ORD != 0, (LAY & 4) != 0, HIO, XB>(kp, fp, h, i[k], ps[k], xb);
     }
   });
 }
@@ -2140,10 +2200,10 @@ int launch_collide(const lbmi_kparam_t & kp, double * f,
   return (int) hipGetLastError();
 }
 
-template <int NVEL, bool WRAP, int LAY, bool HIO>
+template <int NVEL, bool WRAP, int LAY, bool HIO, bool XB>
 int launch_pc_hio(const lbmi_kparam_t & kp, const double * f, double * fp,
-	      const lbmi_hydro_dev_t & h, int wrapmask, int i0, int i1,
-	      int j0, int j1, hipStream_t st) {
+		  const lbmi_hydro_dev_t & h, int wrapmask, int i0, int i1,
+		  int j0, int j1, hipStream_t st, const lbmi_xbuf_t & xb) {
   constexpr int ALIGNV = ((LAY & 3) == 0) ? LBMI_ALIGN : LBW;
   static_assert((LAY & 3) == 0 || BLOCK*SPT == LBW, "blocked order: one thread block per layout block");
   const int i0a = (i0/ALIGNV)*ALIGNV;
@@ -2162,10 +2222,10 @@ int launch_pc_hio(const lbmi_kparam_t & kp, const double * f, double * fp,
   if (lds > 65536u) {
     /* above 64 KiB the limit must be raised per kernel */
     const void * fn = nullptr;
-    if (kp.scheme == LBMI_M10) fn = (const void *) k_propagate_collide<NVEL, LBMI_M10, WRAP, LAY, HIO>;
-    if (kp.scheme == LBMI_BGK) fn = (const void *) k_propagate_collide<NVEL, LBMI_BGK, WRAP, LAY, HIO>;
+    if (kp.scheme == LBMI_M10) fn = (const void *) k_propagate_collide<NVEL, LBMI_M10, WRAP, LAY, HIO, XB>;
+    if (kp.scheme == LBMI_BGK) fn = (const void *) k_propagate_collide<NVEL, LBMI_BGK, WRAP, LAY, HIO, XB>;
     if constexpr (NVEL == 19) {
-      if (kp.scheme == LBMI_TRT) fn = (const void *) k_propagate_collide<NVEL, LBMI_TRT, WRAP, LAY, HIO>;
+      if (kp.scheme == LBMI_TRT) fn = (const void *) k_propagate_collide<NVEL, LBMI_TRT, WRAP, LAY, HIO, XB>;
     }
     if (fn) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
@@ -2174,20 +2234,20 @@ int launch_pc_hio(const lbmi_kparam_t & kp, const double * f, double * fp,
   }
   switch (kp.scheme) {
   case LBMI_M10:
-    hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_M10, WRAP, LAY, HIO>), grid,
+    hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_M10, WRAP, LAY, HIO, XB>), grid,
 		       block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk,
-		       j0, j1, nblk_first);
+		       j0, j1, nblk_first, xb);
     break;
   case LBMI_BGK:
-    hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_BGK, WRAP, LAY, HIO>), grid,
+    hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_BGK, WRAP, LAY, HIO, XB>), grid,
 		       block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk,
-		       j0, j1, nblk_first);
+		       j0, j1, nblk_first, xb);
     break;
   case LBMI_TRT:
     if constexpr (NVEL == 19) {
-      hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_TRT, WRAP, LAY, HIO>), grid,
+      hipLaunchKernelGGL((k_propagate_collide<NVEL, LBMI_TRT, WRAP, LAY, HIO, XB>), grid,
 			 block, lds, st, kp, f, fp, h, wrapmask, i0, i1, nblk,
-			 j0, j1, nblk_first);
+			 j0, j1, nblk_first, xb);
       break;
     }
     return (int) hipErrorInvalidValue;
@@ -2200,29 +2260,38 @@ int launch_pc_hio(const lbmi_kparam_t & kp, const double * f, double * fp,
 template <int NVEL, bool WRAP, int LAY>
 int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
 	      const lbmi_hydro_dev_t & h, int wrapmask, int i0, int i1,
-	      int j0, int j1, hipStream_t st) {
-  if (h.force == nullptr && h.rho == nullptr && h.u == nullptr) {
-    return launch_pc_hio<NVEL, WRAP, LAY, false>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
+	      int j0, int j1, hipStream_t st, const lbmi_xbuf_t * xb) {
+  const bool hio = (h.force != nullptr || h.rho != nullptr || h.u != nullptr);
+  const lbmi_xbuf_t none = {nullptr, nullptr, nullptr, nullptr};
+  if constexpr (WRAP && (LAY & 4) == 0) {
+    /* the boundary planes of a slab against the exchange buffers */
+    if (xb != nullptr) {
+      if (hio) return launch_pc_hio<NVEL, WRAP, LAY, true, true>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st, *xb);
+      return launch_pc_hio<NVEL, WRAP, LAY, false, true>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st, *xb);
+    }
   }
-  return launch_pc_hio<NVEL, WRAP, LAY, true>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
+  if (xb != nullptr) return (int) hipErrorInvalidValue;
+  if (hio) return launch_pc_hio<NVEL, WRAP, LAY, true, false>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st, none);
+  return launch_pc_hio<NVEL, WRAP, LAY, false, false>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st, none);
 }
 
 template <int NVEL>
 int launch_pc_any(const lbmi_kparam_t & kp, const double * f, double * fp,
 		  const lbmi_hydro_dev_t & h, int wrapmask, int lay, int i0,
-		  int i1, int j0, int j1, hipStream_t st) {
+		  int i1, int j0, int j1, hipStream_t st,
+		  const lbmi_xbuf_t * xb) {
   if (!wrapmask) {
-    if (lay != 0) return (int) hipErrorInvalidValue;
-    return launch_pc<NVEL, false, 0>(kp, f, fp, h, 0, i0, i1, j0, j1, st);
+    if (lay != 0 || xb != nullptr) return (int) hipErrorInvalidValue;
+    return launch_pc<NVEL, false, 0>(kp, f, fp, h, 0, i0, i1, j0, j1, st, nullptr);
   }
-  if (lay == 0) return launch_pc<NVEL, true, 0>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
+  if (lay == 0) return launch_pc<NVEL, true, 0>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st, xb);
 #if LBMI_BLOCK*LBMI_SPT == 256
-  if (kp.nt_store & 1) {
-    if (lay == 1) return launch_pc<NVEL, true, 5>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
-    if (lay == 2) return launch_pc<NVEL, true, 6>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
+  if ((kp.nt_store & 1) && xb == nullptr) {
+    if (lay == 1) return launch_pc<NVEL, true, 5>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st, nullptr);
+    if (lay == 2) return launch_pc<NVEL, true, 6>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st, nullptr);
   }
-  if (lay == 1) return launch_pc<NVEL, true, 1>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
-  if (lay == 2) return launch_pc<NVEL, true, 2>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
+  if (lay == 1) return launch_pc<NVEL, true, 1>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st, xb);
+  if (lay == 2) return launch_pc<NVEL, true, 2>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st, xb);
 #endif
   return (int) hipErrorInvalidValue;
 }
@@ -2556,6 +2625,7 @@ extern "C" int lbmi_k_propagate_collide(const lbmi_kparam_t * kp,
 					const lbmi_hydro_dev_t * h,
 					int wrapmask, int lay, int xlo,
 					int xhi, int xlo2, int xhi2,
+					const lbmi_xbuf_t * xb,
 					void * stream) {
   hipStream_t st = (hipStream_t) stream;
   if (xhi < xlo) {
@@ -2570,10 +2640,10 @@ extern "C" int lbmi_k_propagate_collide(const lbmi_kparam_t * kp,
     j1 = (xhi2 + 1)*kp->strx;
   }
   if (kp->nvel == 19) {
-    return launch_pc_any<19>(*kp, f, fprime, *h, wrapmask, lay, i0, i1, j0, j1, st);
+    return launch_pc_any<19>(*kp, f, fprime, *h, wrapmask, lay, i0, i1, j0, j1, st, xb);
   }
   if (kp->nvel == 27) {
-    return launch_pc_any<27>(*kp, f, fprime, *h, wrapmask, lay, i0, i1, j0, j1, st);
+    return launch_pc_any<27>(*kp, f, fprime, *h, wrapmask, lay, i0, i1, j0, j1, st, xb);
   }
   return (int) hipErrorInvalidValue;
 }

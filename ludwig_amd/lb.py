@@ -540,6 +540,25 @@ class LB:
         _l.check(_l.library().lbmi_comm_unique_id(buf))
         return buf.raw
 
+    def comm_init_ring(self, ring):
+        """Join an in-process ring (lbmi_comm_init_ring) instead of RCCL."""
+        _l.check(self._lib.lbmi_comm_init_ring(self._h, ring._r))
+
+    def comm_info(self):
+        """(ranks of the ring, own rank, transport: 0 none, 1 RCCL, 2 in-process)"""
+        n, r, t = ctypes.c_int(0), ctypes.c_int(-1), ctypes.c_int(0)
+        _l.check(self._lib.lbmi_comm_info(self._h, ctypes.byref(n),
+                                          ctypes.byref(r), ctypes.byref(t)))
+        return n.value, r.value, t.value
+
+    def timing_read_detail(self):
+        """Average ms of (interior launch, exchange, boundary launch) over the
+        sampled slab steps, and the number of samples."""
+        ms = (ctypes.c_double * 3)()
+        n = ctypes.c_int(0)
+        _l.check(self._lib.lbmi_timing_read_detail(self._h, ms, ctypes.byref(n)))
+        return [ms[0], ms[1], ms[2]], n.value
+
     def comm_init(self, unique_id):
         buf = ctypes.create_string_buffer(bytes(unique_id), _l.UNIQUE_ID_BYTES)
         _l.check(self._lib.lbmi_comm_init(self._h, buf))
@@ -558,6 +577,51 @@ def io_filename(directory, stub, timestep):
     _l.check(_l.library().lbmi_io_filename(str(directory).encode(),
                                            stub.encode(), int(timestep), buf, 1024))
     return buf.value.decode()
+
+
+class Ring:
+    """lbmi_ring_t: cartsz handles of ONE process on one device as the ranks
+    of the X ring (one thread each; LB(..., own_stream=True))."""
+
+    def __init__(self, nranks):
+        self._lib = _l.library()
+        self._r = ctypes.c_void_p()
+        _l.check(self._lib.lbmi_ring_create(int(nranks), ctypes.byref(self._r)))
+        self.nranks = int(nranks)
+
+    def abort(self):
+        """A rank's driver has failed: release the others from their waits."""
+        if self._r:
+            self._lib.lbmi_ring_abort(self._r)
+
+    def free(self):
+        if self._r:
+            _l.check(self._lib.lbmi_ring_free(self._r))
+            self._r = ctypes.c_void_p()
+
+
+def x_schedule(nvel, nlocal, nhalo, cartsz, cartrank, scheme=HALO_REDUCED,
+               packed=True):
+    """lbmi_x_schedule: the point-to-point operations of one X exchange of a
+    rank, in issue order, as dicts (kind 'send'|'recv', peer, buffer 'sendlo'|
+    'sendhi'|'recvlo'|'recvhi'|'data', offset, count). Pure host: no GPU."""
+    lib = _l.library()
+    opts = _l.Options()
+    _l.check(lib.lbmi_options_default(ctypes.byref(opts)))
+    opts.nvel = nvel
+    opts.nlocal[:] = list(nlocal)
+    opts.nhalo = nhalo
+    opts.cartsz = cartsz
+    opts.cartrank = cartrank
+    ops = (_l.XOp * 128)()
+    n = ctypes.c_int(0)
+    _l.check(lib.lbmi_x_schedule(ctypes.byref(opts), int(scheme), int(bool(packed)),
+                                 ctypes.cast(ops, ctypes.c_void_p), 128,
+                                 ctypes.byref(n)))
+    names = ("sendlo", "sendhi", "recvlo", "recvhi", "data")
+    return [{"kind": "send" if ops[k].kind == 0 else "recv", "peer": ops[k].peer,
+             "buffer": names[ops[k].buffer], "offset": int(ops[k].offset),
+             "count": int(ops[k].count)} for k in range(n.value)]
 
 
 def model(nvel):

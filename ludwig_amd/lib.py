@@ -39,6 +39,17 @@ class HydroPtrs(ctypes.Structure):
     ]
 
 
+class XOp(ctypes.Structure):
+    """lbmi_xop_t: one point-to-point operation of the X exchange"""
+    _fields_ = [
+        ("kind", ctypes.c_int),
+        ("peer", ctypes.c_int),
+        ("buffer", ctypes.c_int),
+        ("offset", ctypes.c_longlong),
+        ("count", ctypes.c_longlong),
+    ]
+
+
 class FeSymm(ctypes.Structure):
     """lbmi_fe_symm_t"""
     _fields_ = [
@@ -140,10 +151,19 @@ SYMBOLS = [
     ("lbmi_set_stream", _i, [_vp, _vp]),
     ("lbmi_timing", _i, [_vp, _i]),
     ("lbmi_timing_read", _i, [_vp, _pd, ctypes.POINTER(_i)]),
+    ("lbmi_timing_read_detail", _i, [_vp, _pd, ctypes.POINTER(_i)]),
     ("lbmi_tune", _i, [_vp, ctypes.c_char_p, _i]),
     ("lbmi_comm_unique_id", _i, [_vp]),
     ("lbmi_comm_init", _i, [_vp, _vp]),
     ("lbmi_comm_free", _i, [_vp]),
+    ("lbmi_comm_info", _i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i),
+                            ctypes.POINTER(_i)]),
+    ("lbmi_x_schedule", _i, [ctypes.POINTER(Options), _i, _i, _vp, _i,
+                             ctypes.POINTER(_i)]),
+    ("lbmi_ring_create", _i, [_i, ctypes.POINTER(_vp)]),
+    ("lbmi_comm_init_ring", _i, [_vp, _vp]),
+    ("lbmi_ring_free", _i, [_vp]),
+    ("lbmi_ring_abort", _i, [_vp]),
 ]
 
 

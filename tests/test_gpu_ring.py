@@ -1,0 +1,213 @@
+"""N ranks of the slab decomposition on ONE GPU: an in-process ring of N
+handles (lbmi_ring_t, one thread per rank) runs the product's multi-GPU step
+-- interior launch, pack / exchange schedule / boundary launch against the
+exchange buffers, three streams per rank -- with device-to-device copies in
+place of ncclSend / ncclRecv (RCCL refuses two ranks on one device). The
+schedule executed is lbmi_x_ops, the one RCCL gets (tests/test_slab_gloo.py
+drives the same list over gloo on the CPU). Compared with the single-domain
+oracle, including the two-rank case where previous and next rank coincide."""
+
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lb_oracle as lbo                       # noqa: E402
+from tests.common import interior, relmax                  # noqa: E402
+
+FBODY = (2e-6, -1e-6, 1e-6)
+
+
+def _oracle(nvel, ntotal, nsteps, scheme="m10", force=None):
+    p = lbo.make_param(nvel, ntotal, 1, scheme, 0.1, 0.3 if scheme == "m10" else 0.1,
+                       1.0, FBODY)
+    f = lbo.init_synthetic(p)
+    fp = np.zeros_like(f)
+    rho = np.zeros(lbo.nall(p))
+    u = np.zeros((3,) + tuple(lbo.nall(p)))
+    for _ in range(nsteps):
+        f, fp = lbo.step(p, f, fp, force=force, rho=rho, u=u)
+    return p, f, rho, u
+
+
+def _run_ring(world, nvel, ntotal, nsteps, mode, tune=(), scheme="m10",
+              force=None, lazy=False, observe=None):
+    """Each rank in a thread of its own. Returns per rank the interior f, rho,
+    u, the local moments, what `observe(lb, hy, rank, step)` returned, and the
+    ring size the handle reported."""
+    import ludwig_amd
+    import torch
+    ring = ludwig_amd.Ring(world)
+    out = [None] * world
+    err = []
+    start = threading.Barrier(world)
+
+    def rank_main(rank):
+        try:
+            dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, 1)
+            lb = ludwig_amd.LB(nvel, dec.nlocal, 1, mode=mode, cartsz=world,
+                               cartrank=rank, own_stream=True,
+                               halo_scheme=ludwig_amd.HALO_REDUCED)
+            lb.relaxation_set(scheme, 0.1, 0.3 if scheme == "m10" else 0.1)
+            lb.body_force_set(FBODY)
+            for k, v in tune:
+                lb.tune(k, v)
+            if lazy:
+                lb.tune("hydro_lazy", 1)
+            lb.comm_init_ring(ring)
+            p = lbo.make_param(nvel, dec.nlocal, 1, scheme, 0.1, 0.3, 1.0, FBODY)
+            f0 = lbo.init_synthetic(p, ntotal, dec.noffset)
+            fl = None
+            if force is not None:
+                fl = np.ascontiguousarray(
+                    force[:, dec.noffset[0]:dec.noffset[0] + dec.nlocal[0] + 2])
+            hy = ludwig_amd.Hydro(lb.nall, lb.device, force=fl)
+            lb.lb_memcpy_h2d(f0)
+            seen = []
+            start.wait()
+            for n in range(nsteps):
+                lb.lb_collide(hy)
+                lb.lb_halo()
+                lb.lb_propagation()
+                if observe is not None:
+                    seen.append(observe(lb, hy, rank, n))
+            if lazy:
+                lb.hydro_sync()
+            mo = lb.moments()
+            f = lb.lb_memcpy_d2h()
+            lb.synchronize()
+            torch.cuda.synchronize()
+            out[rank] = (interior(f, 1).copy(), interior(hy.rho.cpu().numpy(), 1),
+                         interior(hy.u.cpu().numpy(), 1), mo, seen, lb.comm_info())
+            start.wait()                 # nobody frees while a peer still reads
+            lb.free()
+        except Exception as e:           # noqa: BLE001
+            err.append((rank, repr(e)))
+            ring.abort()
+            start.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not err, err
+    assert all(not t.is_alive() for t in threads)
+    ring.free()                      # (refuses while a handle is attached)
+    return out
+
+
+def _join(out, k):
+    return np.concatenate([o[k] for o in out], axis=-3)
+
+
+@pytest.mark.parametrize("tune", [
+    (),                                              # the defaults: direct, packed, concurrent, blocked
+    (("x_direct", 0),),                              # pack, messages, unpack
+    (("x_direct", 0), ("x_packed", 0), ("blocked", 0)),   # zero-copy planes
+    (("x_concurrent", 0),),
+    (("blocked", 0),),
+], ids=["direct", "unpack", "zerocopy", "serial_boundary", "soa"])
+@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("nvel", [19, 27])
+def test_fused_slabs_equal_single_domain(nvel, world, tune):
+    ntotal = (12, 14, 14)            # slabs of 6, 4, 3 planes; 16 x 16 = 256 sites per plane
+    nsteps = 5
+    import ludwig_amd
+    out = _run_ring(world, nvel, ntotal, nsteps, ludwig_amd.FUSED, tune)
+    p, f, rho, u = _oracle(nvel, ntotal, nsteps)
+    assert relmax(_join(out, 0), interior(f, 1)) < 1e-12
+    assert relmax(_join(out, 1), interior(rho, 1)) < 1e-12
+    assert relmax(_join(out, 2), interior(u, 1)) < 1e-12
+    mref = lbo.moments(p, f)
+    assert abs(sum(o[3][1] for o in out) - mref[1]) / mref[1] < 1e-12
+    for o in out:
+        assert o[5][0] == world and o[5][2] == 2
+
+
+@pytest.mark.parametrize("mode_name", ["eager", "fused_halo"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_staged_modes_on_slabs(world, mode_name):
+    """lb_halo as a call of its own on slabs: X through the ring with the
+    full or reduced selection, then Y and Z."""
+    import ludwig_amd
+    mode = {"eager": ludwig_amd.EAGER, "fused_halo": ludwig_amd.FUSED_HALO}[mode_name]
+    ntotal, nsteps = (6, 7, 5), 4
+    out = _run_ring(world, 19, ntotal, nsteps, mode, scheme="bgk")
+    p, f, rho, u = _oracle(19, ntotal, nsteps, scheme="bgk")
+    assert relmax(_join(out, 0), interior(f, 1)) < 1e-12
+    assert relmax(_join(out, 2), interior(u, 1)) < 1e-12
+
+
+def test_one_plane_per_slab_and_thin_slabs():
+    """nlocal[X] = 1 (first and last interior plane are the same plane, no
+    interior launch) and 2 (no interior launch either)."""
+    import ludwig_amd
+    for world, ntotal in ((4, (4, 14, 14)), (3, (6, 6, 5))):
+        out = _run_ring(world, 19, ntotal, 4, ludwig_amd.FUSED)
+        p, f, rho, u = _oracle(19, ntotal, 4)
+        assert relmax(_join(out, 0), interior(f, 1)) < 1e-12
+
+
+def test_lazy_hydro_and_force_field_on_slabs():
+    import ludwig_amd
+    ntotal, nsteps, world = (8, 6, 7), 4, 2
+    rng = np.random.default_rng(5)
+    force = 1e-4 * (rng.random((3, ntotal[0] + 2, ntotal[1] + 2, ntotal[2] + 2)) - 0.5)
+    out = _run_ring(world, 19, ntotal, nsteps, ludwig_amd.FUSED, force=force, lazy=True)
+    p, f, rho, u = _oracle(19, ntotal, nsteps, force=force)
+    assert relmax(_join(out, 0), interior(f, 1)) < 1e-12
+    assert relmax(_join(out, 1), interior(rho, 1)) < 1e-12
+    assert relmax(_join(out, 2), interior(u, 1)) < 1e-12
+
+
+def test_observers_between_steps_do_not_disturb_the_exchange():
+    """A flush between two steps (moments, a copy out) invalidates what the
+    boundary launch left in the send buffers; a field halo in between uses
+    other buffers. Every observation equals the single domain's at that step."""
+    import ludwig_amd
+    import torch
+    ntotal, nsteps, world = (9, 6, 6), 6, 3
+    refs = {}
+    p = lbo.make_param(19, ntotal, 1, "m10", 0.1, 0.3, 1.0, FBODY)
+    f = lbo.init_synthetic(p)
+    fp = np.zeros_like(f)
+    for n in range(nsteps):
+        f, fp = lbo.step(p, f, fp)
+        refs[n] = interior(f, 1).copy()
+
+    def observe(lb, hy, rank, n):
+        if n == 1:
+            return ("f", lb.lb_memcpy_d2h())            # flush
+        if n == 2:
+            phi = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+            torch.cuda.synchronize()
+            lb.field_halo_n(phi, 1)                       # another exchange in between
+            lb.synchronize()
+            return None
+        if n == 4:
+            return ("m", lb.moments())                   # flush again
+        return None
+
+    out = _run_ring(world, 19, ntotal, nsteps, ludwig_amd.FUSED, observe=observe)
+    got1 = np.concatenate([interior(o[4][1][1], 1) for o in out], axis=1)
+    assert relmax(got1, refs[1]) < 1e-12
+    assert relmax(_join(out, 0), refs[nsteps - 1]) < 1e-12
+
+
+def test_ring_needs_own_streams_and_matching_size():
+    import ludwig_amd
+    from ludwig_amd.lib import LbmiError
+    ring = ludwig_amd.Ring(2)
+    lb = ludwig_amd.LB(19, (4, 6, 6), 1, mode=ludwig_amd.FUSED, cartsz=2, cartrank=0)
+    with pytest.raises(LbmiError, match="own stream"):
+        lb.comm_init_ring(ring)
+    lb.free()
+    lb = ludwig_amd.LB(19, (4, 6, 6), 1, mode=ludwig_amd.FUSED, cartsz=3, cartrank=0,
+                       own_stream=True)
+    with pytest.raises(LbmiError, match="ring of 2"):
+        lb.comm_init_ring(ring)
+    lb.free()
+    ring.free()

@@ -1,11 +1,18 @@
-"""The N > 1 path on CPU: two gloo ranks, each owning an X slab.
+"""The N > 1 path on CPU: gloo ranks, each owning an X slab, exchange their
+boundary planes by executing THE PRODUCT'S schedule -- lbmi_x_schedule
+(include/lbmi.h), the very list of sends and receives (peer, buffer, offset,
+count, order) that liblbmi issues as ncclSend / ncclRecv inside one group
+(lbmi_host.c: lbmi_x_ops -> lbmi_x_sendrecv). gloo's point-to-point matching
+is RCCL's: the k-th send towards a peer meets the k-th receive from it; no
+tags are used, so a schedule whose order does not pair up fails here -- also
+in the two-rank case, where the previous and the next rank are the same peer
+(test_a_wrong_order_is_noticed shows that it would).
 
-What this covers (host logic shared with the product): the slab
-decomposition (ludwig_amd.SlabDecomposition), the neighbour ring, which
-plane goes to which neighbour's halo, the message lengths, and that the
-slab-decomposed time step (X by exchange, Y/Z locally, in that order)
-equals the single-domain step. The arithmetic is the oracle's; the device
-kernels for the same exchange are tested in tests/test_gpu_parity.py.
+What is the test's own: packing the planes into the staging buffers by their
+documented layout ([k][plane site], components of the reduced or full
+selection in p order) and the oracle's arithmetic for the rest of the step.
+The device kernels behind the same schedule run in tests/test_gpu_ring.py.
+Replaces the reference's halo_swap.c:762-881.
 """
 
 import os
@@ -21,6 +28,8 @@ import ludwig_amd
 from oracle import lb_oracle as lbo
 from tests.common import interior
 
+FBODY = (1e-6, 0.0, -1e-6)
+
 
 def _free_port():
     s = socket.socket()
@@ -30,41 +39,67 @@ def _free_port():
     return port
 
 
-def _exchange_x(dec, f, nh):
-    """Periodic ring: last interior plane -> next's low halo; first interior
-    plane -> prev's high halo (halo_swap.c:762-784, 862-865). Full planes
-    including the y/z halo extents."""
-    lo_send = np.ascontiguousarray(f[:, nh])                  # first plane
-    hi_send = np.ascontiguousarray(f[:, nh + dec.nlocal[0] - 1])
-    lo_recv = np.empty_like(lo_send)
-    hi_recv = np.empty_like(hi_send)
-    assert lo_send[0].size == dec.plane_doubles(1)
-    ops = [
-        dist.P2POp(dist.isend, torch.from_numpy(hi_send), dec.next, tag=1),
-        dist.P2POp(dist.irecv, torch.from_numpy(lo_recv), dec.prev, tag=1),
-        dist.P2POp(dist.isend, torch.from_numpy(lo_send), dec.prev, tag=2),
-        dist.P2POp(dist.irecv, torch.from_numpy(hi_recv), dec.next, tag=2),
-    ]
-    for r in dist.batch_isend_irecv(ops):
+def _selection(cv, reduced):
+    if reduced:
+        return ludwig_amd.SlabDecomposition.reduced_populations(cv)
+    allp = list(range(len(cv)))
+    return allp, allp
+
+
+def _exchange_x(dec, f, nh, cv, reduced, packed, tamper=None):
+    """One X exchange of f (nvel, nall) by the product's schedule."""
+    nvel = f.shape[0]
+    scheme = ludwig_amd.HALO_REDUCED if reduced else ludwig_amd.HALO_FULL
+    ops = ludwig_amd.x_schedule(nvel, dec.nlocal, nh, dec.cartsz, dec.cartrank,
+                                scheme=scheme, packed=packed)
+    if tamper is not None:
+        ops = tamper(ops)
+    lo, hi = _selection(cv, reduced)          # fill a LOW halo / a HIGH halo
+    first, last = nh, nh + dec.nlocal[0] - 1
+    psz = dec.plane_doubles(1)
+    flat = f.reshape(-1)
+    assert flat.base is not None or flat is f  # a view: receives land in f
+    buf = {"data": flat}
+    if packed:
+        # include/lbmi.h: SENDHI = last interior plane, the components that
+        # fill a LOW halo, for the next rank; SENDLO = first interior plane,
+        # the components that fill a HIGH halo, for the previous rank
+        buf["sendhi"] = np.ascontiguousarray(f[lo, last]).reshape(-1)
+        buf["sendlo"] = np.ascontiguousarray(f[hi, first]).reshape(-1)
+        buf["recvlo"] = np.full(len(lo) * psz, np.nan)
+        buf["recvhi"] = np.full(len(hi) * psz, np.nan)
+        assert len(ops) == 4
+    else:
+        assert len(ops) == 2 * (len(lo) + len(hi))
+    p2p = []
+    for op in ops:
+        t = torch.from_numpy(buf[op["buffer"]])[op["offset"]:op["offset"] + op["count"]]
+        assert t.numel() == op["count"]
+        fn = dist.isend if op["kind"] == "send" else dist.irecv
+        p2p.append(dist.P2POp(fn, t, op["peer"]))
+    for r in dist.batch_isend_irecv(p2p):
         r.wait()
-    f[:, nh - 1] = lo_recv
-    f[:, nh + dec.nlocal[0]] = hi_recv
+    if packed:
+        f[lo, first - 1] = buf["recvlo"].reshape(len(lo), *f.shape[2:])
+        f[hi, last + 1] = buf["recvhi"].reshape(len(hi), *f.shape[2:])
 
 
-def _worker(rank, world, port, nvel, ntotal, nsteps, q):
+def _worker(rank, world, port, nvel, ntotal, nsteps, reduced, packed, tamper, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["GLOO_SOCKET_IFNAME"] = "lo"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         nh = 1
         dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, nh)
-        p = lbo.make_param(nvel, dec.nlocal, nh, "m10", 0.1, 0.3, 1.0,
-                           (1e-6, 0.0, -1e-6))
+        cv = lbo.model(nvel)["cv"]
+        p = lbo.make_param(nvel, dec.nlocal, nh, "m10", 0.1, 0.3, 1.0, FBODY)
         f = lbo.init_synthetic(p, ntotal, dec.noffset)
         fp = np.zeros_like(f)
+        tf = _TAMPER[tamper] if (tamper and rank == 0) else None
         for _ in range(nsteps):
             lbo.collide(p, f)
-            _exchange_x(dec, f, nh)      # X first ...
+            _exchange_x(dec, f, nh, cv, reduced, packed, tf)   # X first ...
             lbo.halo_yz(p, f)            # ... then Y, Z over the full extent
             lbo.propagate(p, f, fp)
             f, fp = fp, f
@@ -75,33 +110,98 @@ def _worker(rank, world, port, nvel, ntotal, nsteps, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nvel", [19, 27])
-def test_two_slabs_equal_single_domain(nvel):
-    world, ntotal, nsteps = 2, (8, 5, 6), 4
+def _swap_sends(ops):
+    """A schedule that sends downwards before upwards on ONE side only."""
+    sends = [k for k, op in enumerate(ops) if op["kind"] == "send"]
+    ops = list(ops)
+    ops[sends[0]], ops[sends[1]] = ops[sends[1]], ops[sends[0]]
+    return ops
+
+
+_TAMPER = {"swap_sends": _swap_sends}
+
+
+def _run(world, nvel, ntotal, nsteps, reduced, packed, tamper=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker,
-                         args=(r, world, port, nvel, ntotal, nsteps, q))
+                         args=(r, world, port, nvel, ntotal, nsteps, reduced,
+                               packed, tamper, q))
              for r in range(world)]
     for pr in procs:
         pr.start()
     res = {}
     for _ in range(world):
-        rank, fi, mo = q.get(timeout=120)
+        rank, fi, mo = q.get(timeout=180)
         res[rank] = (fi, mo)
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0
+    return res
 
-    p = lbo.make_param(nvel, ntotal, 1, "m10", 0.1, 0.3, 1.0, (1e-6, 0.0, -1e-6))
+
+def _single_domain(nvel, ntotal, nsteps):
+    p = lbo.make_param(nvel, ntotal, 1, "m10", 0.1, 0.3, 1.0, FBODY)
     f = lbo.init_synthetic(p)
     fp = np.zeros_like(f)
     for _ in range(nsteps):
         f, fp = lbo.step(p, f, fp)
-    ref = interior(f, 1)
-    got = np.concatenate([res[0][0], res[1][0]], axis=1)
-    assert np.array_equal(got, ref)       # same arithmetic, same order
+    return p, f
+
+
+@pytest.mark.parametrize("world,nvel,reduced,packed", [
+    (2, 19, True, True),        # the FUSED step's exchange; prev == next
+    (3, 19, True, True),
+    (2, 27, True, True),
+    (3, 27, False, True),       # lb_halo semantics: every population
+    (2, 19, True, False),       # zero-copy: one message per component
+    (3, 27, True, False),
+    (2, 19, False, False),
+])
+def test_slabs_equal_single_domain(world, nvel, reduced, packed):
+    ntotal, nsteps = ({2: 8, 3: 9}[world], 5, 6), 4
+    res = _run(world, nvel, ntotal, nsteps, reduced, packed)
+    p, f = _single_domain(nvel, ntotal, nsteps)
+    got = np.concatenate([res[r][0] for r in range(world)], axis=1)
+    assert np.array_equal(got, interior(f, 1))       # same arithmetic, same order
     mref = lbo.moments(p, f)[[0, 1, 5, 6, 7]]
     assert abs(res[0][1][1] - mref[1]) / mref[1] < 1e-14
-    assert np.array_equal(res[0][1], res[1][1])
+    for r in range(1, world):
+        assert np.array_equal(res[0][1], res[r][1])
+
+
+def test_a_wrong_order_is_noticed():
+    """Two ranks, one of them issuing its two sends in the other order: the
+    planes land in the wrong halos and the result is not the single domain's.
+    (What makes the test above a test of the product's ordering.)"""
+    world, nvel, ntotal, nsteps = 2, 19, (8, 5, 6), 2
+    res = _run(world, nvel, ntotal, nsteps, True, True, tamper="swap_sends")
+    _, f = _single_domain(nvel, ntotal, nsteps)
+    got = np.concatenate([res[r][0] for r in range(world)], axis=1)
+    assert not np.array_equal(got, interior(f, 1))
+
+
+def test_schedule_pairs_up_for_any_ring_size():
+    """Host-only: for 1 .. 8 ranks every send of the schedule has exactly one
+    receive on the peer that it meets under in-order matching, with the same
+    length, and the buffers are the ones the layout says (sendhi -> the next
+    rank's recvlo, sendlo -> the previous rank's recvhi)."""
+    for nvel in (19, 27):
+        for world in range(1, 9):
+            for packed in (True, False):
+                sched = [ludwig_amd.x_schedule(nvel, (4, 5, 6), 1, world, r, packed=packed)
+                         for r in range(world)]
+                for r in range(world):
+                    for peer in set(op["peer"] for op in sched[r]):
+                        sends = [op for op in sched[r] if op["kind"] == "send" and op["peer"] == peer]
+                        recvs = [op for op in sched[peer] if op["kind"] == "recv" and op["peer"] == r]
+                        assert len(sends) == len(recvs)
+                        for s, v in zip(sends, recvs):
+                            assert s["count"] == v["count"]
+                            if packed:
+                                want = {"sendhi": "recvlo", "sendlo": "recvhi"}[s["buffer"]]
+                                assert v["buffer"] == want
+                            if packed and world > 2:
+                                assert peer == ((r + 1) % world if s["buffer"] == "sendhi"
+                                                else (r - 1) % world)
