@@ -395,6 +395,12 @@ int lbmi_lb_state(lbmi_t * lb, int state[3]);
 int lbmi_lb_memcpy_h2d(lbmi_t * lb, const double * f_host);
 int lbmi_lb_memcpy_d2h(lbmi_t * lb, double * f_host);
 int lbmi_lb_moments(lbmi_t * lb, const char * status, double out[9]);
+/* lb_0th_moment (model.c:817-832) of every interior site of the first
+ * distribution, summed in p order as there, to a HOST array of
+ * nlocal[X]*nlocal[Y]*nlocal[Z] doubles in (ic, jc, kc) order: the numbers
+ * stats_distribution_print adds up (stats_distribution.c:73-88). A caller
+ * that adds them in that order prints the reference's CPU digits. */
+int lbmi_lb_density(lbmi_t * lb, double * rho_host);
 
 /* hydro->rho and hydro->u on demand (lbmi_tune "hydro_lazy", 1; FUSED and
  * FUSED_HALO): lbmi_lb_collide then does not store them (32 B/site per step)
@@ -482,6 +488,11 @@ int lbmi_cahn_hilliard(lbmi_t * lb, double a, double b, double kappa,
 		       double mobility, const double * phi,
 		       const double * delsq, const double * u,
 		       double * phi_out);
+/* dst <- src at the interior sites of an SoA device field of ncomp components
+ * (halo of dst untouched): puts phi_out back into phi for a caller that, like
+ * the reference, updates its order parameter in place. */
+int lbmi_field_interior_copy(lbmi_t * lb, int ncomp, const double * src,
+			     double * dst);
 
 /* lbmi_symmetric_force (from phi) and lbmi_cahn_hilliard (from phi) in ONE
  * pass: they share the seven (grad, delsq) evaluations around every site.

@@ -23,6 +23,12 @@
  *                        distributions they work on are the reference's
  *      lb_free(), field_free(), map_free(), wall_free(): the originals, after
  *                        forgetting what this file remembers of the object
+ *      stats_distribution_print(), stats_distribution_momentum()
+ *                        stats_distribution.h (stats_distribution.c:55-139): the
+ *                        density statistics and the Kahan-summed momentum
+ *      phi_force_calculation() phi_force.h, phi_cahn_hilliard()
+ *                        phi_cahn_hilliard.h: with LBMI_FE=1 and the symmetric
+ *                        free energy in the plain periodic fluid case
  *
  *  by unpacking lb_t / hydro_t / map_t and calling the C-ABI of
  *  include/lbmi.h. The other contents of collision.c / model.c /
@@ -43,7 +49,12 @@
  *  -Dphi_lb_to_field=phi_lb_to_field_ref, hydro.c with -Dhydro_u_zero=
  *  hydro_u_zero_ref -Dhydro_f_zero=hydro_f_zero_ref, field.c with -Dfield_halo=
  *  field_halo_ref -Dfield_free=field_free_ref, field_grad.c with
- *  -Dfield_grad_compute=field_grad_compute_ref) so that their originals remain
+ *  -Dfield_grad_compute=field_grad_compute_ref -Dfield_grad_free=
+ *  field_grad_free_ref, stats_distribution.c with
+ *  -Dstats_distribution_print=stats_distribution_print_ref
+ *  -Dstats_distribution_momentum=stats_distribution_momentum_ref, phi_force.c
+ *  with -Dphi_force_calculation=phi_force_calculation_ref, phi_cahn_hilliard.c
+ *  with -Dphi_cahn_hilliard=phi_cahn_hilliard_ref) so that their originals remain
  *  available as fall-backs (colloids, Lees-Edwards, host halo
  *  schemes, noise), and this file is compiled
  *  with the same -D_D3Q19_|-D_D3Q27_ -DADDR_SOA as the rest of libludwig.a
@@ -57,6 +68,7 @@
  *****************************************************************************/
 
 #include <assert.h>
+#include <float.h>
 #include <math.h>
 #include <stddef.h>
 #include <stdlib.h>
@@ -82,6 +94,12 @@
 #include "leesedwards.h"
 #include "bbl.h"
 #include "colloids.h"
+#include "stats_distribution.h"
+#include "phi_force.h"
+#include "phi_force_stress.h"
+#include "phi_cahn_hilliard.h"
+#include "advection.h"
+#include "fe_force_method.h"
 
 #include "lbmi.h"
 
@@ -101,11 +119,19 @@ int bounce_back_on_links_ref(bbl_t * bbl, lb_t * lb, wall_t * wall,
 int lb_free_ref(lb_t * lb);
 int field_free_ref(field_t * obj);
 int map_free_ref(map_t * obj);
+int stats_distribution_print_ref(lb_t * lb, map_t * map);
+int stats_distribution_momentum_ref(lb_t * lb, map_t * map, double g[3]);
+int phi_force_calculation_ref(pe_t * pe, cs_t * cs, lees_edw_t * le,
+			      wall_t * wall, pth_t * pth, fe_t * fe,
+			      map_t * map, field_t * phi, hydro_t * hydro);
+int phi_cahn_hilliard_ref(phi_ch_t * pch, fe_t * fe, field_t * phi,
+			  hydro_t * hydro, map_t * map, noise_t * noise);
 int phi_lb_to_field_ref(field_t * phi, lb_t * lb);
 int hydro_u_zero_ref(hydro_t * hydro, const double uzero[3]);
 int hydro_f_zero_ref(hydro_t * hydro, const double fzero[3]);
 int field_halo_ref(field_t * field);
 int field_grad_compute_ref(field_grad_t * fgrad);
+void field_grad_free_ref(field_grad_t * obj);
 
 /* One liblbmi handle per lb_t (Ludwig has one lb_t per rank) */
 
@@ -116,6 +142,7 @@ typedef struct shim_s {
   wall_t * wall;                  /* whose links the handle holds a copy of */
   int wall_nlink;
   int colloids;                   /* bounce_back_on_links has seen colloids */
+  int ncollide;                   /* bound collisions so far */
   int param_valid;                /* param_committed is what the device has */
   lb_collide_param_t param_committed;
 } shim_t;
@@ -193,6 +220,14 @@ static void shim_forget(const void * obj) {
   }
 }
 
+/* the gradient arrays of a field_grad_t: keyed by the address of the host
+ * member, forgotten with the field they belong to */
+
+static void shim_grad_arrays(field_grad_t * fg, double ** grad, double ** delsq) {
+  *grad = (double *) shim_cached(&fg->grad, &fg->target->grad, sizeof(double *));
+  *delsq = (double *) shim_cached(&fg->delsq, &fg->target->delsq, sizeof(double *));
+}
+
 static double * shim_field_data(field_t * field) {
   return (double *) shim_cached(field, &field->target->data, sizeof(double *));
 }
@@ -267,6 +302,8 @@ static lbmi_t * shim_handle(lb_t * lb) {
         shim_.wall = NULL;
     shim_.wall_nlink = 0;
     shim_.param_valid = 0;
+    shim_.colloids = 0;
+    shim_.ncollide = 0;
 
     shim_device_f(lb, &f, &fprime);
     SHIM_CHECK(lb, lbmi_lb_bind(shim_.h, f, fprime));
@@ -398,9 +435,12 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
      * subgrid_force_from_particles (colloids, ludwig.c:2071, 2149) -- is
      * outside the library: with a free energy or colloids the force is taken
      * to have been written every step. */
-    if (fe != NULL || shim_.colloids) {
+    if (fe != NULL || shim_.colloids || shim_.ncollide == 0) {
+      /* (the first collision: colloids show at the first
+       * bounce_back_on_links, after it) */
       SHIM_CHECK(lb, lbmi_hydro_field_dirty(h, hy.force));
     }
+    shim_.ncollide += 1;
 
     if (lb->ndist == 2 || (fe && fe->use_stress_relaxation)) {
       /* lb_collision_binary (collision.c:610-1027), or the single-fluid
@@ -414,10 +454,7 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
       bin.kappa = param.kappa;
       physics_mobility(phys, &bin.mobility);
       bin.phi = shim_field_data(fs->phi);
-      tdpAssert(tdpMemcpy(&bin.grad, &fs->dphi->target->grad, sizeof(double *),
-			  tdpMemcpyDeviceToHost));
-      tdpAssert(tdpMemcpy(&bin.delsq, &fs->dphi->target->delsq,
-			  sizeof(double *), tdpMemcpyDeviceToHost));
+      shim_grad_arrays(fs->dphi, (double **) &bin.grad, (double **) &bin.delsq);
       if (lb->ndist == 2) {
 	SHIM_CHECK(lb, lbmi_lb_collide_binary(h, &hy, &bin));
       }
@@ -591,6 +628,14 @@ int field_free(field_t * obj) {
   return field_free_ref(obj);
 }
 
+void field_grad_free(field_grad_t * obj) {
+  if (obj) {
+    shim_forget(&obj->grad);
+    shim_forget(&obj->delsq);
+  }
+  field_grad_free_ref(obj);
+}
+
 int map_free(map_t * obj) {
   shim_forget(obj);
   return map_free_ref(obj);
@@ -664,6 +709,11 @@ int lb_propagation(lb_t * lb) {
 int lb_memcpy(lb_t * lb, tdpMemcpyKind flag) {
 
   assert(lb);
+
+  /* ludwig.c:507 copies the initial distributions to the device before the
+   * first step: the handle comes into being here, so that the free-energy
+   * sector of the first step and the report of step 0 are already bound */
+  if (flag == tdpMemcpyHostToDevice && shim_supported(lb)) (void) shim_handle(lb);
 
   if (shim_.h && shim_.lb == lb) {
     SHIM_CHECK(lb, lbmi_lb_flush(shim_.h));
@@ -836,10 +886,7 @@ int field_grad_compute(field_grad_t * fgrad) {
       (fgrad->field->le && lees_edw_nplane_total(fgrad->field->le) > 0)) {
     return field_grad_compute_ref(fgrad);
   }
-  tdpAssert(tdpMemcpy(&grad, &fgrad->target->grad, sizeof(double *),
-		      tdpMemcpyDeviceToHost));
-  tdpAssert(tdpMemcpy(&delsq, &fgrad->target->delsq, sizeof(double *),
-		      tdpMemcpyDeviceToHost));
+  shim_grad_arrays(fgrad, &grad, &delsq);
   if (npt == 7) {
     SHIM_CHECK(shim_.lb, lbmi_field_grad_7pt(h, shim_field_data(fgrad->field),
 					     grad, delsq));
@@ -848,5 +895,247 @@ int field_grad_compute(field_grad_t * fgrad) {
     SHIM_CHECK(shim_.lb, lbmi_field_grad_27pt(h, shim_field_data(fgrad->field),
 					      grad, delsq));
   }
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  stats_distribution_print, stats_distribution_momentum
+ *  (stats_distribution.c:55-139, 201-350): row a17
+ *
+ *  The reference walks over the HOST copy of f for the density statistics and
+ *  runs distribution_gm_kernel -- one compare-and-swap lock per block around a
+ *  serial Kahan loop -- for the momentum. Here the density of every interior
+ *  site comes from the device (summed in p order, as lb_0th_moment) and is
+ *  added up on the host in the reference's site order, so the line printed
+ *  is the reference's to the last digit (its variance is a difference of
+ *  nearly equal sums: the order of the additions shows in it); the momentum
+ *  is the library's shuffle + LDS + two-stage Kahan reduction. Both flush a
+ *  deferred propagation first: they do not depend on an lb_memcpy in front.
+ *
+ *****************************************************************************/
+
+int stats_distribution_print(lb_t * lb, map_t * map) {
+
+  assert(lb);
+  assert(map);
+
+  if (!shim_supported(lb) || shim_.h == NULL || shim_.lb != lb) {
+    return stats_distribution_print_ref(lb, map);
+  }
+
+  {
+    int nlocal[3];
+    size_t n = 0;
+    double stat_local[5] = {0.0, 0.0, 0.0, +DBL_MAX, -DBL_MAX};
+    double stat_total[5];
+    double rhomean, rhovar;
+    double * rho = NULL;
+    MPI_Comm comm;
+
+    cs_nlocal(lb->cs, nlocal);
+    pe_mpi_comm(lb->pe, &comm);
+    rho = (double *) malloc(sizeof(double)*(size_t) nlocal[X]*nlocal[Y]*nlocal[Z]);
+    if (rho == NULL) pe_fatal(lb->pe, "liblbmi: malloc(rho) failed\n");
+    SHIM_CHECK(lb, lbmi_lb_density(shim_.h, rho));
+    shim_sync_pointers(lb, shim_.h);              /* a flush may have swapped */
+
+    for (int ic = 1; ic <= nlocal[X]; ic++) {     /* stats_distribution.c:73-88 */
+      for (int jc = 1; jc <= nlocal[Y]; jc++) {
+	for (int kc = 1; kc <= nlocal[Z]; kc++, n++) {
+	  int status = MAP_FLUID;
+	  map_status(map, cs_index(lb->cs, ic, jc, kc), &status);
+	  if (status != MAP_FLUID) continue;
+	  stat_local[0] += 1.0;
+	  stat_local[1] += rho[n];
+	  stat_local[2] += rho[n]*rho[n];
+	  stat_local[3] = dmin(rho[n], stat_local[3]);
+	  stat_local[4] = dmax(rho[n], stat_local[4]);
+	}
+      }
+    }
+    free(rho);
+
+    MPI_Reduce(stat_local, stat_total, 3, MPI_DOUBLE, MPI_SUM, 0, comm);
+    MPI_Reduce(stat_local + 3, stat_total + 3, 1, MPI_DOUBLE, MPI_MIN, 0, comm);
+    MPI_Reduce(stat_local + 4, stat_total + 4, 1, MPI_DOUBLE, MPI_MAX, 0, comm);
+
+    rhomean = stat_total[1]/stat_total[0];
+    rhovar  = (stat_total[2]/stat_total[0]) - rhomean*rhomean;
+
+    pe_info(lb->pe, "\nScalars - total mean variance min max\n");
+    pe_info(lb->pe, "[rho] %14.2f %14.11f %14.7e %14.11f %14.11f\n",
+	    stat_total[1], rhomean, fabs(rhovar), stat_total[3], stat_total[4]);
+  }
+
+  return 0;
+}
+
+int stats_distribution_momentum(lb_t * lb, map_t * map, double g[3]) {
+
+  assert(lb);
+  assert(map);
+  assert(g);
+
+  if (!shim_supported(lb) || shim_.h == NULL || shim_.lb != lb) {
+    return stats_distribution_momentum_ref(lb, map, g);
+  }
+
+  {
+    double out[9];
+    double glocal[3];
+    char * status = (char *) shim_cached(map, &map->target->status, sizeof(char *));
+    MPI_Comm comm;
+
+    pe_mpi_comm(lb->pe, &comm);
+    SHIM_CHECK(lb, lbmi_lb_moments(shim_.h, status, out));
+    shim_sync_pointers(lb, shim_.h);
+    /* the rank's compensated sums; across ranks a plain sum (the reference
+     * merges the compensation terms as well, stats_distribution.c:245-262) */
+    glocal[X] = out[5]; glocal[Y] = out[6]; glocal[Z] = out[7];
+    g[X] = 0.0; g[Y] = 0.0; g[Z] = 0.0;
+    MPI_Reduce(glocal, g, 3, MPI_DOUBLE, MPI_SUM, 0, comm);
+  }
+
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  phi_force_calculation (phi_force.c:74-136), phi_cahn_hilliard
+ *  (phi_cahn_hilliard.c:206-284): row f2, with LBMI_FE=1
+ *
+ *  One kernel each in place of pth_stress_compute + pth_force_fluid_driver
+ *  (a 9-component stress array in between) and of advection_x + the flux
+ *  kernels + the update (four flux arrays in between). Only in the case the
+ *  replacements were written and tested for -- anything else is the original:
+ *  symmetric free energy, force by stress divergence, finite-difference order
+ *  parameter (one distribution), no walls, no porous medium, no colloids, no
+ *  Lees-Edwards planes, no order-parameter noise, no external chemical-
+ *  potential gradient, the plain forward step (conserve == 0), advection
+ *  order <= 4, gradients by the 7- or 27-point fluid stencil.
+ *
+ *****************************************************************************/
+
+static int shim_fe_wanted(void) {
+  static int wanted = -1;
+  if (wanted < 0) {
+    const char * e = getenv("LBMI_FE");
+    wanted = (e != NULL && e[0] == '1');
+  }
+  return wanted;
+}
+
+static int shim_fe_symm_ok(fe_t * fe, field_t * phi, lees_edw_t * le, int * npt) {
+  fe_symm_t * fs = (fe_symm_t *) fe;
+  if (!shim_fe_wanted() || shim_.h == NULL || shim_.colloids) return 0;
+  if (fe == NULL || fe->id != FE_SYMMETRIC || shim_.lb->ndist != 1) return 0;
+  if (phi == NULL || fs->phi != phi || phi->nf != 1) return 0;
+  if (le != NULL && lees_edw_nplane_total(le) > 0) return 0;
+  if (shim_handle_if_any(phi->cs) == NULL) return 0;
+  *npt = 0;
+  if (fs->dphi->d2 == grad_3d_7pt_fluid_d2) *npt = 7;
+  if (fs->dphi->d2 == grad_3d_27pt_fluid_d2) *npt = 27;
+  return (*npt != 0 && fs->dphi->level == 2);
+}
+
+int phi_force_calculation(pe_t * pe, cs_t * cs, lees_edw_t * le, wall_t * wall,
+			  pth_t * pth, fe_t * fe, map_t * map, field_t * phi,
+			  hydro_t * hydro) {
+  int npt = 0;
+  int is_pm = 0;
+
+  assert(pth);
+
+  if (hydro == NULL) return 0;                               /* phi_force.c:86 */
+  if (pth->method == FE_FORCE_METHOD_NO_FORCE) return 0;
+
+  if (wall) wall_is_pm(wall, &is_pm);
+  if (pth->method != FE_FORCE_METHOD_STRESS_DIVERGENCE || is_pm ||
+      (wall && wall_present(wall)) || !shim_fe_symm_ok(fe, phi, le, &npt)) {
+    return phi_force_calculation_ref(pe, cs, le, wall, pth, fe, map, phi, hydro);
+  }
+
+  {
+    fe_symm_t * fs = (fe_symm_t *) fe;
+    fe_symm_param_t param;
+    double * grad = NULL;
+    double * delsq = NULL;
+    fe_symm_param(fs, &param);
+    shim_grad_arrays(fs->dphi, &grad, &delsq);
+    {
+      static int told = 0;
+      if (!told) pe_info(pe, "liblbmi: phi_force_calculation bound (LBMI_FE=1)\n");
+      told = 1;
+    }
+    /* F_a -= d_b P_ab at the interior sites, from the arrays the (bound)
+     * field_grad_compute has just filled */
+    SHIM_CHECK(shim_.lb, lbmi_symmetric_force(shim_.h, param.a, param.b,
+					      param.kappa, shim_field_data(phi),
+					      grad, delsq,
+					      shim_field_data(hydro->force)));
+  }
+
+  return 0;
+}
+
+int phi_cahn_hilliard(phi_ch_t * pch, fe_t * fe, field_t * phi,
+		      hydro_t * hydro, map_t * map, noise_t * noise) {
+  static double * scratch = NULL;        /* the new phi, nsite doubles (device) */
+  static size_t scratch_sites = 0;
+  int npt = 0, order = 0, noise_phi = 0, ispm = 0;
+  double gm[3] = {0.0, 0.0, 0.0};
+  physics_t * phys = NULL;
+
+  assert(pch);
+  assert(fe);
+  assert(phi);
+
+  physics_ref(&phys);
+  physics_grad_mu(phys, gm);
+  advection_order(&order);
+  if (noise) noise_present(noise, NOISE_PHI, &noise_phi);
+  if (map) map_pm(map, &ispm);
+
+  if (hydro == NULL || noise_phi || ispm || pch->info.conserve != 0 ||
+      order < 1 || order > 4 || gm[X] != 0.0 || gm[Y] != 0.0 || gm[Z] != 0.0 ||
+      !shim_fe_symm_ok(fe, phi, pch->le, &npt)) {
+    return phi_cahn_hilliard_ref(pch, fe, phi, hydro, map, noise);
+  }
+
+  {
+    fe_symm_t * fs = (fe_symm_t *) fe;
+    fe_symm_param_t param;
+    double mobility = 0.0;
+    double * grad = NULL;
+    double * delsq = NULL;
+    double * phid = shim_field_data(phi);
+    double * u = shim_field_data(hydro->u);
+    size_t nsites = (size_t) phi->nsites;
+
+    fe_symm_param(fs, &param);
+    physics_mobility(phys, &mobility);
+    shim_grad_arrays(fs->dphi, &grad, &delsq);
+    if (scratch_sites < nsites) {
+      if (scratch) tdpAssert(tdpFree(scratch));
+      tdpAssert(tdpMalloc((void **) &scratch, sizeof(double)*nsites));
+      scratch_sites = nsites;
+    }
+    {
+      static int told = 0;
+      if (!told) pe_info(pch->pe, "liblbmi: phi_cahn_hilliard bound (LBMI_FE=1)\n");
+      told = 1;
+    }
+    SHIM_CHECK(shim_.lb, lbmi_fe_scheme_set(shim_.h, npt, order));
+    /* hydro_u_halo (phi_cahn_hilliard.c:224), then advection, diffusive
+     * flux and forward step in one kernel; the reference updates phi in
+     * place, so the new interior goes back into its array */
+    SHIM_CHECK(shim_.lb, lbmi_field_halo_n(shim_.h, 3, 1, u));
+    SHIM_CHECK(shim_.lb, lbmi_cahn_hilliard(shim_.h, param.a, param.b,
+					    param.kappa, mobility, phid, delsq,
+					    u, scratch));
+    SHIM_CHECK(shim_.lb, lbmi_field_interior_copy(shim_.h, 1, scratch, phid));
+  }
+
   return 0;
 }

@@ -1287,6 +1287,10 @@ int lbmi_field_halo(lbmi_t * lb, int nel, double * data) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "nel = %d (1..%d)", nel, LBMI_NVEL_MAX);
   }
   HIPCHECK(hipSetDevice(lb->device));
+  {
+    int ifail = lbmi_hydro_touch(lb, data, NULL);    /* hydro_u_halo of a lazy u */
+    if (ifail) return ifail;
+  }
   for (int d = 0; d < 3; d++) {
     memset(&sel[d], 0, sizeof(sel[d]));
     for (int n = 0; n < nel; n++) {
@@ -2733,6 +2737,25 @@ int lbmi_lb_moments(lbmi_t * lb, const char * status, double out[9]) {
   return lbmi_moments(lb, lb->f, status, out);
 }
 
+/* lb_0th_moment of every interior site (first distribution), (ic, jc, kc)
+ * order, to a HOST array of nlocal[X]*nlocal[Y]*nlocal[Z] doubles: what
+ * stats_distribution_print sums up. fprime, dead once nothing is pending,
+ * is the device scratch. */
+
+int lbmi_lb_density(lbmi_t * lb, double * rho_host) {
+  size_t n;
+  int ifail;
+  if (lb == NULL || rho_host == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  ifail = lbmi_lb_flush(lb);
+  if (ifail) return ifail;
+  n = (size_t) lb->kp.nlocal[X]*(size_t) lb->kp.nlocal[Y]*(size_t) lb->kp.nlocal[Z];
+  KCHECK(lbmi_k_density(&lb->kp, lb->f, lb->fprime, lb->stream));
+  HIPCHECK(hipMemcpyAsync(rho_host, lb->fprime, sizeof(double)*n,
+			  hipMemcpyDeviceToHost, lb->stream));
+  HIPCHECK(hipStreamSynchronize(lb->stream));
+  return 0;
+}
+
 /*****************************************************************************
  *
  *  Rows "next": hydro housekeeping and the distribution record stream
@@ -2792,6 +2815,10 @@ int lbmi_field_halo_n(lbmi_t * lb, int nel, int nswap, double * data) {
     }
   }
   HIPCHECK(hipSetDevice(lb->device));
+  {
+    int ifail = lbmi_hydro_touch(lb, data, NULL);    /* hydro_u_halo of a lazy u */
+    if (ifail) return ifail;
+  }
   memset(&sel, 0, sizeof(sel));
   for (int n = 0; n < nel; n++) {
     sel.lo[sel.nlo++] = (int8_t) n;
@@ -2814,6 +2841,28 @@ int lbmi_field_halo_n(lbmi_t * lb, int nel, int nswap, double * data) {
 }
 
 /* field_grad_compute with grad_3d_7pt_fluid_d2 (gradient_3d_7pt_fluid.c) */
+
+/* dst <- src at the interior sites of an SoA device field of ncomp
+ * components: what puts the result of an out-of-place update
+ * (lbmi_cahn_hilliard, phi -> phi_out) back where a caller that updates in
+ * place keeps it, halo of dst untouched */
+
+int lbmi_field_interior_copy(lbmi_t * lb, int ncomp, const double * src,
+			     double * dst) {
+  if (lb == NULL || src == NULL || dst == NULL || src == dst) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_field_interior_copy: bad pointers");
+  }
+  if (ncomp < 1 || ncomp > LBMI_NVEL_MAX) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "ncomp = %d (1..%d)", ncomp, LBMI_NVEL_MAX);
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  {
+    int ifail = lbmi_hydro_touch(lb, src, dst);
+    if (ifail) return ifail;
+  }
+  KCHECK(lbmi_k_interior_copy(&lb->kp, ncomp, src, dst, lb->stream));
+  return 0;
+}
 
 int lbmi_fe_scheme_set(lbmi_t * lb, int grad_npt, int advection_order) {
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");

@@ -217,6 +217,14 @@ int lbmi_k_wall_bbl_slip(const lbmi_kparam_t * kp, const lbmi_wall_tab_t * tab,
 			 double * part, double * fnet, int * err,
 			 void * stream);
 
+/* dst <- src at the interior sites of an SoA field of ncomp components */
+int lbmi_k_interior_copy(const lbmi_kparam_t * kp, int ncomp,
+			 const double * src, double * dst, void * stream);
+
+/* rho = sum_p f_p (p order) of the interior sites, dense, (ic, jc, kc) order */
+int lbmi_k_density(const lbmi_kparam_t * kp, const double * f, double * rho,
+		   void * stream);
+
 /* Moments: partial (nblk x 12 doubles workspace) then final (out_dev[9]) */
 int lbmi_k_moments_nblk(void);
 int lbmi_k_moments(const lbmi_kparam_t * kp, const double * f,

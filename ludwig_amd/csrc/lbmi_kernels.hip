@@ -2162,6 +2162,42 @@ void k_moments_final(int npartial, const double * __restrict__ work,
   }
 }
 
+/* k_interior_copy: dst <- src at the interior sites of an SoA field of ncomp
+ * components (the halo of dst stays as it is) */
+
+__global__ __launch_bounds__(BLOCK)
+void k_interior_copy(lbmi_kparam_t kp, int ncomp, const double * __restrict__ src,
+		     double * __restrict__ dst) {
+  const int i0 = kp.nhalo*kp.strx;
+  const int i1 = (kp.nhalo + kp.nlocal[0])*kp.strx;
+  int i = i0 + blockIdx.x*BLOCK + threadIdx.x;
+  if (i >= i1) return;
+  Site s = decode(kp, i);
+  if (!s.interior) return;
+  for (int n = 0; n < ncomp; n++) {
+    dst[(size_t) kp.nsite*n + i] = src[(size_t) kp.nsite*n + i];
+  }
+}
+
+/* k_density: lb_0th_moment (model.c:817-832) of every interior site, summed in
+ * p order as there, into a dense array in (ic, jc, kc) order: what
+ * stats_distribution_print walks over (stats_distribution.c:73-88). The host
+ * adds the values up in the reference's own order, so the printed sums agree
+ * with its CPU path to the last digit. */
+
+template <int NVEL>
+__global__ __launch_bounds__(BLOCK)
+void k_density(lbmi_kparam_t kp, const double * __restrict__ f,
+	       double * __restrict__ rho, long long ninterior) {
+  long long ib = (long long) blockIdx.x*BLOCK + threadIdx.x;
+  if (ib >= ninterior) return;
+  const size_t i = interior_site(kp, ib);
+  const size_t ns = (size_t) kp.nsite;
+  double r = 0.0;
+  static_for<0, NVEL>([&](auto P) { r += f[ns*P + i]; });
+  rho[ib] = r;
+}
+
 /* ---- launch helpers --------------------------------------------------------- */
 
 inline unsigned grid_for(unsigned nblk, unsigned group = 0) {
@@ -3101,6 +3137,27 @@ extern "C" int lbmi_k_wall_bbl_slip(const lbmi_kparam_t * kp,
 		     *tab, f, nlink, linki, linkj, linkp, linkk, linkq, links,
 		     status, part, err);
   hipLaunchKernelGGL(k_wall_fnet, dim3(1), dim3(64), 0, st, nblk, part, fnet);
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_interior_copy(const lbmi_kparam_t * kp, int ncomp,
+				    const double * src, double * dst,
+				    void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  const long long n = (long long) kp->nlocal[0]*kp->strx;
+  dim3 grid((unsigned) ((n + BLOCK - 1)/BLOCK)), block(BLOCK);
+  hipLaunchKernelGGL(k_interior_copy, grid, block, 0, st, *kp, ncomp, src, dst);
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_density(const lbmi_kparam_t * kp, const double * f,
+			      double * rho, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  const long long n = (long long) kp->nlocal[0]*kp->nlocal[1]*kp->nlocal[2];
+  dim3 grid((unsigned) ((n + BLOCK - 1)/BLOCK)), block(BLOCK);
+  if (kp->nvel == 19) hipLaunchKernelGGL(k_density<19>, grid, block, 0, st, *kp, f, rho, n);
+  else if (kp->nvel == 27) hipLaunchKernelGGL(k_density<27>, grid, block, 0, st, *kp, f, rho, n);
+  else return (int) hipErrorInvalidValue;
   return (int) hipGetLastError();
 }
 

@@ -273,6 +273,13 @@ class LB:
         a = (ctypes.c_double * 3)(*([float(v) for v in values] + [0.0] * 3)[:3])
         _l.check(self._lib.lbmi_hydro_field_set(self._h, _ptr(field), ncomp, a))
 
+    def density(self):
+        """lbmi_lb_density: rho of the interior sites, (nlocal) array."""
+        out = np.zeros(self.nlocal, dtype=np.float64)
+        _l.check(self._lib.lbmi_lb_density(
+            self._h, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     def hydro_sync(self):
         """lbmi_lb_hydro_sync: rho, u of the last collision, if a lazy
         collision (tune hydro_lazy) still owes them."""

@@ -123,11 +123,13 @@ SYMBOLS = [
     ("lbmi_lb_memcpy_h2d", _i, [_vp, _vp]),
     ("lbmi_lb_memcpy_d2h", _i, [_vp, _vp]),
     ("lbmi_lb_moments", _i, [_vp, _vp, _pd]),
+    ("lbmi_lb_density", _i, [_vp, _vp]),
     ("lbmi_lb_hydro_sync", _i, [_vp]),
     ("lbmi_hydro_field_dirty", _i, [_vp, _vp]),
     ("lbmi_hydro_field_set", _i, [_vp, _vp, _i, _pd]),
     ("lbmi_field_halo_n", _i, [_vp, _i, _i, _vp]),
     ("lbmi_fe_scheme_set", _i, [_vp, _i, _i]),
+    ("lbmi_field_interior_copy", _i, [_vp, _i, _vp, _vp]),
     ("lbmi_field_grad_7pt", _i, [_vp, _vp, _vp, _vp]),
     ("lbmi_field_grad_27pt", _i, [_vp, _vp, _vp, _vp]),
     ("lbmi_field_grad", _i, [_vp, _vp, _vp, _vp]),

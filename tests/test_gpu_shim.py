@@ -181,7 +181,7 @@ import subprocess as _sp                                     # noqa: E402
 INPUTS = os.path.join(HERE, "golden", "inputs")
 
 
-def _ludwig(inp, mode, shim=True):
+def _ludwig(inp, mode, shim=True, extra_env=None):
     """Run the reference's executable on an input of tests/golden/inputs.
     mode = None leaves LBMI_MODE unset (the binding's default). Whatever the
     child wrote is kept when it fails (a GPU fault must leave evidence): in
@@ -193,6 +193,8 @@ def _ludwig(inp, mode, shim=True):
     env.pop("LBMI_MODE", None)
     if mode is not None:
         env["LBMI_MODE"] = mode
+    env.pop("LBMI_FE", None)
+    env.update(extra_env or {})
     import shutil
     with tempfile.TemporaryDirectory() as tmp:
         # main.c: the input file is "input" in the working directory
@@ -359,3 +361,66 @@ def test_ludwig_two_dimensional_lattice(mode):
     for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
         for a, b in zip(_last(log, tag), ref[key]):
             assert abs(a - b) <= 2e-7 * abs(b) + 1e-16
+
+
+# --- rows a17 and f2 inside the application ---------------------------------------
+
+def _droplet_checks(log, ref):
+    rho = _last(log, "[rho]")
+    assert rho[0] == ref["rho_total"]
+    assert abs(rho[3] - ref["rho_min"]) < 2e-11 and abs(rho[4] - ref["rho_max"]) < 2e-11
+    phi = _last(log, "[phi]")
+    assert abs(phi[2] - ref["phi_var"]) <= 2e-7 * ref["phi_var"]
+    assert abs(phi[3] - ref["phi_min"]) <= 2e-7 and abs(phi[4] - ref["phi_max"]) <= 2e-7
+    assert abs(_last(log, "[fed]")[-1] - ref["fed"]) <= 1e-9 * abs(ref["fed"])
+    for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
+        for a, b in zip(_last(log, tag), ref[key]):
+            assert abs(a - b) <= 2e-7 * abs(b) + 1e-16
+
+
+@pytest.mark.parametrize("mode", ["halo", "fused"])
+def test_ludwig_droplet_with_the_free_energy_sector_bound(mode):
+    """LBMI_FE=1: phi_force_calculation and phi_cahn_hilliard of the binding
+    (one kernel each, no stress array, no flux arrays) in place of the
+    reference's pth_* / advection_* / phi_ch_* kernels, on top of everything
+    else: twenty coupled steps of the relaxing droplet iodrop-mpi1-io1 (27-point
+    gradients, second-order advection), the report after step 20."""
+    ref = _json.load(open(os.path.join(HERE, "golden", "regression_symmetric_drop.json")))
+    ref = ref["iodrop-mpi1-io1"]["reports"]["20"]
+    log = _ludwig("iodrop.inp", mode, extra_env={"LBMI_FE": "1"})
+    assert "phi_force_calculation bound" in log and "phi_cahn_hilliard bound" in log
+    _droplet_checks(log, ref)
+
+
+@pytest.mark.parametrize("name", ["spin_fd1", "symm_pat"])
+def test_ludwig_more_regressions_with_the_free_energy_sector_bound(name):
+    """spin_fd1 (spinodal quench, ten steps), symm_pat (ONE step from a patchy
+    phi: steep gradients, large forces) with LBMI_FE=1: the handle of the
+    binding exists from the lb_memcpy of ludwig.c:507 on, so the first step's
+    free-energy sector is bound as well."""
+    ref = _json.load(open(os.path.join(HERE, "golden", "regression_app_extra.json")))[name]
+    log = _ludwig(name + ".inp", None, extra_env={"LBMI_FE": "1"})
+    assert "phi_force_calculation bound" in log and "phi_cahn_hilliard bound" in log
+    rho = _last(log, "[rho]")
+    assert rho[0] == ref["rho"][0]
+    assert abs(rho[2] - ref["rho"][2]) <= 1e-12
+    assert abs(rho[3] - ref["rho"][3]) < 2e-11 and abs(rho[4] - ref["rho"][4]) < 2e-11
+    phi = _last(log, "[phi]")
+    for a, b in zip(phi, ref["phi"]):
+        assert abs(a - b) <= 2e-7 * abs(b) + 1e-12
+    fed = _last(log, "[fed]")
+    assert abs(fed[-1] - ref["fed"]) <= 1e-9 * abs(ref["fed"])
+    for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
+        for a, b in zip(_last(log, tag), ref[key]):
+            assert abs(a - b) <= 2e-7 * abs(b) + 1e-16
+
+
+def test_the_free_energy_binding_leaves_other_cases_to_the_reference():
+    """LBMI_FE=1 on a case outside its conditions (symmetric_lb: two
+    distributions, no finite-difference order parameter): nothing is bound,
+    the log is the reference's."""
+    ref = _json.load(open(os.path.join(HERE, "golden", "regression_app_extra.json")))["spin_lb1"]
+    log = _ludwig("spin_lb1.inp", None, extra_env={"LBMI_FE": "1"})
+    assert "bound (LBMI_FE=1)" not in log
+    rho = _last(log, "[rho]")
+    assert rho[0] == ref["rho"][0] and abs(rho[2] - ref["rho"][2]) <= 1e-12
