@@ -128,7 +128,7 @@ typedef enum lbmi_mode_e {
 
 typedef struct lbmi_options_s {
   int nvel;                 /* 19 or 27 (lb_data.h:33-44)                    */
-  int ndist;                /* 1, or 2 (symmetric_lb: EAGER mode)            */
+  int ndist;                /* 1, or 2 (symmetric_lb; not LBMI_MODE_INPLACE)  */
   int nlocal[3];            /* local lattice extent (cs_nlocal)              */
   int nhalo;                /* halo width of the allocation (cs_nhalo)       */
   int device;               /* HIP device ordinal, or -1: current device     */
@@ -251,11 +251,13 @@ int lbmi_lb_mode_set(lbmi_t * lb, int mode);
  * between (a host language with expensive foreign calls, a benchmark). */
 int lbmi_lb_run(lbmi_t * lb, const lbmi_hydro_t * hydro, int nsteps);
 
-/* ndist = 2, free_energy symmetric_lb (LBMI_MODE_EAGER or
- * LBMI_MODE_FUSED_HALO: there lbmi_lb_propagation of both distributions is
- * deferred into the next lbmi_lb_collide_binary, and lbmi_lb_phi_to_field
- * called in between takes phi of the propagated state from the pending
- * array): the second distribution carries the order parameter. f holds both,
+/* ndist = 2, free_energy symmetric_lb (LBMI_MODE_EAGER; LBMI_MODE_FUSED_HALO:
+ * lbmi_lb_propagation of both distributions is deferred into the next
+ * lbmi_lb_collide_binary, and lbmi_lb_phi_to_field called in between takes
+ * phi of the propagated state from the pending array; LBMI_MODE_FUSED: on one
+ * GPU the halo swap of both is deferred as well -- the pulls wrap by index --
+ * and on slabs it is FUSED_HALO): the second distribution carries the order
+ * parameter. f holds both,
  * f[(n*nvel + p)*nsite + index]; lbmi_lb_halo and lbmi_lb_propagation move
  * both; lbmi_lb_moments looks at n = 0 (as stats_distribution.c does).
  *   lbmi_lb_phi_to_field   phi_lb_to_field (phi_lb_coupler.c:39-112):

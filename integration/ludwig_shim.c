@@ -16,6 +16,8 @@
  *      wall_bbl()        wall.h:99         (replaces wall.c:960-989, slip included)
  *      phi_lb_to_field() phi_lb_coupler.h  (replaces phi_lb_coupler.c:39-64)
  *      hydro_u_zero(), hydro_f_zero()  hydro.h:64-65 (hydro.c:279-330)
+ *      hydro_memcpy()    hydro.h:56        (the original, after rho and u that a
+ *                        lazy collision still owes have been formed: LBMI_HYDRO)
  *      field_halo()      field.h:96        (field.c; FIELD_HALO_TARGET only)
   *      field_grad_compute() field_grad.h:49 (3d_7pt_fluid / 3d_27pt_fluid d2)
  *      wall_set_wall_distributions() wall.h:100, bounce_back_on_links()
@@ -47,7 +49,8 @@
  *  -Dbounce_back_on_links=bounce_back_on_links_ref, map.c with -Dmap_free=
  *  map_free_ref, phi_lb_coupler.c with
  *  -Dphi_lb_to_field=phi_lb_to_field_ref, hydro.c with -Dhydro_u_zero=
- *  hydro_u_zero_ref -Dhydro_f_zero=hydro_f_zero_ref, field.c with -Dfield_halo=
+ *  hydro_u_zero_ref -Dhydro_f_zero=hydro_f_zero_ref -Dhydro_memcpy=
+ *  hydro_memcpy_ref, field.c with -Dfield_halo=
  *  field_halo_ref -Dfield_free=field_free_ref, field_grad.c with
  *  -Dfield_grad_compute=field_grad_compute_ref -Dfield_grad_free=
  *  field_grad_free_ref, stats_distribution.c with
@@ -129,6 +132,7 @@ int phi_cahn_hilliard_ref(phi_ch_t * pch, fe_t * fe, field_t * phi,
 int phi_lb_to_field_ref(field_t * phi, lb_t * lb);
 int hydro_u_zero_ref(hydro_t * hydro, const double uzero[3]);
 int hydro_f_zero_ref(hydro_t * hydro, const double fzero[3]);
+int hydro_memcpy_ref(hydro_t * hydro, tdpMemcpyKind flag);
 int field_halo_ref(field_t * field);
 int field_grad_compute_ref(field_grad_t * fgrad);
 void field_grad_free_ref(field_grad_t * obj);
@@ -168,7 +172,16 @@ static int shim_supported(lb_t * lb) {
   if (lb->model.nvel != 19 && lb->model.nvel != 27) return 0;
   if (lb->haloscheme != LB_HALO_TARGET) return 0;
   cs_cartsz(lb->cs, cartsz);
-  if (cartsz[Y] != 1 || cartsz[Z] != 1) return 0;
+  if (cartsz[Y] != 1 || cartsz[Z] != 1) {
+    static int told = 0;
+    if (!told) {
+      pe_info(lb->pe, "liblbmi: decomposition %d_%d_%d: only slabs along X "
+	      "(grid N_1_1) are covered; this run uses the reference's own "
+	      "lattice Boltzmann kernels\n", cartsz[X], cartsz[Y], cartsz[Z]);
+    }
+    told = 1;
+    return 0;
+  }
   return 1;
 }
 
@@ -287,7 +300,7 @@ static lbmi_t * shim_handle(lb_t * lb) {
     opts.halo_scheme = LBMI_HALO_FULL;           /* halo_swap_packed semantics */
         opts.mode = LBMI_MODE_FUSED_HALO;              /* ndist 1 or 2 */
     if (mode && mode[0] == 'e') opts.mode = LBMI_MODE_EAGER;
-    if (mode && mode[0] == 'f' && lb->ndist == 1) opts.mode = LBMI_MODE_FUSED;
+    if (mode && mode[0] == 'f') opts.mode = LBMI_MODE_FUSED;   /* ndist 1 or 2 */
     if (mode && mode[0] != 'e' && mode[0] != 'f' && mode[0] != 'h') {
       pe_fatal(lb->pe, "liblbmi: LBMI_MODE=%s (halo, eager or fused)\n", mode);
     }
@@ -441,6 +454,24 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
       SHIM_CHECK(lb, lbmi_hydro_field_dirty(h, hy.force));
     }
     shim_.ncollide += 1;
+
+    /* LBMI_HYDRO=lazy: the plain single-fluid run, where nobody on the
+     * device reads hydro->rho, u between two collisions (no free energy, no
+     * viscosity model, no colloids, no Lees-Edwards planes): the collision
+     * does not store them; hydro_memcpy (statistics, output) and hydro_u_halo
+     * get them formed first. 32 B/site per step. */
+    {
+      static int wanted = -1;
+      int lazy;
+      if (wanted < 0) {
+	const char * e = getenv("LBMI_HYDRO");
+	wanted = (e != NULL && e[0] == 'l');
+      }
+      lazy = (wanted && fe == NULL && visc == NULL && !shim_.colloids &&
+	      lb->ndist == 1 &&
+	      !(hydro->le && lees_edw_nplane_total(hydro->le) > 0));
+      SHIM_CHECK(lb, lbmi_tune(h, "hydro_lazy", lazy));
+    }
 
     if (lb->ndist == 2 || (fe && fe->use_stress_relaxation)) {
       /* lb_collision_binary (collision.c:610-1027), or the single-fluid
@@ -829,6 +860,15 @@ static lbmi_t * shim_handle_if_any(cs_t * cs) {
     return NULL;
   }
   return shim_.h;
+}
+
+int hydro_memcpy(hydro_t * hydro, tdpMemcpyKind flag) {
+  assert(hydro);
+  if (shim_.h != NULL && flag == tdpMemcpyDeviceToHost) {
+    SHIM_CHECK(shim_.lb, lbmi_lb_hydro_sync(shim_.h));
+    SHIM_CHECK(shim_.lb, lbmi_synchronize(shim_.h));
+  }
+  return hydro_memcpy_ref(hydro, flag);
 }
 
 int hydro_u_zero(hydro_t * hydro, const double uzero[3]) {

@@ -264,10 +264,9 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   if (opts->ndist != 1 && opts->ndist != 2) {
     return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = %d: 1 or 2", opts->ndist);
   }
-  if (opts->ndist == 2 && opts->mode != LBMI_MODE_EAGER &&
-      opts->mode != LBMI_MODE_FUSED_HALO) {
-    /* the two-distribution (symmetric_lb) step: three stages */
-    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = 2 needs LBMI_MODE_EAGER or LBMI_MODE_FUSED_HALO");
+  if (opts->ndist == 2 && opts->mode == LBMI_MODE_INPLACE) {
+    /* the two-distribution (symmetric_lb) step: two arrays */
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = 2 needs LBMI_MODE_EAGER, LBMI_MODE_FUSED_HALO or LBMI_MODE_FUSED");
   }
   if (opts->nhalo < 1) return lbmi_fail(LBMI_ERR_ARGUMENT, "nhalo < 1");
   for (int d = 0; d < 3; d++) {
@@ -1408,6 +1407,7 @@ static int lbmi_deferred(const lbmi_t * lb) {
 static int lbmi_blocked_ok(const lbmi_t * lb) {
   int nfull = lbmi_k_blocked_sites(&lb->kp);
   if (!lb->use_blocked || lb->opts.mode != LBMI_MODE_FUSED) return 0;
+  if (lb->opts.ndist != 1) return 0;
   if (lb->opts.cartsz == 1 && !lb->have_comm) {
     /* every pull is wrapped by index: nothing beyond the interior planes */
     int last = (lb->kp.nhalo + lb->kp.nlocal[X])*lb->kp.strx;
@@ -2333,7 +2333,9 @@ int lbmi_lb_phi_to_field(lbmi_t * lb, double * phi) {
   HIPCHECK(hipSetDevice(lb->device));
   /* FUSED_HALO with the propagation pending: phi of the propagated state,
    * straight from the post-collision array (which has its halo) */
-  KCHECK(lbmi_k_phi_from_g(&lb->kp, lb->f, phi, lb->pending_prop, lb->stream));
+  KCHECK(lbmi_k_phi_from_g(&lb->kp, lb->f, phi, lb->pending_prop,
+			   (lb->pending_prop && !lb->halo_done) ? 7 : 0,
+			   lb->stream));
   return 0;
 }
 
@@ -2360,10 +2362,13 @@ int lbmi_lb_collide_binary(lbmi_t * lb, const lbmi_hydro_t * hydro,
   }
   /* (1/tau_2) = 2/(2M + 1), collision.c:1965-1968 */
   if (lb->pending_prop) {
-    /* FUSED_HALO: propagation(t) of both distributions inside collision(t+1) */
+    /* propagation(t) of both distributions inside collision(t+1): from the
+     * halo where lb_halo has filled it (FUSED_HALO), by index wrap where that
+     * is pending as well (FUSED on one GPU) */
     KCHECK(lbmi_k_collide_binary(&lb->kp, lb->f, lb->fprime, &h, fe->a, fe->b,
 				 fe->kappa, 2.0/(1.0 + 2.0*fe->mobility),
-				 fe->phi, fe->grad, fe->delsq, lb->stream));
+				 fe->phi, fe->grad, fe->delsq,
+				 lb->halo_done ? 0 : 7, lb->stream));
     lb->pending_prop = 0;
     lb->pending_halo = 0;
     lb->halo_done = 0;
@@ -2372,7 +2377,7 @@ int lbmi_lb_collide_binary(lbmi_t * lb, const lbmi_hydro_t * hydro,
   }
   KCHECK(lbmi_k_collide_binary(&lb->kp, lb->f, lb->f, &h, fe->a, fe->b,
 			       fe->kappa, 2.0/(1.0 + 2.0*fe->mobility), fe->phi,
-			       fe->grad, fe->delsq, lb->stream));
+			       fe->grad, fe->delsq, 0, lb->stream));
   return 0;
 }
 
@@ -2395,8 +2400,11 @@ int lbmi_lb_halo(lbmi_t * lb) {
     if (lb->pending_prop) {
       return lbmi_fail(LBMI_ERR_STATE, "lb_halo while a propagation is pending");
     }
-    if (lb->opts.mode == LBMI_MODE_FUSED_HALO) {
-      /* eager: f gets its halo now; only the propagation will be deferred */
+    if (lb->opts.mode == LBMI_MODE_FUSED_HALO ||
+	(lb->opts.ndist == 2 && (lb->opts.cartsz > 1 || lb->have_comm))) {
+      /* eager: f gets its halo now; only the propagation will be deferred
+       * (two distributions on slabs: FUSED is FUSED_HALO; on one GPU the
+       * next collision wraps by index instead) */
       for (int n = 0; n < lb->opts.ndist; n++) {
 	size_t off = (size_t) n*(size_t) lb->kp.nvel*(size_t) lb->kp.nsite;
 	int ifail = lbmi_halo(lb, lb->f + off, lb->opts.halo_scheme);
@@ -2522,8 +2530,11 @@ int lbmi_lb_flush(lbmi_t * lb) {
 
   if (lb->pending_halo) {
     if (!lb->halo_done) {
-      int ifail = lbmi_halo(lb, lb->f, lb->opts.halo_scheme);
-      if (ifail) return ifail;
+      for (int n = 0; n < lb->opts.ndist; n++) {
+	size_t off = (size_t) n*(size_t) lb->kp.nvel*(size_t) lb->kp.nsite;
+	int ifail = lbmi_halo(lb, lb->f + off, lb->opts.halo_scheme);
+	if (ifail) return ifail;
+      }
     }
     lb->pending_halo = 0;
     lb->halo_done = 0;
@@ -2550,9 +2561,8 @@ int lbmi_lb_mode_set(lbmi_t * lb, int mode) {
       mode != LBMI_MODE_INPLACE && mode != LBMI_MODE_FUSED_HALO) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "mode = %d", mode);
   }
-  if (lb->opts.ndist == 2 && mode != LBMI_MODE_EAGER &&
-      mode != LBMI_MODE_FUSED_HALO) {
-    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = 2 needs LBMI_MODE_EAGER or LBMI_MODE_FUSED_HALO");
+  if (lb->opts.ndist == 2 && mode == LBMI_MODE_INPLACE) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = 2 needs LBMI_MODE_EAGER, LBMI_MODE_FUSED_HALO or LBMI_MODE_FUSED");
   }
   if (mode == lb->opts.mode) return 0;
   if (lb->f != NULL) {

@@ -174,16 +174,18 @@ int lbmi_k_collide_fe(const lbmi_kparam_t * kp, double * f,
 		      const double * delsq, void * stream);
 
 /* Two distributions (symmetric_lb): f2[(n*nvel + p)*nsite + i] */
-/* pull != 0 / src != f2: a propagation is pending on the array read (it has
- * its halo): populations come from i - c_p, results go to f2 */
+/* pull != 0 / src != f2: a propagation is pending on the array read:
+ * populations come from i - c_p (the array has its halo, wrapmask 0) or, in
+ * the directions of wrapmask, from the periodic image inside the domain (the
+ * halo swap is pending as well); results go to f2 */
 int lbmi_k_phi_from_g(const lbmi_kparam_t * kp, const double * f2,
-		      double * phi, int pull, void * stream);
+		      double * phi, int pull, int wrapmask, void * stream);
 int lbmi_k_collide_binary(const lbmi_kparam_t * kp, const double * src,
 			  double * f2,
 			  const lbmi_hydro_dev_t * h, double a, double b,
 			  double kappa, double rtau2, const double * phi,
 			  const double * grad, const double * delsq,
-			  void * stream);
+			  int wrapmask, void * stream);
 
 /* Bounce-back on links (wall_bbl_kernel, wall.c:996-1107). Tables travel by
  * value; part: nblk*3 doubles of per-block momentum, added to fnet[3] (device)

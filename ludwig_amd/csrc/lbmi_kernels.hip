@@ -1868,11 +1868,29 @@ void k_symm_fe_step_tiled(lbmi_kparam_t kp, Symm q, double mobility, int order,
  * is re-projected from phi, jphi (relaxed towards phi u at rtau2) and
  * sphi = phi u u + mu delta. f2[(n*NVEL + p)*nsite + i]. */
 
+/* offset (in sites) of the source of population p for a pull at a site whose
+ * wrap corrections are w (directions wrapped by index: the source of a pull
+ * across a periodic face is the image inside the domain, not the halo) */
+template <int NVEL, int P>
+__device__ __forceinline__ int pull_offset(const lbmi_kparam_t & kp,
+					    const WrapAdj & w) {
+  using M = Model<NVEL>;
+  constexpr int cx = M::c(P,0), cy = M::c(P,1), cz = M::c(P,2);
+  int off = cx*kp.strx + cy*kp.stry + cz;
+  if constexpr (cx ==  1) off -= w.wlo[0];
+  if constexpr (cx == -1) off -= w.whi[0];
+  if constexpr (cy ==  1) off -= w.wlo[1];
+  if constexpr (cy == -1) off -= w.whi[1];
+  if constexpr (cz ==  1) off -= w.wlo[2];
+  if constexpr (cz == -1) off -= w.whi[2];
+  return off;
+}
+
 template <int NVEL, bool PULL>
 __global__ __launch_bounds__(BLOCK)
 void k_phi_from_g(lbmi_kparam_t kp, const double * __restrict__ f2,
-		  double * __restrict__ phi, int i0, int i1, unsigned nblk) {
-  using M = Model<NVEL>;
+		  double * __restrict__ phi, int wrapmask, int i0, int i1,
+		  unsigned nblk) {
   unsigned lb;
   if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
   int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
@@ -1882,11 +1900,14 @@ void k_phi_from_g(lbmi_kparam_t kp, const double * __restrict__ f2,
   const size_t ns = (size_t) kp.nsite;
   const double * __restrict__ g = f2 + ns*NVEL;
   double sum = 0.0;
-  /* PULL: the propagation is pending (FUSED_HALO): population p of this
-   * site still sits at i - c_p of the post-collision array, halo included */
+  /* PULL: the propagation is pending: population p of this site still sits
+   * at i - c_p of the post-collision array -- in its halo where that has
+   * been swapped (FUSED_HALO, wrapmask 0), at the periodic image where the
+   * halo swap is pending too (FUSED on one GPU) */
+  const WrapAdj w = wrap_adjust(kp, s, PULL ? wrapmask : 0);
   static_for<0, NVEL>([&](auto P) {
     constexpr int p = P;
-    const int off = PULL ? (M::c(p,0)*kp.strx + M::c(p,1)*kp.stry + M::c(p,2)) : 0;
+    const int off = PULL ? pull_offset<NVEL, p>(kp, w) : 0;
     sum += g[ns*p + (i - off)];
   });
   phi[i] = sum;
@@ -1902,7 +1923,7 @@ void k_collide_binary(lbmi_kparam_t kp, const double * src, double * f2,
 		      lbmi_hydro_dev_t h, Symm q, double rtau2,
 		      const double * __restrict__ phi,
 		      const double * __restrict__ grad,
-		      const double * __restrict__ delsq,
+		      const double * __restrict__ delsq, int wrapmask,
 		      int i0, int i1, unsigned nblk) {
 
   using M = Model<NVEL>;
@@ -1919,9 +1940,10 @@ void k_collide_binary(lbmi_kparam_t kp, const double * src, double * f2,
 
   double fl[NVEL];
   double gl[NVEL];
+  const WrapAdj w = wrap_adjust(kp, s, PULL ? wrapmask : 0);
   static_for<0, NVEL>([&](auto P) {
     constexpr int p = P;
-    const int off = PULL ? (M::c(p,0)*kp.strx + M::c(p,1)*kp.stry + M::c(p,2)) : 0;
+    const int off = PULL ? pull_offset<NVEL, p>(kp, w) : 0;
     fl[p] = src[ns*p + (i - off)];
     if constexpr (p > 0) gl[p] = gsrc[ns*p + (i - off)];
   });
@@ -3020,25 +3042,26 @@ extern "C" int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, int npt,
 }
 
 extern "C" int lbmi_k_phi_from_g(const lbmi_kparam_t * kp, const double * f2,
-				 double * phi, int pull, void * stream) {
+				 double * phi, int pull, int wrapmask,
+				 void * stream) {
   hipStream_t st = (hipStream_t) stream;
   Range1D r = interior_range(*kp);
   dim3 grid(r.grid), block(BLOCK);
   if (kp->nvel == 19 && !pull) {
     hipLaunchKernelGGL((k_phi_from_g<19, false>), grid, block, 0, st, *kp, f2, phi,
-		       r.i0, r.i1, r.nblk);
+		       wrapmask, r.i0, r.i1, r.nblk);
   }
   else if (kp->nvel == 19) {
     hipLaunchKernelGGL((k_phi_from_g<19, true>), grid, block, 0, st, *kp, f2, phi,
-		       r.i0, r.i1, r.nblk);
+		       wrapmask, r.i0, r.i1, r.nblk);
   }
   else if (kp->nvel == 27 && !pull) {
     hipLaunchKernelGGL((k_phi_from_g<27, false>), grid, block, 0, st, *kp, f2, phi,
-		       r.i0, r.i1, r.nblk);
+		       wrapmask, r.i0, r.i1, r.nblk);
   }
   else if (kp->nvel == 27) {
     hipLaunchKernelGGL((k_phi_from_g<27, true>), grid, block, 0, st, *kp, f2, phi,
-		       r.i0, r.i1, r.nblk);
+		       wrapmask, r.i0, r.i1, r.nblk);
   }
   else {
     return (int) hipErrorInvalidValue;
@@ -3052,23 +3075,23 @@ static int launch_collide_binary(const lbmi_kparam_t & kp, const double * src,
 				 const lbmi_hydro_dev_t & h, Symm q,
 				 double rtau2, const double * phi,
 				 const double * grad, const double * delsq,
-				 hipStream_t st) {
+				 int wrapmask, hipStream_t st) {
   Range1D r = interior_range(kp);
   dim3 grid(r.grid), block(BLOCK);
   switch (kp.scheme) {
   case LBMI_M10:
     hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_M10, PULL>), grid, block, 0, st,
-		       kp, src, f2, h, q, rtau2, phi, grad, delsq, r.i0, r.i1, r.nblk);
+		       kp, src, f2, h, q, rtau2, phi, grad, delsq, wrapmask, r.i0, r.i1, r.nblk);
     break;
   case LBMI_BGK:
     hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_BGK, PULL>), grid, block, 0, st,
-		       kp, src, f2, h, q, rtau2, phi, grad, delsq, r.i0, r.i1, r.nblk);
+		       kp, src, f2, h, q, rtau2, phi, grad, delsq, wrapmask, r.i0, r.i1, r.nblk);
     break;
   case LBMI_TRT:
     if constexpr (NVEL == 19) {
       hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_TRT, PULL>), grid, block, 0,
-			 st, kp, src, f2, h, q, rtau2, phi, grad, delsq, r.i0, r.i1,
-			 r.nblk);
+			 st, kp, src, f2, h, q, rtau2, phi, grad, delsq, wrapmask,
+			 r.i0, r.i1, r.nblk);
       break;
     }
     return (int) hipErrorInvalidValue;
@@ -3083,17 +3106,18 @@ extern "C" int lbmi_k_collide_binary(const lbmi_kparam_t * kp,
 				     const lbmi_hydro_dev_t * h, double a,
 				     double b, double kappa, double rtau2,
 				     const double * phi, const double * grad,
-				     const double * delsq, void * stream) {
+				     const double * delsq, int wrapmask,
+				     void * stream) {
   hipStream_t st = (hipStream_t) stream;
   Symm q = {a, b, kappa};
   /* src == f2: in place; otherwise pull from src (propagation fused in) */
   if (src == f2) {
-    if (kp->nvel == 19) return launch_collide_binary<19, false>(*kp, f2, f2, *h, q, rtau2, phi, grad, delsq, st);
-    if (kp->nvel == 27) return launch_collide_binary<27, false>(*kp, f2, f2, *h, q, rtau2, phi, grad, delsq, st);
+    if (kp->nvel == 19) return launch_collide_binary<19, false>(*kp, f2, f2, *h, q, rtau2, phi, grad, delsq, 0, st);
+    if (kp->nvel == 27) return launch_collide_binary<27, false>(*kp, f2, f2, *h, q, rtau2, phi, grad, delsq, 0, st);
   }
   else {
-    if (kp->nvel == 19) return launch_collide_binary<19, true>(*kp, src, f2, *h, q, rtau2, phi, grad, delsq, st);
-    if (kp->nvel == 27) return launch_collide_binary<27, true>(*kp, src, f2, *h, q, rtau2, phi, grad, delsq, st);
+    if (kp->nvel == 19) return launch_collide_binary<19, true>(*kp, src, f2, *h, q, rtau2, phi, grad, delsq, wrapmask, st);
+    if (kp->nvel == 27) return launch_collide_binary<27, true>(*kp, src, f2, *h, q, rtau2, phi, grad, delsq, wrapmask, st);
   }
   return (int) hipErrorInvalidValue;
 }

@@ -74,8 +74,8 @@ def test_create_argument_errors(lib):
     o.ndist = 3
     assert lib.lbmi_create(ctypes.byref(o), ctypes.byref(h)) == -2
     lib.lbmi_options_default(ctypes.byref(o))
-    o.ndist = 2                      # two distributions: EAGER only
-    o.mode = 1
+    o.ndist = 2                      # two distributions: not the in-place mode
+    o.mode = 2
     assert lib.lbmi_create(ctypes.byref(o), ctypes.byref(h)) == -2
     assert b"EAGER" in lib.lbmi_last_error()
     lib.lbmi_options_default(ctypes.byref(o))

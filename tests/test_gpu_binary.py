@@ -60,12 +60,14 @@ def test_binary_collision_vs_reference(name):
     lb.free()
 
 
-@pytest.mark.parametrize("mode", [0, 3], ids=["eager", "fused_halo"])
+@pytest.mark.parametrize("mode", [0, 3, 1], ids=["eager", "fused_halo", "fused"])
 @pytest.mark.parametrize("name", golden_binary_names())
 def test_binary_steps_vs_reference(name, mode):
     """Whole steps as ludwig.c runs them with free_energy symmetric_lb.
     FUSED_HALO: the propagation of both distributions is deferred into the
-    next collision, and phi_lb_to_field pulls from the pending state."""
+    next collision, and phi_lb_to_field pulls from the pending state. FUSED:
+    the halo swap of both is deferred as well: the pulls of the collision and
+    of phi_lb_to_field wrap the periodic box by index."""
     import ludwig_amd
     import torch
     g = load_golden(name)
@@ -95,7 +97,7 @@ def test_binary_steps_vs_reference(name, mode):
     lb.free()
 
 
-@pytest.mark.parametrize("mode", [0, 3], ids=["eager", "fused_halo"])
+@pytest.mark.parametrize("mode", [0, 3, 1], ids=["eager", "fused_halo", "fused"])
 @pytest.mark.parametrize("nvel,scheme", [(19, "bgk"), (19, "trt"), (27, "bgk")])
 def test_binary_seeded_vs_oracle(nvel, scheme, mode):
     """Larger box, other relaxation schemes, a force field: oracle parity."""
@@ -142,8 +144,6 @@ def test_binary_seeded_vs_oracle(nvel, scheme, mode):
 def test_binary_rejections():
     import ludwig_amd
     with pytest.raises(ludwig_amd.LbmiError):
-        ludwig_amd.LB(19, (4, 4, 4), 1, ndist=2, mode=ludwig_amd.FUSED)
-    with pytest.raises(ludwig_amd.LbmiError):
         ludwig_amd.LB(19, (4, 4, 4), 1, ndist=2, mode=ludwig_amd.INPLACE)
     with pytest.raises(ludwig_amd.LbmiError):
         ludwig_amd.LB(19, (4, 4, 4), 1, ndist=3)
@@ -188,7 +188,7 @@ def test_stress_relaxation_vs_reference(name, mode):
     lb.free()
 
 
-@pytest.mark.parametrize("mode", [0, 3], ids=["eager", "fused_halo"])
+@pytest.mark.parametrize("mode", [0, 3, 1], ids=["eager", "fused_halo", "fused"])
 def test_binary_steps_on_the_slab_path(mode):
     """ndist = 2 with the X halo of both distributions and of phi through a
     1-rank RCCL ring = the single-rank run, bit for bit."""
@@ -219,6 +219,46 @@ def test_binary_steps_on_the_slab_path(mode):
         lb.free()
     assert np.array_equal(out[0], out[1])
     assert relmax(out[1], interior(g["f_final"], 1)) < 1e-12
+
+
+def test_binary_fused_is_eager_at_every_observation():
+    """FUSED with two distributions on one GPU (halo swap and propagation of
+    both pending between steps): copies out after any call of the step and phi
+    taken from the pending state equal EAGER bit for bit."""
+    import ludwig_amd
+    import torch
+    g = load_golden("bin_q19_a")
+    meta = g["meta"]
+    obs = []
+    for mode in (0, 1):
+        rec = []
+        lb = _lb(meta, mode=mode)
+        hy = ludwig_amd.Hydro(lb.nall, lb.device)
+        lb.fe_scheme_set(7, 1)
+        phi = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+        grad = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+        delsq = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+        lb.lb_memcpy_h2d(g["f0"])
+        for n in range(5):
+            lb.phi_to_field(phi)
+            rec.append(interior(_host(lb, phi), 1).copy())
+            lb.field_halo_n(phi, 1)
+            lb.field_grad(phi, grad, delsq)
+            lb.lb_collide_binary(hy, meta["a"], meta["b"], meta["kappa"],
+                                 meta["mobility"], phi, grad, delsq)
+            if n == 1:
+                rec.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+            lb.lb_halo()
+            if n == 2:
+                rec.append(lb.lb_memcpy_d2h().copy())       # the halo of both included
+            lb.lb_propagation()
+            if n == 3:
+                rec.append(interior(lb.lb_memcpy_d2h(), 1).copy())   # flushes
+        rec.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+        lb.free()
+        obs.append(rec)
+    for a, b in zip(obs[0], obs[1]):
+        assert np.array_equal(a, b)
 
 
 def test_binary_fused_halo_is_eager_at_every_observation():

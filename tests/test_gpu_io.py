@@ -144,7 +144,8 @@ def test_slabs_write_one_file(tmp_path):
 def test_reference_reads_files_written_here(name, nvel, tmp_path):
     exe = os.path.join(REF, "ref_driver_d3q%d" % nvel)
     if not os.path.exists(exe):
-        pytest.skip("compiled reference (oracle/_ref) not on this box")
+        pytest.fail("compiled reference (oracle/_ref) is missing: `make -C oracle ref` "
+                    "in the development container")
     import ludwig_amd
     g = load_io_golden(name)
     n = _nlocal(g)

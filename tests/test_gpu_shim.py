@@ -26,7 +26,10 @@ KEYS = ("f_collide", "rho", "u", "f_halo", "f_prop", "f_final")
 def _exe(nvel, shim):
     exe = os.path.join(REF, "ref_driver_hip_d3q%d%s" % (nvel, "_shim" if shim else ""))
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/%s not built (make -C oracle hip)" % os.path.basename(exe))
+        # (not a skip: the binaries travel with the snapshot, and a missing one
+        # would silently take the whole boundary out of the suite)
+        pytest.fail("oracle/_ref/%s is missing: build it in the development "
+                    "container with `make -C oracle hip`" % os.path.basename(exe))
     return exe
 
 
@@ -147,7 +150,7 @@ def _compare_fe(out, g):
         assert relmax(interior(out[key], 1), interior(g[key], 1)) < 1e-12, key
 
 
-@pytest.mark.parametrize("mode", ["eager", "halo"])
+@pytest.mark.parametrize("mode", ["eager", "halo", "fused"])
 @pytest.mark.parametrize("case", mg.BINARY_CASES, ids=[c[0] for c in mg.BINARY_CASES])
 def test_shim_two_distribution_step(case, mode):
     """free_energy symmetric_lb inside the reference: phi_lb_to_field,
@@ -188,12 +191,16 @@ def _ludwig(inp, mode, shim=True, extra_env=None):
     gpurun_out/ (merged back from the GPU box) and in the assertion message."""
     exe = os.path.join(REF, "ludwig_hip_d3q19" + ("_shim" if shim else ""))
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/%s not built (make -C oracle hip)" % os.path.basename(exe))
+        # (not a skip: the binaries travel with the snapshot, and a missing one
+        # would silently take the whole boundary out of the suite)
+        pytest.fail("oracle/_ref/%s is missing: build it in the development "
+                    "container with `make -C oracle hip`" % os.path.basename(exe))
     env = dict(os.environ)
     env.pop("LBMI_MODE", None)
     if mode is not None:
         env["LBMI_MODE"] = mode
     env.pop("LBMI_FE", None)
+    env.pop("LBMI_HYDRO", None)
     env.update(extra_env or {})
     import shutil
     with tempfile.TemporaryDirectory() as tmp:
@@ -268,7 +275,7 @@ def test_ludwig_binary_fluid_droplet_with_the_binding(mode):
             assert abs(a - b) <= 2e-8 * abs(b) + 1e-16
 
 
-@pytest.mark.parametrize("mode", ["eager", "halo"])
+@pytest.mark.parametrize("mode", ["eager", "halo", "fused"])
 @pytest.mark.parametrize("name", ["spin_lb1", "symm_dr2", "spin_fd1", "symm_pat"])
 def test_ludwig_application_more_regressions(name, mode):
     """spin_lb1: free_energy symmetric_lb (two distributions, ghost modes
@@ -424,3 +431,27 @@ def test_the_free_energy_binding_leaves_other_cases_to_the_reference():
     assert "bound (LBMI_FE=1)" not in log
     rho = _last(log, "[rho]")
     assert rho[0] == ref["rho"][0] and abs(rho[2] - ref["rho"][2]) <= 1e-12
+
+
+@pytest.mark.parametrize("mode", ["halo", "fused"])
+@pytest.mark.parametrize("name", ["dist_1dp", "rect_ct1"])
+def test_ludwig_with_lazy_hydro(name, mode):
+    """LBMI_HYDRO=lazy: lb_collide does not store hydro->rho, u; the velocity
+    statistics (hydro_memcpy, then stats_velocity_minmax on the host) get
+    them formed from the post-collision distributions: the extrema of the
+    reference's logs (Poiseuille start, ten steps; the duct between walls,
+    a hundred steps with hydro_u_zero every step and solid sites at rest)."""
+    if name == "dist_1dp":
+        ref = _json.load(open(os.path.join(HERE, "golden", "regression_d3q19_short.json")))
+        ref = ref["serial-dist-1dp"]["final"]
+        rho_ref = (ref["rho_total"], ref["rho_min"], ref["rho_max"])
+    else:
+        ref = _json.load(open(os.path.join(HERE, "golden", "regression_app_extra.json")))[name]
+        rho_ref = (ref["rho"][0], ref["rho"][3], ref["rho"][4])
+    log = _ludwig(name + ".inp", mode, extra_env={"LBMI_HYDRO": "lazy"})
+    rho = _last(log, "[rho]")
+    assert rho[0] == rho_ref[0]
+    assert abs(rho[3] - rho_ref[1]) < 2e-11 and abs(rho[4] - rho_ref[2]) < 2e-11
+    for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
+        for a, b in zip(_last(log, tag), ref[key]):
+            assert abs(a - b) <= 2e-7 * abs(b) + 1e-14
