@@ -94,8 +94,8 @@ def binary(args, mode):
     ms = timed(step, lb, args.steps)
     sites = n[0] * n[1] * n[2]
     if mode != ludwig_amd.EAGER:
-        print("two distributions (symmetric_lb), FUSED_HALO: %.4f ms/step = %.0f MLUPS"
-              % (ms, 1e-3 * sites / ms), flush=True)
+        print("two distributions (symmetric_lb), %s: %.4f ms/step = %.0f MLUPS"
+              % ({3: "FUSED_HALO", 1: "FUSED"}[mode], ms, 1e-3 * sites / ms), flush=True)
         lb.free()
         return
     parts = {}
@@ -124,6 +124,7 @@ def main():
             walls(args, mode, slip)
     binary(args, ludwig_amd.EAGER)
     binary(args, ludwig_amd.FUSED_HALO)
+    binary(args, ludwig_amd.FUSED)
 
 
 if __name__ == "__main__":
