@@ -1794,6 +1794,30 @@ enum {FT_X = 4, FT_Y = 8, FT_Z = 32, FT_H = 2,
  * neighbour across a face from the opposite face -- so that neither phi nor
  * u needs a halo swap beforehand (single rank). */
 
+/* What the force and the fluxes need from one site: grad phi, the isotropic
+ * part p0 of the pressure tensor and the chemical potential (symmetric.c:
+ * 371-420: P_ab = p0 delta_ab + kappa d_a phi d_b phi, mu = a phi + b phi^3 -
+ * kappa delsq phi), from the phi tile */
+
+struct FeSite {
+  double g[3];
+  double p0;
+  double mu;
+};
+
+template <int NPT>
+__device__ __forceinline__
+FeSite fe_eval(const Symm & q, const double * __restrict__ tile, int lp) {
+  FeSite e;
+  double d2;
+  grad_at<NPT>(tile, (size_t) lp, FT_LY*FT_LZ, FT_LZ, e.g, d2);
+  const double ph = tile[lp];
+  e.p0 = 0.5*q.a*ph*ph + 0.75*q.b*ph*ph*ph*ph - q.kappa*ph*d2
+    - 0.5*q.kappa*(e.g[0]*e.g[0] + e.g[1]*e.g[1] + e.g[2]*e.g[2]);
+  e.mu = q.a*ph + q.b*ph*ph*ph - q.kappa*d2;
+  return e;
+}
+
 template <bool ACCUMULATE, int NPT, bool WRAP>
 __global__ __launch_bounds__(FT_Y*FT_Z)
 void k_symm_fe_step_tiled(lbmi_kparam_t kp, Symm q, double mobility, int order,
@@ -1813,48 +1837,165 @@ void k_symm_fe_step_tiled(lbmi_kparam_t kp, Symm q, double mobility, int order,
   const int nh = kp.nhalo;
   const int x0 = nh + bx*FT_X, y0 = nh + by*FT_Y, z0 = nh + bz*FT_Z;
 
-  for (int l = (int) threadIdx.x; l < FT_LX*FT_LY*FT_LZ; l += FT_Y*FT_Z) {
-    const int lz = l % FT_LZ, ly = (l / FT_LZ) % FT_LY, lx = l / (FT_LZ*FT_LY);
-    int gx = x0 - FT_H + lx, gy = y0 - FT_H + ly, gz = z0 - FT_H + lz;
-    double v = 0.0;
-    if (gx < kp.nall[0] && gy < kp.nall[1] && gz < kp.nall[2]) {
+  /* This thread's column, and the velocities of its first site: issued before
+   * the tile is loaded, so that their latency is behind the loader's (the
+   * pass is bound by the latency of dependent loads, not by HBM or FP64
+   * issue: profiles/r02_fe_pass_counters.txt) */
+  const int tz = (int) threadIdx.x % FT_Z, ty = (int) threadIdx.x / FT_Z;
+  const int gy = y0 + ty, gz = z0 + tz;
+  const bool mine = (gy < nh + kp.nlocal[1] && gz < nh + kp.nlocal[2]);
+  const size_t ns = (size_t) kp.nsite;
+  int up[3] = {kp.strx, kp.stry, 1};
+  int um[3] = {-kp.strx, -kp.stry, -1};
+  if constexpr (WRAP) {
+    if (gy == nh + kp.nlocal[1] - 1) up[1] = -(kp.nlocal[1] - 1)*kp.stry;
+    if (gy == nh) um[1] = (kp.nlocal[1] - 1)*kp.stry;
+    if (gz == nh + kp.nlocal[2] - 1) up[2] = -(kp.nlocal[2] - 1);
+    if (gz == nh) um[2] = kp.nlocal[2] - 1;
+  }
+  /* un[id]: u_id at the site, at its + and at its - neighbour in direction id */
+  double un[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  auto load_u = [&](int gx) {
+    const int i = gx*kp.strx + gy*kp.stry + gz;
+    if constexpr (WRAP) {
+      up[0] = (gx == nh + kp.nlocal[0] - 1) ? -(kp.nlocal[0] - 1)*kp.strx : kp.strx;
+      um[0] = (gx == nh) ? (kp.nlocal[0] - 1)*kp.strx : -kp.strx;
+    }
+    static_for<0, 3>([&](auto D) {
+      constexpr int id = D;
+      un[id][0] = u[ns*id + i];
+      un[id][1] = u[ns*id + (size_t) (i + up[id])];
+      un[id][2] = u[ns*id + (size_t) (i + um[id])];
+    });
+  };
+  /* (27-point gradients: the evaluations already take every register there
+   * is; requesting the velocities a site ahead costs more than it hides) */
+  constexpr bool AHEAD = (NPT == 7);
+  if (AHEAD && mine && x0 < nh + kp.nlocal[0]) load_u(x0);
+
+  /* The tile, a row of FT_LZ values per thread group: the thread's z column
+   * and its (at most two) rows are fixed, so that the loop over the x planes
+   * carries no division and the wrap of x is scalar work. */
+  {
+    enum {ROWS = (FT_Y*FT_Z)/FT_LZ};                 /* rows loaded at a time */
+    const int lz = (int) threadIdx.x % FT_LZ;
+    const int r0 = (int) threadIdx.x / FT_LZ;        /* ROWS*FT_LZ <= threads */
+    int gz = z0 - FT_H + lz;
+    bool okz = (r0 < ROWS) && (gz < kp.nall[2]);
+    if constexpr (WRAP) {
+      /* a halo coordinate (at most nhalo <= nlocal away) -> its image */
+      if (gz < nh) gz += kp.nlocal[2];
+      else if (gz >= nh + kp.nlocal[2]) gz -= kp.nlocal[2];
+    }
+    for (int ly = r0; ly < FT_LY; ly += ROWS) {
+      int gy = y0 - FT_H + ly;
+      const bool ok = okz && (gy < kp.nall[1]);
       if constexpr (WRAP) {
-	/* a halo coordinate (at most nhalo <= nlocal away) -> its image */
-	if (gx < nh) gx += kp.nlocal[0];
-	else if (gx >= nh + kp.nlocal[0]) gx -= kp.nlocal[0];
 	if (gy < nh) gy += kp.nlocal[1];
 	else if (gy >= nh + kp.nlocal[1]) gy -= kp.nlocal[1];
-	if (gz < nh) gz += kp.nlocal[2];
-	else if (gz >= nh + kp.nlocal[2]) gz -= kp.nlocal[2];
       }
-      v = phi[(size_t) gx*kp.strx + (size_t) gy*kp.stry + gz];
+      const size_t rowoff = (size_t) gy*kp.stry + gz;
+      for (int lx = 0; lx < FT_LX; lx++) {
+	int gx = x0 - FT_H + lx;
+	const bool okx = (gx < kp.nall[0]);
+	if constexpr (WRAP) {
+	  if (gx < nh) gx += kp.nlocal[0];
+	  else if (gx >= nh + kp.nlocal[0]) gx -= kp.nlocal[0];
+	}
+	if (r0 < ROWS) {
+	  tile[(lx*FT_LY + ly)*FT_LZ + lz] =
+	    (ok && okx) ? phi[(size_t) gx*kp.strx + rowoff] : 0.0;
+	}
+      }
     }
-    tile[l] = v;
   }
   __syncthreads();
 
-  const int tz = (int) threadIdx.x % FT_Z, ty = (int) threadIdx.x / FT_Z;
-  const int gy = y0 + ty, gz = z0 + tz;
-  if (gy >= nh + kp.nlocal[1] || gz >= nh + kp.nlocal[2]) return;
+  if (!mine) return;
 
-  for (int tx = 0; tx < FT_X; tx++) {
+  constexpr int pstr[3] = {FT_LY*FT_LZ, FT_LZ, 1};
+  const double wz = (kp.nlocal[2] == 1) ? 0.0 : 1.0;
+
+  /* the thread walks FT_X sites along x: what it evaluated at x + 1 is the
+   * centre of the next site and the x - 1 neighbour of the one after, so a
+   * site costs five evaluations (x + 1, y +- 1, z +- 1), not seven */
+  int ip = ((0 + FT_H)*FT_LY + (ty + FT_H))*FT_LZ + (tz + FT_H);
+  FeSite em = fe_eval<NPT>(q, tile, ip - pstr[0]);
+  FeSite ec = fe_eval<NPT>(q, tile, ip);
+
+  for (int tx = 0; tx < FT_X; tx++, ip += pstr[0]) {
     const int gx = x0 + tx;
     if (gx >= nh + kp.nlocal[0]) break;
     const int i = gx*kp.strx + gy*kp.stry + gz;
-    const int ip = ((tx + FT_H)*FT_LY + (ty + FT_H))*FT_LZ + (tz + FT_H);
-    int up[3] = {kp.strx, kp.stry, 1};
-    int um[3] = {-kp.strx, -kp.stry, -1};
-    if constexpr (WRAP) {
-      if (gx == nh + kp.nlocal[0] - 1) up[0] = -(kp.nlocal[0] - 1)*kp.strx;
-      if (gx == nh) um[0] = (kp.nlocal[0] - 1)*kp.strx;
-      if (gy == nh + kp.nlocal[1] - 1) up[1] = -(kp.nlocal[1] - 1)*kp.stry;
-      if (gy == nh) um[1] = (kp.nlocal[1] - 1)*kp.stry;
-      if (gz == nh + kp.nlocal[2] - 1) up[2] = -(kp.nlocal[2] - 1);
-      if (gz == nh) um[2] = kp.nlocal[2] - 1;
+    /* the velocities of this site have arrived by now; those of the next
+     * one are requested before anything is computed with these */
+    double uc[3][3];
+    if constexpr (!AHEAD) load_u(gx);
+    static_for<0, 9>([&](auto N) { uc[N/3][N % 3] = un[N/3][N % 3]; });
+    if (AHEAD && tx + 1 < FT_X && gx + 1 < nh + kp.nlocal[0]) load_u(gx + 1);
+    const FeSite ep = fe_eval<NPT>(q, tile, ip + pstr[0]);
+    const double phi0 = tile[ip];
+    double f[3] = {0.0, 0.0, 0.0};
+    double fhi[3], flo[3];
+
+    static_for<0, 3>([&](auto D) {
+      constexpr int id = D;
+      FeSite hi, lo;
+      if constexpr (id == 0) {
+	hi = ep;
+	lo = em;
+      }
+      else {
+	hi = fe_eval<NPT>(q, tile, ip + pstr[id]);
+	lo = fe_eval<NPT>(q, tile, ip - pstr[id]);
+      }
+      /* F_a = -d_b P_ab: -(1/2)(P(+) + P(0)) + (1/2)(P(-) + P(0)), column id
+       * (phi_force.c / pth_force_fluid_kernel, the reference's association) */
+      static_for<0, 3>([&](auto A) {
+	constexpr int ia = A;
+	const double c0 = ((ia == id) ? ec.p0 : 0.0) + q.kappa*ec.g[ia]*ec.g[id];
+	const double cp = ((ia == id) ? hi.p0 : 0.0) + q.kappa*hi.g[ia]*hi.g[id];
+	const double cm = ((ia == id) ? lo.p0 : 0.0) + q.kappa*lo.g[ia]*lo.g[id];
+	f[ia] -= 0.5*(cp + c0);
+	f[ia] += 0.5*(cm + c0);
+      });
+      const double ud0 = uc[id][0];
+      double pm2 = 0.0, pp2 = 0.0;
+      if (order > 2) {
+	pm2 = tile[ip - 2*pstr[id]];
+	pp2 = tile[ip + 2*pstr[id]];
+      }
+      const double pm1 = tile[ip - pstr[id]], pp1 = tile[ip + pstr[id]];
+      {
+	const double uf = 0.5*(ud0 + uc[id][1]);
+	double fl = adv_flux(order, false, uf, pm1, phi0, pp1, pp2);
+	fl -= mobility*(hi.mu - ec.mu);
+	fhi[id] = fl;
+      }
+      {
+	const double uf = 0.5*(ud0 + uc[id][2]);
+	double fl = adv_flux(order, id == 0, uf, pm2, pm1, phi0, pp1);
+	fl -= mobility*(ec.mu - lo.mu);
+	flo[id] = fl;
+      }
+    });
+
+    if constexpr (ACCUMULATE) {
+      force[i] += f[0];
+      force[ns + i] += f[1];
+      force[2*ns + i] += f[2];
     }
-    fe_step_site<ACCUMULATE, NPT>(kp, q, mobility, order, tile, ip,
-				  FT_LY*FT_LZ, FT_LZ, nullptr, nullptr, u,
-				  force, phi_out, i, up, um);
+    else {
+      /* hydro_f_zero + add in one store: the caller asserts that nothing
+       * else has contributed to the force field this step */
+      force[i] = f[0];
+      force[ns + i] = f[1];
+      force[2*ns + i] = f[2];
+    }
+    phi_out[i] = phi0 - (+ fhi[0] - flo[0] + fhi[1] - flo[1]
+			 + wz*fhi[2] - wz*flo[2]);
+    em = ec;
+    ec = ep;
   }
 }
 
