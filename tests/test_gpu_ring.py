@@ -211,3 +211,81 @@ def test_ring_needs_own_streams_and_matching_size():
         lb.comm_init_ring(ring)
     lb.free()
     ring.free()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_binary_fluid_step_on_slabs(world):
+    """BASELINE config 4 on slabs (nhalo 2): field halo of phi (two layers) and
+    of u over the ring, the one-pass force + Cahn-Hilliard kernel, the FUSED LB
+    step with its own exchange buffers in between -- against the oracle's
+    single domain."""
+    import ludwig_amd
+    import torch
+    ntotal, h, nsteps = (12, 10, 8), 2, 4
+    a, b, kappa, mob = -0.00625, 0.00625, 0.004, 1.25
+    p = lbo.make_param(19, ntotal, h, "m10", 0.1, 0.3)
+    rng = np.random.default_rng(23)
+    phi0 = np.zeros(lbo.nall(p))
+    interior(phi0, h)[...] = 0.1 * rng.standard_normal(ntotal)
+    f0 = lbo.init_synthetic(p)
+    phi, f = phi0.copy(), f0.copy()
+    fp = np.zeros_like(f)
+    u = np.zeros((3,) + phi.shape)
+    rho = np.zeros(phi.shape)
+    for _ in range(nsteps):
+        force = np.zeros((3,) + phi.shape)
+        lbo.field_halo(p, phi, 2)
+        grad, delsq = lbo.grad(p, phi, 7)
+        lbo.symm_force(p, a, b, kappa, phi, grad, delsq, force)
+        lbo.field_halo(p, u, 1)
+        lbo.cahn_hilliard(p, a, b, kappa, mob, phi, delsq, u, order=2)
+        u[...] = 0.0
+        f, fp = lbo.step(p, f, fp, force, None, rho, u)
+
+    ring = ludwig_amd.Ring(world)
+    out = [None] * world
+    err = []
+    start = threading.Barrier(world)
+
+    def rank_main(rank):
+        try:
+            dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, h)
+            x0, nx = dec.noffset[0], dec.nlocal[0]
+            lb = ludwig_amd.LB(19, dec.nlocal, h, mode=ludwig_amd.FUSED, cartsz=world,
+                               cartrank=rank, own_stream=True,
+                               halo_scheme=ludwig_amd.HALO_REDUCED)
+            lb.relaxation_set("m10", 0.1, 0.3)
+            lb.fe_scheme_set(7, 2)
+            lb.comm_init_ring(ring)
+            hy = ludwig_amd.Hydro(lb.nall, lb.device, force=np.zeros((3,) + lb.nall))
+            pa = torch.from_numpy(np.ascontiguousarray(phi0[x0:x0 + nx + 2 * h])).to(lb.device)
+            pb = torch.zeros_like(pa)
+            torch.cuda.synchronize()
+            lb.lb_memcpy_h2d(np.ascontiguousarray(f0[:, x0:x0 + nx + 2 * h]))
+            start.wait()
+            for _ in range(nsteps):
+                lb.field_halo_n(pa, 2)
+                lb.field_halo_n(hy.u, 1)
+                lb.symmetric_step(a, b, kappa, mob, pa, hy.u, hy.force, pb, accumulate=False)
+                pa, pb = pb, pa
+                lb.step(hy)
+            fo = lb.lb_memcpy_d2h()
+            lb.synchronize()
+            torch.cuda.synchronize()
+            out[rank] = (interior(fo, h).copy(), interior(pa.cpu().numpy(), h).copy())
+            start.wait()
+            lb.free()
+        except Exception as e:           # noqa: BLE001
+            err.append((rank, repr(e)))
+            ring.abort()
+            start.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not err, err
+    ring.free()
+    assert relmax(np.concatenate([o[1] for o in out], axis=0), interior(phi, h)) < 1e-12
+    assert relmax(np.concatenate([o[0] for o in out], axis=1), interior(f, h)) < 1e-12
