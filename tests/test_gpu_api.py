@@ -230,7 +230,10 @@ def test_random_call_sequences_match_eager(mode, seed, tmp_path):
     """State-machine fuzz: a random but legal interleaving of the step calls
     with observers (device-to-host copies, moments, record packs, file
     round trips, lbmi_lb_run) and tuning switches; every observation must be
-    what EAGER shows at the same point of the same sequence."""
+    what EAGER shows at the same point of the same sequence. Since round 2
+    the sequences also switch rho, u on demand on and off, ask for u
+    (lbmi_lb_hydro_sync) at any point, and change the execution mode of the
+    handle in mid-run (lbmi_lb_mode_set)."""
     _fuzz(mode, seed, tmp_path, ring=False)
 
 
@@ -263,6 +266,15 @@ def _fuzz(mode, seed, tmp_path, ring):
                 script.append(("moments",))
             elif r < 0.32:
                 script.append(("records",))
+            elif r < 0.40:
+                script.append(("u",))
+        r2 = rng.random()
+        if r2 < 0.2:
+            script.append(("tune", "hydro_lazy", int(rng.integers(0, 2))))
+        elif r2 < 0.3:
+            script.append(("mode_set", int(rng.choice([0, 1, 3]))))
+        elif r2 < 0.4 and ring:
+            script.append(("tune", "x_direct", int(rng.integers(0, 2))))
         r = rng.random()
         if r < 0.2:
             script.append(("tune", "blocked", int(rng.integers(0, 2))))
@@ -301,6 +313,13 @@ def _fuzz(mode, seed, tmp_path, ring):
                 seen.append(lb.moments(hy.status))
             elif act[0] == "records":
                 seen.append(lb.lb_io_aggr_pack().copy())
+            elif act[0] == "u":
+                # rho, u of the last collision: owed by a lazy one, there already otherwise
+                lb.hydro_sync()
+                seen.append(host_u(lb, hy))
+            elif act[0] == "mode_set":
+                if run_mode != 0:
+                    lb.mode_set(act[1])
             elif act[0] == "tune":
                 lb.tune(act[1], act[2])
             elif act[0] == "io":
@@ -309,6 +328,7 @@ def _fuzz(mode, seed, tmp_path, ring):
             elif act[0] == "run":
                 lb.run(hy, act[1])
         seen.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+        lb.hydro_sync()
         seen.append(host_u(lb, hy))
         lb.free()
         return seen
