@@ -404,6 +404,16 @@ int lbmi_lb_moments(lbmi_t * lb, const char * status, double out[9]);
  * that adds them in that order prints the reference's CPU digits. */
 int lbmi_lb_density(lbmi_t * lb, double * rho_host);
 
+/* cahn_stats_reduce (cahn_hilliard_stats.c:123-215; the numbers behind the
+ * "[phi]" line of cahn_hilliard_stats and phi->field_init_sum of
+ * cahn_hilliard_stats_time0) for any scalar device field of nsite doubles:
+ * over the interior sites that are MAP_FLUID in `status` (NULL: all), out
+ * (HOST array of 5) = volume, sum (Kahan-compensated), sum of squares,
+ * minimum, maximum. One pass and a tree reduction where the reference runs
+ * three kernels with a serial loop under a lock each. Local to this rank. */
+int lbmi_field_stats(lbmi_t * lb, const double * field, const char * status,
+		     double out[5]);
+
 /* hydro->rho and hydro->u on demand (lbmi_tune "hydro_lazy", 1; FUSED and
  * FUSED_HALO): lbmi_lb_collide then does not store them (32 B/site per step)
  * but remembers the arrays it was given, and lbmi_lb_hydro_sync -- or

@@ -28,6 +28,8 @@
  *      stats_distribution_print(), stats_distribution_momentum()
  *                        stats_distribution.h (stats_distribution.c:55-139): the
  *                        density statistics and the Kahan-summed momentum
+ *      cahn_hilliard_stats(), cahn_hilliard_stats_time0()
+ *                        cahn_hilliard_stats.h: the statistics of phi
  *      phi_force_calculation() phi_force.h, phi_cahn_hilliard()
  *                        phi_cahn_hilliard.h: with LBMI_FE=1 and the symmetric
  *                        free energy in the plain periodic fluid case
@@ -57,7 +59,9 @@
  *  -Dstats_distribution_print=stats_distribution_print_ref
  *  -Dstats_distribution_momentum=stats_distribution_momentum_ref, phi_force.c
  *  with -Dphi_force_calculation=phi_force_calculation_ref, phi_cahn_hilliard.c
- *  with -Dphi_cahn_hilliard=phi_cahn_hilliard_ref) so that their originals remain
+ *  with -Dphi_cahn_hilliard=phi_cahn_hilliard_ref, cahn_hilliard_stats.c with
+ *  -Dcahn_hilliard_stats=cahn_hilliard_stats_ref -Dcahn_hilliard_stats_time0=
+ *  cahn_hilliard_stats_time0_ref) so that their originals remain
  *  available as fall-backs (colloids, Lees-Edwards, host halo
  *  schemes, noise), and this file is compiled
  *  with the same -D_D3Q19_|-D_D3Q27_ -DADDR_SOA as the rest of libludwig.a
@@ -102,6 +106,7 @@
 #include "phi_force_stress.h"
 #include "phi_cahn_hilliard.h"
 #include "advection.h"
+#include "cahn_hilliard_stats.h"
 #include "fe_force_method.h"
 
 #include "lbmi.h"
@@ -129,6 +134,8 @@ int phi_force_calculation_ref(pe_t * pe, cs_t * cs, lees_edw_t * le,
 			      map_t * map, field_t * phi, hydro_t * hydro);
 int phi_cahn_hilliard_ref(phi_ch_t * pch, fe_t * fe, field_t * phi,
 			  hydro_t * hydro, map_t * map, noise_t * noise);
+int cahn_hilliard_stats_ref(phi_ch_t * pch, field_t * phi, map_t * map);
+int cahn_hilliard_stats_time0_ref(phi_ch_t * pch, field_t * phi, map_t * map);
 int phi_lb_to_field_ref(field_t * phi, lb_t * lb);
 int hydro_u_zero_ref(hydro_t * hydro, const double uzero[3]);
 int hydro_f_zero_ref(hydro_t * hydro, const double fzero[3]);
@@ -1177,5 +1184,110 @@ int phi_cahn_hilliard(phi_ch_t * pch, fe_t * fe, field_t * phi,
     SHIM_CHECK(shim_.lb, lbmi_field_interior_copy(shim_.h, 1, scratch, phid));
   }
 
+  return 0;
+}
+
+/*****************************************************************************
+ *
+ *  cahn_hilliard_stats, cahn_hilliard_stats_time0
+ *  (cahn_hilliard_stats.c:52-215)
+ *
+ *  The sum, variance and extrema of phi that ludwig.c prints at every
+ *  statistics step (and phi->field_init_sum at start-up). The reference
+ *  collects them with three kernels whose blocks take turns under a
+ *  compare-and-swap lock: 4.3 ms per call at 32^3, about 5 s at 128^3 -- ten of
+ *  the sixteen seconds the 100-step droplet run takes with everything else
+ *  bound (profiles/r02_app_timing.txt). Here: one pass and a tree reduction
+ *  (lbmi_field_stats), Kahan-compensated as there. Not for the "conserve"
+ *  variants (a doubly compensated sum against a correction field).
+ *
+ *  The first call comes at start-up (ludwig.c:429), before an lb_t has
+ *  passed through this file: a handle of its own, made from the coordinate
+ *  system of phi, serves the calls that need no distributions.
+ *
+ *****************************************************************************/
+
+static lbmi_t * shim_field_handle(cs_t * cs) {
+  static lbmi_t * aux = NULL;
+  static int aux_nlocal[3] = {0, 0, 0};
+  lbmi_t * h = shim_handle_if_any(cs);
+  int nlocal[3];
+  if (h != NULL) return h;
+  if (DATA_MODEL != DATA_MODEL_SOA) return NULL;
+  cs_nlocal(cs, nlocal);
+  if (aux != NULL && (nlocal[X] != aux_nlocal[X] || nlocal[Y] != aux_nlocal[Y] ||
+		      nlocal[Z] != aux_nlocal[Z])) {
+    lbmi_free(aux);
+    aux = NULL;
+  }
+  if (aux == NULL) {
+    lbmi_options_t opts;
+    lbmi_options_default(&opts);
+    cs_nlocal(cs, opts.nlocal);
+    cs_nhalo(cs, &opts.nhalo);
+    if (lbmi_create(&opts, &aux) != 0) return NULL;    /* the original will do */
+    if (lbmi_set_stream(aux, NULL) != 0) {
+      lbmi_free(aux);
+      aux = NULL;
+      return NULL;
+    }
+    cs_nlocal(cs, aux_nlocal);
+  }
+  return aux;
+}
+
+static int shim_phi_stats(phi_ch_t * pch, field_t * phi, map_t * map,
+			  double stats[5]) {
+  lbmi_t * h = NULL;
+  double local[5];
+  MPI_Comm comm;
+  if (pch->info.conserve != 0 || phi->nf != 1) return 0;
+  if (phi->le && lees_edw_nplane_total(phi->le) > 0) return 0;
+  h = shim_field_handle(phi->cs);
+  if (h == NULL) return 0;
+  if (lbmi_field_stats(h, shim_field_data(phi),
+		       (char *) shim_cached(map, &map->target->status, sizeof(char *)),
+		       local) != 0) {
+    pe_fatal(pch->pe, "liblbmi: %s (%s:%d)\n", lbmi_last_error(), __FILE__, __LINE__);
+  }
+  pe_mpi_comm(pch->pe, &comm);
+  /* (across ranks a plain sum of the compensated local sums; the reference
+   * merges the compensation terms too, cahn_hilliard_stats.c:187-199) */
+  MPI_Reduce(local + 0, stats + 0, 3, MPI_DOUBLE, MPI_SUM, 0, comm);
+  MPI_Reduce(local + 3, stats + 3, 1, MPI_DOUBLE, MPI_MIN, 0, comm);
+  MPI_Reduce(local + 4, stats + 4, 1, MPI_DOUBLE, MPI_MAX, 0, comm);
+  return 1;
+}
+
+int cahn_hilliard_stats_time0(phi_ch_t * pch, field_t * phi, map_t * map) {
+  double stats[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  MPI_Comm comm;
+  assert(pch);
+  assert(phi);
+  assert(map);
+  if (!shim_phi_stats(pch, phi, map, stats)) {
+    return cahn_hilliard_stats_time0_ref(pch, phi, map);
+  }
+  pe_mpi_comm(pch->pe, &comm);
+  phi->field_init_sum = stats[1];
+  MPI_Bcast(&phi->field_init_sum, 1, MPI_DOUBLE, 0, comm);
+  return 0;
+}
+
+int cahn_hilliard_stats(phi_ch_t * pch, field_t * phi, map_t * map) {
+  double stats[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  assert(pch);
+  assert(phi);
+  assert(map);
+  if (!shim_phi_stats(pch, phi, map, stats)) {
+    return cahn_hilliard_stats_ref(pch, phi, map);
+  }
+  {
+    double rvol = 1.0/stats[0];
+    double fbar = rvol*stats[1];                 /* mean */
+    double fvar = rvol*stats[2] - fbar*fbar;     /* variance */
+    pe_info(pch->pe, "[phi] %14.7e %14.7e%14.7e %14.7e%14.7e\n",
+	    stats[1], fbar, fvar, stats[3], stats[4]);
+  }
   return 0;
 }

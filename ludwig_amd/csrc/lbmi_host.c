@@ -2747,6 +2747,33 @@ int lbmi_lb_moments(lbmi_t * lb, const char * status, double out[9]) {
   return lbmi_moments(lb, lb->f, status, out);
 }
 
+/* Statistics of a scalar device field (nsite doubles) over the interior sites
+ * that are fluid in `status` (or all, status == NULL): what cahn_stats_reduce
+ * collects (cahn_hilliard_stats.c:123-215). out (HOST): volume, sum
+ * (Kahan-compensated), sum of squares, minimum, maximum. Local to this rank. */
+
+int lbmi_field_stats(lbmi_t * lb, const double * field, const char * status,
+		     double out[5]) {
+  double tmp[9];
+  if (lb == NULL || field == NULL || out == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  HIPCHECK(hipSetDevice(lb->device));
+  {
+    int ifail = lbmi_hydro_touch(lb, field, NULL);
+    if (ifail) return ifail;
+  }
+  KCHECK(lbmi_k_field_stats(&lb->kp, field, status, lb->mom_work, lb->mom_out,
+			    lb->stream));
+  HIPCHECK(hipMemcpyAsync(tmp, lb->mom_out, 9*sizeof(double),
+			  hipMemcpyDeviceToHost, lb->stream));
+  HIPCHECK(hipStreamSynchronize(lb->stream));
+  out[0] = tmp[0];
+  out[1] = tmp[5];
+  out[2] = tmp[2];
+  out[3] = tmp[3];
+  out[4] = tmp[4];
+  return 0;
+}
+
 /* lb_0th_moment of every interior site (first distribution), (ic, jc, kc)
  * order, to a HOST array of nlocal[X]*nlocal[Y]*nlocal[Z] doubles: what
  * stats_distribution_print sums up. fprime, dead once nothing is pending,

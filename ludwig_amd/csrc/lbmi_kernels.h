@@ -233,6 +233,13 @@ int lbmi_k_moments(const lbmi_kparam_t * kp, const double * f,
 		   const char * status, double * work, double * out_dev,
 		   void * stream);
 
+/* Statistics of a scalar field over interior fluid sites, through the
+ * workspace and the final stage of the moments: out_dev[0] volume, [2] sum of
+ * squares, [3] min, [4] max, [5] Kahan-compensated sum */
+int lbmi_k_field_stats(const lbmi_kparam_t * kp, const double * field,
+		       const char * status, double * work, double * out_dev,
+		       void * stream);
+
 /* Host model tables (same constexpr source as the device code) */
 int lbmi_k_model(int nvel, int8_t * cv, double * wv, double * na, double * ma);
 

@@ -2302,6 +2302,42 @@ void k_moments_partial(lbmi_kparam_t kp, const double * __restrict__ f,
   if (threadIdx.x == 0) partial_store(acc, work + (size_t) blockIdx.x*MOM_NW);
 }
 
+/* k_field_stats_partial: the statistics of a scalar field over interior fluid
+ * sites that cahn_stats_reduce collects with three kernels, each a serial
+ * loop under a compare-and-swap lock per block (cahn_hilliard_stats.c:
+ * 226-480): volume, Kahan-compensated sum, sum of squares, minimum, maximum
+ * -- one pass, the reduction tree of the moments (shuffles, LDS, two stages,
+ * no atomics). The partial uses the slots of the moments: g[0] carries the
+ * compensated sum, srho2 the squares. */
+
+__global__ __launch_bounds__(BLOCK)
+void k_field_stats_partial(lbmi_kparam_t kp, const double * __restrict__ field,
+			   const char * __restrict__ status,
+			   double * __restrict__ work) {
+  const int nh = kp.nhalo;
+  const int i0 = nh*kp.strx;
+  const int i1 = (nh + kp.nlocal[0])*kp.strx;
+
+  Partial acc;
+  partial_zero(acc);
+
+  for (int i = i0 + blockIdx.x*BLOCK + threadIdx.x; i < i1;
+       i += gridDim.x*BLOCK) {
+    Site s = decode(kp, i);
+    if (!s.interior) continue;
+    if (status && status[i] != 0) continue;
+    const double v = field[i];
+    acc.vol += 1.0;
+    acc.srho2 += v*v;
+    acc.rmin = fmin(acc.rmin, v);
+    acc.rmax = fmax(acc.rmax, v);
+    kadd(acc.g[0], v);
+  }
+
+  block_reduce(acc);
+  if (threadIdx.x == 0) partial_store(acc, work + (size_t) blockIdx.x*MOM_NW);
+}
+
 __global__ __launch_bounds__(BLOCK)
 void k_moments_final(int npartial, const double * __restrict__ work,
 		     double * __restrict__ out) {
@@ -3323,6 +3359,20 @@ extern "C" int lbmi_k_density(const lbmi_kparam_t * kp, const double * f,
   if (kp->nvel == 19) hipLaunchKernelGGL(k_density<19>, grid, block, 0, st, *kp, f, rho, n);
   else if (kp->nvel == 27) hipLaunchKernelGGL(k_density<27>, grid, block, 0, st, *kp, f, rho, n);
   else return (int) hipErrorInvalidValue;
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_field_stats(const lbmi_kparam_t * kp, const double * field,
+				  const char * status, double * work,
+				  double * out_dev, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  int n = kp->nlocal[0]*kp->strx;
+  int nblk = (n + BLOCK - 1)/BLOCK;
+  if (nblk > MOM_NBLK) nblk = MOM_NBLK;
+  hipLaunchKernelGGL(k_field_stats_partial, dim3(nblk), dim3(BLOCK), 0, st, *kp,
+		     field, status, work);
+  hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(BLOCK), 0, st, nblk, work,
+		     out_dev);
   return (int) hipGetLastError();
 }
 

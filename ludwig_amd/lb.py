@@ -280,6 +280,14 @@ class LB:
             self._h, out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
+    def field_stats(self, field, status=None):
+        """lbmi_field_stats: (volume, Kahan sum, sum of squares, min, max)
+        of a scalar device field over interior fluid sites."""
+        out = (ctypes.c_double * 5)()
+        _l.check(self._lib.lbmi_field_stats(
+            self._h, _ptr(field), None if status is None else _ptr(status), out))
+        return np.array(out[:])
+
     def hydro_sync(self):
         """lbmi_lb_hydro_sync: rho, u of the last collision, if a lazy
         collision (tune hydro_lazy) still owes them."""

@@ -124,6 +124,7 @@ SYMBOLS = [
     ("lbmi_lb_memcpy_d2h", _i, [_vp, _vp]),
     ("lbmi_lb_moments", _i, [_vp, _vp, _pd]),
     ("lbmi_lb_density", _i, [_vp, _vp]),
+    ("lbmi_field_stats", _i, [_vp, _vp, _vp, _pd]),
     ("lbmi_lb_hydro_sync", _i, [_vp]),
     ("lbmi_hydro_field_dirty", _i, [_vp, _vp]),
     ("lbmi_hydro_field_set", _i, [_vp, _vp, _i, _pd]),

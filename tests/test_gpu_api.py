@@ -1,6 +1,8 @@
 """GPU tests of the remaining C-ABI surface: tuning knobs do not change
 results, error paths, moments on caller-owned arrays, timing counters."""
 
+import math
+
 import numpy as np
 import pytest
 
@@ -386,3 +388,38 @@ def test_lb_run_as_graph_equals_steps(nvel, scheme, own_stream):
         out.append(rec)
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("nlocal,nhalo", [((9, 7, 12), 1), ((16, 14, 14), 2), ((1, 5, 3), 1)])
+def test_field_stats_match_numpy(nlocal, nhalo):
+    """lbmi_field_stats (cahn_stats_reduce, cahn_hilliard_stats.c:123-215):
+    volume, compensated sum, sum of squares, extrema of a scalar field over
+    the interior sites that are fluid; halo and solid sites hold values that
+    would show if they were counted."""
+    import ludwig_amd
+    import torch
+    lb = ludwig_amd.LB(19, nlocal, nhalo)
+    rng = np.random.default_rng(3)
+    phi = 1e6 * np.ones(lb.nall)                          # halo: poison
+    interior(phi, nhalo)[...] = 0.3 * rng.standard_normal(nlocal) + 1e-3
+    status = np.zeros(lb.nall, dtype=np.int8)
+    h = nhalo
+    if nlocal[0] > 4:
+        status[h + 1:h + 3, h:h + 2, h + 1:h + 4] = 1
+        phi[h + 1:h + 3, h:h + 2, h + 1:h + 4] = -1e6    # solid: poison
+    dphi = torch.from_numpy(phi).to(lb.device)
+    dst = torch.from_numpy(status).to(lb.device)
+    torch.cuda.synchronize()
+    for st, mask in ((dst, interior(status, h) == 0), (None, None)):
+        if st is None:
+            if nlocal[0] > 4:
+                continue                                   # (the poison would count)
+            vals = interior(phi, h).ravel()
+        else:
+            vals = interior(phi, h)[mask]
+        out = lb.field_stats(dphi, st)
+        assert out[0] == vals.size
+        assert abs(out[1] - math.fsum(vals)) <= 4e-16 * np.abs(vals).sum()
+        assert abs(out[2] - math.fsum(vals * vals)) <= 1e-14 * (vals * vals).sum()
+        assert out[3] == vals.min() and out[4] == vals.max()
+    lb.free()

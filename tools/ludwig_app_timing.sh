@@ -4,7 +4,7 @@
 R=$PWD/oracle/_ref
 run() {  # name exe mode
   d=$(mktemp -d); cp $1 $d/input
-  ( cd $d && LBMI_MODE=$3 timeout -k 10 150 $2 > log 2>&1; echo "exit $?"; echo "== $(basename $1) $(basename $2) LBMI_MODE=$3"; grep -E "Time step loop|Collision:|Propagation:|Lattice halos|Force calculation|phi update|phi gradients|finished|Total:" log; tail -3 log )
+  ( cd $d && LBMI_MODE=$3 LBMI_FE=${4:-0} LBMI_HYDRO=${5:-} timeout -k 10 150 $2 > log 2>&1; echo "exit $?"; echo "== $(basename $1) $(basename $2) LBMI_MODE=$3 LBMI_FE=${4:-0} LBMI_HYDRO=${5:-}"; grep -E "Time step loop|Collision:|Propagation:|Lattice halos|Force calculation|phi update|phi gradients|finished|Total:" log; tail -3 log )
   rm -rf $d
 }
 t=$(mktemp -d)
@@ -43,6 +43,8 @@ config_at_end no
 EOT
 run $t/single256 $R/ludwig_hip_d3q19 eager
 for m in eager halo fused; do run $t/single256 $R/ludwig_hip_d3q19_shim $m; done
+run $t/single256 $R/ludwig_hip_d3q19_shim fused 0 lazy
 run $t/binary128 $R/ludwig_hip_d3q19 eager
-for m in eager fused; do run $t/binary128 $R/ludwig_hip_d3q19_shim $m; done
+for m in halo fused; do run $t/binary128 $R/ludwig_hip_d3q19_shim $m; done
+run $t/binary128 $R/ludwig_hip_d3q19_shim fused 1
 rm -rf $t
