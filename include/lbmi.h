@@ -238,6 +238,13 @@ int lbmi_lb_bind(lbmi_t * lb, double * f, double * fprime);
 /* Current arrays: what lb->target->f / fprime must point at after a call
  * (the swap of propagation.c:240-248). */
 int lbmi_lb_pointers(lbmi_t * lb, double ** f, double ** fprime);
+/* The same for a caller that keeps the pair in DEVICE memory (the members f,
+ * fprime of the device copy of lb_t, which lb_model_swapf rewrites with
+ * blocking copies, propagation.c:240-248): f_slot and fprime_slot are device
+ * addresses of two double*; they receive the current pair from a one-thread
+ * kernel on the handle's stream, ordered with the step and without a host
+ * synchronisation. */
+int lbmi_lb_pointers_store(lbmi_t * lb, double ** f_slot, double ** fprime_slot);
 
 int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro);  /* lb_collide */
 int lbmi_lb_halo(lbmi_t * lb);                                 /* lb_halo    */

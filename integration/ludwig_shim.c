@@ -264,10 +264,11 @@ static void shim_sync_pointers(lb_t * lb, lbmi_t * h) {
   double * fprime = NULL;
   SHIM_CHECK(lb, lbmi_lb_pointers(h, &f, &fprime));
   if (f == last_f && fprime == last_fprime) return;    /* nothing swapped */
-  tdpAssert(tdpMemcpy(&lb->target->f, &f, sizeof(double *),
-		      tdpMemcpyHostToDevice));
-  tdpAssert(tdpMemcpy(&lb->target->fprime, &fprime, sizeof(double *),
-		      tdpMemcpyHostToDevice));
+  /* (lb_model_swapf does this with two blocking copies, propagation.c:240-248;
+   * here a one-thread kernel on the stream of the step writes the two
+   * members of the device struct: foreign kernels, launched on the same
+   * default stream afterwards, see the new pair) */
+  SHIM_CHECK(lb, lbmi_lb_pointers_store(h, &lb->target->f, &lb->target->fprime));
   last_f = f;
   last_fprime = fprime;
 }

@@ -1376,6 +1376,18 @@ int lbmi_lb_pointers(lbmi_t * lb, double ** f, double ** fprime) {
   return 0;
 }
 
+/* lb_model_swapf for a caller that keeps the two pointers in DEVICE memory
+ * (lb->target->f, lb->target->fprime: members of the device copy of lb_t,
+ * propagation.c:240-248): the current pair is written there by a one-thread
+ * kernel on the handle's stream -- ordered with the step, no blocking copy. */
+
+int lbmi_lb_pointers_store(lbmi_t * lb, double ** f_slot, double ** fprime_slot) {
+  if (lb == NULL || f_slot == NULL || fprime_slot == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  HIPCHECK(hipSetDevice(lb->device));
+  KCHECK(lbmi_k_store_pointers(f_slot, fprime_slot, lb->f, lb->fprime, lb->stream));
+  return 0;
+}
+
 static void lbmi_swapf(lbmi_t * lb) {        /* lb_model_swapf */
   double * tmp = lb->f;
   lb->f = lb->fprime;

@@ -219,6 +219,10 @@ int lbmi_k_wall_bbl_slip(const lbmi_kparam_t * kp, const lbmi_wall_tab_t * tab,
 			 double * part, double * fnet, int * err,
 			 void * stream);
 
+/* *slot_f = f, *slot_fprime = fprime on the device, in stream order */
+int lbmi_k_store_pointers(double ** slot_f, double ** slot_fprime, double * f,
+			  double * fprime, void * stream);
+
 /* dst <- src at the interior sites of an SoA field of ncomp components */
 int lbmi_k_interior_copy(const lbmi_kparam_t * kp, int ncomp,
 			 const double * src, double * dst, void * stream);

@@ -3351,6 +3351,23 @@ extern "C" int lbmi_k_interior_copy(const lbmi_kparam_t * kp, int ncomp,
   return (int) hipGetLastError();
 }
 
+/* two pointers into two device slots: lb->target->f / fprime after a swap,
+ * in stream order, without a blocking copy from the host */
+__global__ void k_store_pointers(double ** slot_f, double ** slot_fprime,
+				 double * f, double * fprime) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *slot_f = f;
+    *slot_fprime = fprime;
+  }
+}
+
+extern "C" int lbmi_k_store_pointers(double ** slot_f, double ** slot_fprime,
+				     double * f, double * fprime, void * stream) {
+  hipLaunchKernelGGL(k_store_pointers, dim3(1), dim3(64), 0, (hipStream_t) stream,
+		     slot_f, slot_fprime, f, fprime);
+  return (int) hipGetLastError();
+}
+
 extern "C" int lbmi_k_density(const lbmi_kparam_t * kp, const double * f,
 			      double * rho, void * stream) {
   hipStream_t st = (hipStream_t) stream;

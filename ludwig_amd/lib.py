@@ -92,6 +92,7 @@ SYMBOLS = [
     ("lbmi_moments", _i, [_vp, _vp, _vp, _pd]),
     ("lbmi_lb_bind", _i, [_vp, _vp, _vp]),
     ("lbmi_lb_pointers", _i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    ("lbmi_lb_pointers_store", _i, [_vp, _vp, _vp]),
     ("lbmi_lb_collide", _i, [_vp, ctypes.POINTER(HydroPtrs)]),
     ("lbmi_lb_halo", _i, [_vp]),
     ("lbmi_lb_propagation", _i, [_vp]),
