@@ -776,7 +776,9 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
   }
     if (strcmp(key, "hydro_lazy") == 0) {
     if (!value) {
-      int ifail = lbmi_hydro_materialise(lb);
+      int ifail;
+      HIPCHECK(hipSetDevice(lb->device));
+      ifail = lbmi_hydro_materialise(lb);
       if (ifail) return ifail;
     }
     lb->hydro_lazy = (value != 0);
