@@ -1517,6 +1517,12 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
       const lbmi_xbuf_t * xb = direct ? &xbuf : NULL;
       hipStream_t bst = lb->x_concurrent ? lb->bnd_stream : lb->stream;
 
+      /* direct form, steady state: the messages of THIS step were issued at
+       * the end of the previous call, as soon as its boundary launch had
+       * filled the send buffers -- they have had most of an interior launch
+       * to arrive, not just the start of this one */
+      const int pre = (direct && lb->xsend_valid);
+
       HIPCHECK(hipEventRecord(lb->ev_ready, lb->stream));
       if (detail) HIPCHECK(hipEventRecord(lb->evd[0][lb->nd], lb->stream));
       KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
@@ -1524,15 +1530,16 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
 				      lb->stream));
       if (detail) HIPCHECK(hipEventRecord(lb->evd[1][lb->nd], lb->stream));
 
-      /* comm stream: the boundary planes of f are final at ev_ready */
-      HIPCHECK(hipStreamWaitEvent(lb->comm_stream, lb->ev_ready, 0));
-      if (detail) HIPCHECK(hipEventRecord(lb->evd[2][lb->nd], lb->comm_stream));
-      ifail = lbmi_x_exchange_buf(lb, &lb->sel_reduced[X], lb->f, lb->blocked,
-				  0, lb->fx, direct && lb->xsend_valid,
-				  !direct, lb->comm_stream);
-      if (ifail) return ifail;
-      if (detail) HIPCHECK(hipEventRecord(lb->evd[3][lb->nd], lb->comm_stream));
-      HIPCHECK(hipEventRecord(lb->ev_halo, lb->comm_stream));
+      if (!pre) {
+	/* comm stream: the boundary planes of f are final at ev_ready */
+	HIPCHECK(hipStreamWaitEvent(lb->comm_stream, lb->ev_ready, 0));
+	if (detail && !direct) HIPCHECK(hipEventRecord(lb->evd[2][lb->nd], lb->comm_stream));
+	ifail = lbmi_x_exchange_buf(lb, &lb->sel_reduced[X], lb->f, lb->blocked,
+				    0, lb->fx, 0, !direct, lb->comm_stream);
+	if (ifail) return ifail;
+	if (detail && !direct) HIPCHECK(hipEventRecord(lb->evd[3][lb->nd], lb->comm_stream));
+	HIPCHECK(hipEventRecord(lb->ev_halo, lb->comm_stream));
+      }
 
       /* The two boundary planes depend on the state of the previous step
        * (complete at ev_ready) and on what arrived, not on the interior
@@ -1547,14 +1554,27 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
       KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
 				      lay, xlo, xlo, xhi, (xhi > xlo) ? xhi : xhi - 1,
 				      xb, bst));
-      if (detail) {
-	HIPCHECK(hipEventRecord(lb->evd[5][lb->nd], bst));
-	lb->nd += 1;
+      if (detail) HIPCHECK(hipEventRecord(lb->evd[5][lb->nd], bst));
+      HIPCHECK(hipEventRecord(lb->ev_bnd, bst));
+      if (lb->x_concurrent) HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_bnd, 0));
+
+      if (direct) {
+	/* the messages of the NEXT step, now: what the boundary launch has
+	 * just left in the send buffers is all they carry, and the receive
+	 * buffers are free once it has read them (ev_bnd). If the next call
+	 * is not a fused step, they have travelled for nothing (whatever
+	 * changes f in another way drops xsend_valid, and the step after
+	 * packs and exchanges afresh). Every rank runs the same sequence of
+	 * calls, so the messages pair up as before. */
+	HIPCHECK(hipStreamWaitEvent(lb->comm_stream, lb->ev_bnd, 0));
+	if (detail) HIPCHECK(hipEventRecord(lb->evd[2][lb->nd], lb->comm_stream));
+	ifail = lbmi_x_exchange_buf(lb, &lb->sel_reduced[X], lb->fprime, 0, 0,
+				    lb->fx, 1, 0, lb->comm_stream);
+	if (ifail) return ifail;
+	if (detail) HIPCHECK(hipEventRecord(lb->evd[3][lb->nd], lb->comm_stream));
+	HIPCHECK(hipEventRecord(lb->ev_halo, lb->comm_stream));
       }
-      if (lb->x_concurrent) {
-	HIPCHECK(hipEventRecord(lb->ev_bnd, lb->bnd_stream));
-	HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_bnd, 0));
-      }
+      if (detail) lb->nd += 1;
       xsend = direct;            /* of fprime, which becomes f below */
     }
     lb->blocked = (lay != 0);
