@@ -289,3 +289,62 @@ def test_binary_fluid_step_on_slabs(world):
     ring.free()
     assert relmax(np.concatenate([o[1] for o in out], axis=0), interior(phi, h)) < 1e-12
     assert relmax(np.concatenate([o[0] for o in out], axis=1), interior(f, h)) < 1e-12
+
+
+def test_long_run_on_the_ring():
+    """Four ranks, 240 steps back to back (lbmi_lb_run in chunks, the FIFO
+    slots of the ring reused many times over, the next step's messages issued
+    a step ahead every time), conserved totals read in between: the single
+    domain after the same number of steps."""
+    import ludwig_amd
+    import torch
+    world, ntotal, nsteps = 4, (16, 14, 14), 240
+    p, f, rho, u = _oracle(19, ntotal, nsteps)
+    mref = lbo.moments(p, f)
+    ring = ludwig_amd.Ring(world)
+    out = [None] * world
+    err = []
+    start = threading.Barrier(world)
+
+    def rank_main(rank):
+        try:
+            dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, 1)
+            lb = ludwig_amd.LB(19, dec.nlocal, 1, mode=ludwig_amd.FUSED, cartsz=world,
+                               cartrank=rank, own_stream=True,
+                               halo_scheme=ludwig_amd.HALO_REDUCED)
+            lb.relaxation_set("m10", 0.1, 0.3)
+            lb.body_force_set(FBODY)
+            lb.tune("hydro_lazy", 1)
+            lb.comm_init_ring(ring)
+            pp = lbo.make_param(19, dec.nlocal, 1, "m10", 0.1, 0.3, 1.0, FBODY)
+            hy = ludwig_amd.Hydro(lb.nall, lb.device)
+            lb.lb_memcpy_h2d(lbo.init_synthetic(pp, ntotal, dec.noffset))
+            start.wait()
+            mass = []
+            for chunk in range(6):
+                lb.run(hy, nsteps // 6)
+                mass.append(lb.moments()[1])          # a flush every 40 steps
+            lb.hydro_sync()
+            fo = lb.lb_memcpy_d2h()
+            lb.synchronize()
+            torch.cuda.synchronize()
+            out[rank] = (interior(fo, 1).copy(), mass, interior(hy.u.cpu().numpy(), 1).copy())
+            start.wait()
+            lb.free()
+        except Exception as e:           # noqa: BLE001
+            err.append((rank, repr(e)))
+            ring.abort()
+            start.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not err, err
+    ring.free()
+    assert relmax(_join(out, 0), interior(f, 1)) < 1e-12
+    assert relmax(_join(out, 2), interior(u, 1)) < 1e-12
+    for k in range(6):
+        total = sum(o[1][k] for o in out)
+        assert abs(total - mref[1]) / mref[1] < 1e-12        # mass is conserved throughout
