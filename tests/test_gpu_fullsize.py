@@ -129,3 +129,118 @@ def test_free_slip_walls_conserve_mass_and_tangential_momentum_256(mode):
     assert abs(m1[1] - m0[1]) < 1e-12 * nsites                  # mass
     assert np.max(np.abs(m1[5:7] - m0[5:7])) < 1e-11 * nsites   # g_x, g_y
     lb.free()
+
+
+def test_rho_u_on_demand_equal_stored_256():
+    """hydro_lazy at the full size: rho, u asked for after 6 steps equal the
+    ones the collision stores when it stores them every step (to the 1e-12 of
+    the parity bar; observed ~1e-16), and the distributions are the same bit
+    for bit."""
+    import ludwig_amd
+    import torch
+    res = []
+    for lazy in (0, 1):
+        lb = _setup(ludwig_amd.FUSED, (1.0e-6, 0.0, -1.0e-6))
+        lb.tune("hydro_lazy", lazy)
+        hy = ludwig_amd.Hydro(lb.nall, lb.device)
+        lb.run(hy, 6)
+        lb.hydro_sync()
+        lb.synchronize()
+        torch.cuda.synchronize()
+        res.append((hy.rho[1:-1, 1:-1, 1:-1].clone(), hy.u[:, 1:-1, 1:-1, 1:-1].clone(),
+                    lb.moments()))
+        lb.free()
+    assert float((res[0][0] - res[1][0]).abs().max()) < 1e-12
+    assert float((res[0][1] - res[1][1]).abs().max()) < 1e-12 * float(res[0][1].abs().max())
+    assert np.array_equal(res[0][2], res[1][2])
+
+
+def test_two_slabs_through_the_ring_equal_one_domain_256():
+    """BASELINE config 3 in the small: the 256^3 box as two slabs of 128 planes
+    (two ranks of the in-process ring on this one GPU: interior launch,
+    boundary launch against the exchange buffers, messages a step ahead) =
+    the single-GPU run after 4 steps, bit for bit (same arithmetic per site;
+    only where the neighbours' populations come from differs)."""
+    import threading
+
+    import ludwig_amd
+    import torch
+    from ludwig_amd import synthetic
+    nsteps, world = 4, 2
+    lb = _setup(ludwig_amd.FUSED)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, with_rho_u=False)
+    lb.run(hy, nsteps)
+    ref = lb.lb_memcpy_d2h()[:, 1:-1, 1:-1, 1:-1].copy()
+    mref = lb.moments()
+    lb.free()
+    del hy
+    torch.cuda.empty_cache()
+
+    ring = ludwig_amd.Ring(world)
+    out = [None] * world
+    err = []
+    bar = threading.Barrier(world)
+    m = ludwig_amd.lb.model(NVEL)
+
+    def rank_main(rank):
+        try:
+            dec = ludwig_amd.SlabDecomposition((N, N, N), world, rank, 1)
+            lbr = ludwig_amd.LB(NVEL, dec.nlocal, 1, mode=ludwig_amd.FUSED, cartsz=world,
+                                cartrank=rank, own_stream=True,
+                                halo_scheme=ludwig_amd.HALO_REDUCED)
+            lbr.relaxation_set("m10", 0.1, 0.3)
+            lbr.comm_init_ring(ring)
+            synthetic.fill_device(lbr, m["cv"], m["wv"], (N, N, N),
+                                  xrange=(dec.noffset[0], dec.noffset[0] + dec.nlocal[0]))
+            torch.cuda.synchronize()
+            hyr = ludwig_amd.Hydro(lbr.nall, lbr.device, with_rho_u=False)
+            bar.wait()
+            lbr.run(hyr, nsteps)
+            mo = lbr.moments()
+            out[rank] = (lbr.lb_memcpy_d2h()[:, 1:-1, 1:-1, 1:-1].copy(), mo)
+            bar.wait()
+            lbr.free()
+        except Exception as e:           # noqa: BLE001
+            err.append((rank, repr(e)))
+            ring.abort()
+            bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not err, err
+    ring.free()
+    got = np.concatenate([out[0][0], out[1][0]], axis=1)
+    assert np.array_equal(got, ref)
+    assert abs(out[0][1][1] + out[1][1][1] - mref[1]) / mref[1] < 1e-14
+
+
+def test_d3q27_config5_slab_conserves_and_modes_agree():
+    """BASELINE config 5 per GPU (D3Q27, 64 x 512 x 256): mass and momentum
+    under a body force over 8 steps, and the totals of FUSED and EAGER agree
+    to 1e-13 of the mass."""
+    import ludwig_amd
+    from ludwig_amd import synthetic
+    n = (64, 512, 256)
+    fb = (2.0e-6, 0.0, -1.0e-6)
+    m = ludwig_amd.lb.model(27)
+    mo = []
+    for mode in (ludwig_amd.FUSED, ludwig_amd.EAGER):
+        lb = ludwig_amd.LB(27, n, 1, mode=mode, halo_scheme=ludwig_amd.HALO_REDUCED)
+        lb.relaxation_set("m10", 0.1, 0.3)
+        lb.body_force_set(fb)
+        synthetic.fill_device(lb, m["cv"], m["wv"], n)
+        hy = ludwig_amd.Hydro(lb.nall, lb.device)
+        m0 = lb.moments()
+        lb.run(hy, 8)
+        m1 = lb.moments()
+        nsites = float(n[0] * n[1] * n[2])
+        assert m1[0] == nsites
+        assert abs(m1[1] - m0[1]) / m0[1] < 1e-12
+        for a in range(3):
+            assert abs(m1[5 + a] - (m0[5 + a] + 8 * nsites * fb[a])) / (0.3 * nsites) < 1e-12
+        mo.append(m1)
+        lb.free()
+    assert np.max(np.abs(mo[0] - mo[1])) < 1e-13 * mo[1][1]
