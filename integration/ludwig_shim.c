@@ -379,6 +379,18 @@ static void shim_param_commit(lb_t * lb) {
   shim_.param_valid = 1;
 }
 
+/* The hydro arrays have been, or are about to be, written by code outside
+ * the library (the reference's own kernels): drop what the handle remembers
+ * about their contents ("known to hold zeros", include/lbmi.h). */
+
+static void shim_hydro_foreign(hydro_t * hydro) {
+  if (shim_.h == NULL || hydro == NULL) return;
+  if (hydro->nsite != shim_.lb->nsite) return;   /* never seen by the library */
+  SHIM_CHECK(shim_.lb, lbmi_hydro_field_dirty(shim_.h, shim_field_data(hydro->force)));
+  SHIM_CHECK(shim_.lb, lbmi_hydro_field_dirty(shim_.h, shim_field_data(hydro->u)));
+  SHIM_CHECK(shim_.lb, lbmi_hydro_field_dirty(shim_.h, shim_field_data(hydro->rho)));
+}
+
 /*****************************************************************************
  *
  *  lb_collide
@@ -400,10 +412,18 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
   if (!shim_supported(lb) || noise->on[NOISE_RHO] ||
       (visc != NULL && lb->ndist != 1) ||
       (fe && fe->use_stress_relaxation && fe->id != FE_SYMMETRIC) ||
-      (lb->ndist == 2 && (fe == NULL || fe->id != FE_SYMMETRIC))) {
+      (lb->ndist == 2 && (fe == NULL || fe->id != FE_SYMMETRIC)) ||
+      hydro->nsite != lb->nsite) {
+    /* (the last: with Lees-Edwards planes the hydro arrays carry buffer
+     * planes, lees_edw_nsites: their components are hydro->nsite apart, the
+     * distributions lb->nsite) */
     if (shim_.h && shim_.lb == lb) {
       SHIM_CHECK(lb, lbmi_lb_flush(shim_.h));
       shim_sync_pointers(lb, shim_.h);
+      /* the original reads hydro->force as somebody outside the library
+       * left it and writes hydro->rho, u itself: nothing the library
+       * remembers about their contents holds after this call */
+      shim_hydro_foreign(hydro);
     }
     return lb_collide_ref(lb, hydro, map, noise, fe, visc);
   }
@@ -883,7 +903,7 @@ int hydro_u_zero(hydro_t * hydro, const double uzero[3]) {
   lbmi_t * h = NULL;
   assert(hydro);
   h = shim_handle_if_any(hydro->cs);
-  if (h == NULL) return hydro_u_zero_ref(hydro, uzero);
+  if (h == NULL || hydro->nsite != shim_.lb->nsite) return hydro_u_zero_ref(hydro, uzero);
   SHIM_CHECK(shim_.lb, lbmi_hydro_field_set(h, shim_field_data(hydro->u), 3, uzero));
   return 0;
 }
@@ -892,7 +912,7 @@ int hydro_f_zero(hydro_t * hydro, const double fzero[3]) {
   lbmi_t * h = NULL;
   assert(hydro);
   h = shim_handle_if_any(hydro->cs);
-  if (h == NULL) return hydro_f_zero_ref(hydro, fzero);
+  if (h == NULL || hydro->nsite != shim_.lb->nsite) return hydro_f_zero_ref(hydro, fzero);
   SHIM_CHECK(shim_.lb, lbmi_hydro_field_set(h, shim_field_data(hydro->force), 3, fzero));
   return 0;
 }
@@ -904,12 +924,18 @@ int hydro_f_zero(hydro_t * hydro, const double fzero[3]) {
 int field_halo(field_t * field) {
   lbmi_t * h = NULL;
   int nhalo = 0;
+  int nlocal[3];
   assert(field);
   h = shim_handle_if_any(field->cs);
   cs_nhalo(field->cs, &nhalo);
+  cs_nlocal(field->cs, nlocal);
   if (h == NULL || field->opts.haloscheme != FIELD_HALO_TARGET ||
       (field->le && lees_edw_nplane_total(field->le) > 0) ||
-      field->nhcomm < 1 || field->nhcomm > nhalo || field->nf > 27) {
+      field->nsites != shim_.lb->nsite ||
+      field->nhcomm < 1 || field->nhcomm > nhalo || field->nf > 27 ||
+      /* (a quasi-two-dimensional system: the swap is wider than the box) */
+      field->nhcomm > nlocal[X] || field->nhcomm > nlocal[Y] ||
+      field->nhcomm > nlocal[Z]) {
     return field_halo_ref(field);
   }
   SHIM_CHECK(shim_.lb, lbmi_field_halo_n(h, field->nf, field->nhcomm,

@@ -455,3 +455,53 @@ def test_ludwig_with_lazy_hydro(name, mode):
     for tag, key in (("[minimum ]", "u_min"), ("[maximum ]", "u_max")):
         for a, b in zip(_last(log, tag), ref[key]):
             assert abs(a - b) <= 2e-7 * abs(b) + 1e-14
+
+
+# --- the reference's regression suite: runs the binding must hand back ----------
+
+SWEEP = os.path.join(HERE, "golden", "regression_d3q19_short")
+
+
+def _sweep_tool():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "regression_sweep", os.path.join(HERE, "..", "tools", "regression_sweep.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("name,tol", [
+    ("serial-chol-st3", 1e-12),   # Lees-Edwards planes + liquid crystal: hydro arrays with buffer planes
+    ("serial-le3d-st1", 1e-12),   # Lees-Edwards planes + symmetric free energy
+    ("serial-anch-wn1", 1e-12),   # quasi-two-dimensional box: a field halo wider than the box
+    ("serial-drop-lc3", 1e-12),   # stress relaxation of a free energy the library does not cover
+    ("serial-coll-st1", 2e-11),   # a colloid (bounce_back_on_links on the reference's side);
+                                  # [total] momentum: a sum that cancels to round-off
+])
+def test_ludwig_runs_the_binding_leaves_to_the_reference(name, tol):
+    """Inputs of the reference's d3q19-short regression suite that use what
+    the library does not cover: the bound executable must print what the
+    unbound one prints on the same GPU (tools/regression_sweep.py is the
+    whole suite, profiles/r02_regression_sweep.txt its table). Each of the
+    first four was a defect of the binding found by that sweep."""
+    rs = _sweep_tool()
+    env = dict(os.environ)
+    for k in ("LBMI_MODE", "LBMI_FE", "LBMI_HYDRO"):
+        env.pop(k, None)
+    logs = {}
+    for leg, exe in (("unbound", "ludwig_hip_d3q19"), ("bound", "ludwig_hip_d3q19_shim")):
+        path = os.path.join(REF, exe)
+        if not os.path.exists(path):
+            pytest.fail("oracle/_ref/%s is missing: `make -C oracle hip`" % exe)
+        with tempfile.TemporaryDirectory() as tmp:
+            rc, out, err, _ = rs.run_one(name, path, env, tmp, 300)
+        assert rc == 0 and "Ludwig finished normally." in out, (leg, rc, out[-2000:], err[-2000:])
+        logs[leg] = out
+    bad, worst, first = rs.compare(logs["unbound"], logs["bound"], tol)
+    assert bad == 0, (worst, first)
+    # and both are the run the reference's authors logged (the HIP target moves
+    # the last printed digit of some extrema by itself: 8 digits)
+    expected = open(os.path.join(SWEEP, name + ".log")).read()
+    bad, worst, first = rs.compare(expected, logs["bound"], 5e-8)
+    assert bad == 0, (worst, first)
