@@ -18,7 +18,7 @@ through the same executable without it.
 
 usage: regression_sweep.py collect
        regression_sweep.py run [--first I --last J] [--only NAME,...]
-                               [--unbound 1] [--mode halo] [--out FILE]
+                               [--unbound 1] [--mode halo] [--env K=V,...] [--out FILE]
 """
 
 import argparse
@@ -148,6 +148,9 @@ def run(args):
         env.pop(k, None)
     if args.mode:
         env["LBMI_MODE"] = args.mode
+    for kv in filter(None, args.env.split(",")):
+        k, v = kv.split("=")
+        env[k] = v
     # the unbound executable first: an input it faults on is not given to the
     # bound one (a GPU fault is evidence enough once)
     legs = ([("unbound", EXE)] if args.unbound else []) + [("bound", EXE + "_shim")]
@@ -263,6 +266,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--unbound", type=int, default=1)
     ap.add_argument("--mode", default="")
+    ap.add_argument("--env", default="", help="KEY=VALUE,... for the runs (LBMI_FE=1,LBMI_HYDRO=lazy)")
     ap.add_argument("--tol", type=float, default=1e-12)
     ap.add_argument("--limit", type=int, default=240)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "regression_sweep.jsonl"))
