@@ -52,6 +52,7 @@ REF_FAULTS = {"serial-chol-n01", "serial-chol-n02", "serial-chol-n03", "serial-c
 
 # inputs that need something the suite's Makefile prepares first
 NEEDS = {"serial-rest-c02": "serial-rest-c01",       # restart from c01's files
+         "iodrop-mpi1-io3": "iodrop-mpi1-io2",       # restart from io2's files
          "serial-poly-st1": "util/multi_poly_init"}  # a generated initial state
 
 
@@ -115,10 +116,13 @@ def names():
 def collect():
     os.makedirs(DATA, exist_ok=True)
     n = 0
-    for f in sorted(os.listdir(REFDIR)):
-        if f.startswith("serial-") and (f.endswith(".inp") or f.endswith(".log")):
-            shutil.copy(os.path.join(REFDIR, f), os.path.join(DATA, f))
-            n += 1
+    # d3q19-short: every serial input; d3q19-io: the one-rank runs of the
+    # droplet with the three i/o arrangements (one file, two, ASCII records)
+    for d, prefix in ((REFDIR, "serial-"), (REFDIR.replace("d3q19-short", "d3q19-io"), "iodrop-mpi1-")):
+        for f in sorted(os.listdir(d)):
+            if f.startswith(prefix) and (f.endswith(".inp") or f.endswith(".log")):
+                shutil.copyfile(os.path.join(d, f), os.path.join(DATA, f))
+                n += 1
     print("%d files -> %s" % (n, DATA))
 
 
@@ -140,7 +144,8 @@ def run_one(name, exe, env, workdir, limit):
 def run(args):
     todo = names()
     if args.only:
-        todo = [n for n in todo if n in args.only.split(",") or n[7:] in args.only.split(",")]
+        pick = args.only.split(",")
+        todo = [n for n in todo if n in pick or n[7:] in pick or n[7:11] in pick]
     else:
         todo = todo[args.first:args.last]
     env = dict(os.environ)
@@ -153,7 +158,10 @@ def run(args):
         env[k] = v
     # the unbound executable first: an input it faults on is not given to the
     # bound one (a GPU fault is evidence enough once)
-    legs = ([("unbound", EXE)] if args.unbound else []) + [("bound", EXE + "_shim")]
+    exe_ = EXE.replace("d3q19", "d3q%d" % args.nvel)
+    # (--nvel 27: the suite's inputs with the D3Q27 build; the kept logs are
+    # D3Q19 runs, so only bound against unbound means anything there)
+    legs = ([("unbound", exe_)] if args.unbound else []) + [("bound", exe_ + "_shim")]
     for _, exe in legs:
         if not os.path.exists(exe):
             raise SystemExit(exe + " is missing: `make -C oracle hip` in the development container")
@@ -265,6 +273,7 @@ def main():
     ap.add_argument("--last", type=int, default=None)
     ap.add_argument("--only", default="")
     ap.add_argument("--unbound", type=int, default=1)
+    ap.add_argument("--nvel", type=int, default=19, choices=[19, 27])
     ap.add_argument("--mode", default="")
     ap.add_argument("--env", default="", help="KEY=VALUE,... for the runs (LBMI_FE=1,LBMI_HYDRO=lazy)")
     ap.add_argument("--tol", type=float, default=1e-12)
