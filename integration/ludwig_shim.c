@@ -144,6 +144,71 @@ int field_halo_ref(field_t * field);
 int field_grad_compute_ref(field_grad_t * fgrad);
 void field_grad_free_ref(field_grad_t * obj);
 
+/* LBMI_REPORT=1: at exit, how many calls of every bound symbol the library
+ * took and how many went to the original (what the binding did in this run;
+ * tools/unit_suites.sh and tools/regression_sweep.py read it). */
+
+enum {S_LB_COLLIDE, S_LB_HALO_SWAP, S_LB_PROPAGATION, S_LB_IO_WRITE, S_LB_IO_READ, S_PHI_LB_TO_FIELD, S_WALL_BBL, S_HYDRO_U_ZERO, S_HYDRO_F_ZERO, S_FIELD_HALO, S_FIELD_GRAD_COMPUTE, S_STATS_DISTRIBUTION_PRINT, S_STATS_DISTRIBUTION_MOMENTUM, S_PHI_FORCE_CALCULATION, S_PHI_CAHN_HILLIARD, S_CAHN_HILLIARD_STATS, S_CAHN_HILLIARD_STATS_TIME0, S_NSYM};
+
+static const char * const shim_sym_[S_NSYM] = {
+  "lb_collide",
+  "lb_halo_swap",
+  "lb_propagation",
+  "lb_io_write",
+  "lb_io_read",
+  "phi_lb_to_field",
+  "wall_bbl",
+  "hydro_u_zero",
+  "hydro_f_zero",
+  "field_halo",
+  "field_grad_compute",
+  "stats_distribution_print",
+  "stats_distribution_momentum",
+  "phi_force_calculation",
+  "phi_cahn_hilliard",
+  "cahn_hilliard_stats",
+  "cahn_hilliard_stats_time0"};
+static long shim_calls_[S_NSYM][2];              /* [.][1]: liblbmi, [.][0]: original */
+
+static void shim_report(void) {
+  fprintf(stderr, "liblbmi report: %-28s %10s %10s\n", "symbol", "liblbmi", "original");
+  for (int n = 0; n < S_NSYM; n++) {
+    if (shim_calls_[n][0] + shim_calls_[n][1] == 0) continue;
+    fprintf(stderr, "liblbmi report: %-28s %10ld %10ld\n", shim_sym_[n],
+	    shim_calls_[n][1], shim_calls_[n][0]);
+  }
+}
+
+static void shim_note(int sym, int bound) {
+  static int first = 1;
+  if (first) {
+    const char * e = getenv("LBMI_REPORT");
+    first = 0;
+    if (e != NULL && e[0] == '1') atexit(shim_report);
+  }
+  shim_calls_[sym][bound] += 1;
+}
+
+/* (a function-like macro is not expanded inside its own expansion: every
+ * call of an original below is counted on its way) */
+#define lb_collide_ref(...) (shim_note(S_LB_COLLIDE, 0), lb_collide_ref(__VA_ARGS__))
+#define lb_halo_swap_ref(...) (shim_note(S_LB_HALO_SWAP, 0), lb_halo_swap_ref(__VA_ARGS__))
+#define lb_propagation_ref(...) (shim_note(S_LB_PROPAGATION, 0), lb_propagation_ref(__VA_ARGS__))
+#define lb_io_write_ref(...) (shim_note(S_LB_IO_WRITE, 0), lb_io_write_ref(__VA_ARGS__))
+#define lb_io_read_ref(...) (shim_note(S_LB_IO_READ, 0), lb_io_read_ref(__VA_ARGS__))
+#define phi_lb_to_field_ref(...) (shim_note(S_PHI_LB_TO_FIELD, 0), phi_lb_to_field_ref(__VA_ARGS__))
+#define wall_bbl_ref(...) (shim_note(S_WALL_BBL, 0), wall_bbl_ref(__VA_ARGS__))
+#define hydro_u_zero_ref(...) (shim_note(S_HYDRO_U_ZERO, 0), hydro_u_zero_ref(__VA_ARGS__))
+#define hydro_f_zero_ref(...) (shim_note(S_HYDRO_F_ZERO, 0), hydro_f_zero_ref(__VA_ARGS__))
+#define field_halo_ref(...) (shim_note(S_FIELD_HALO, 0), field_halo_ref(__VA_ARGS__))
+#define field_grad_compute_ref(...) (shim_note(S_FIELD_GRAD_COMPUTE, 0), field_grad_compute_ref(__VA_ARGS__))
+#define stats_distribution_print_ref(...) (shim_note(S_STATS_DISTRIBUTION_PRINT, 0), stats_distribution_print_ref(__VA_ARGS__))
+#define stats_distribution_momentum_ref(...) (shim_note(S_STATS_DISTRIBUTION_MOMENTUM, 0), stats_distribution_momentum_ref(__VA_ARGS__))
+#define phi_force_calculation_ref(...) (shim_note(S_PHI_FORCE_CALCULATION, 0), phi_force_calculation_ref(__VA_ARGS__))
+#define phi_cahn_hilliard_ref(...) (shim_note(S_PHI_CAHN_HILLIARD, 0), phi_cahn_hilliard_ref(__VA_ARGS__))
+#define cahn_hilliard_stats_ref(...) (shim_note(S_CAHN_HILLIARD_STATS, 0), cahn_hilliard_stats_ref(__VA_ARGS__))
+#define cahn_hilliard_stats_time0_ref(...) (shim_note(S_CAHN_HILLIARD_STATS_TIME0, 0), cahn_hilliard_stats_time0_ref(__VA_ARGS__))
+
 /* One liblbmi handle per lb_t (Ludwig has one lb_t per rank) */
 
 typedef struct shim_s {
@@ -524,6 +589,7 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
     else {
       SHIM_CHECK(lb, lbmi_lb_collide(h, &hy));
     }
+    shim_note(S_LB_COLLIDE, 1);
     shim_sync_pointers(lb, h);                   /* FUSED swaps here */
   }
 
@@ -543,6 +609,7 @@ int phi_lb_to_field(field_t * phi, lb_t * lb) {
 
   if (!shim_supported(lb) || lb->ndist != 2) return phi_lb_to_field_ref(phi, lb);
 
+  shim_note(S_PHI_LB_TO_FIELD, 1);
   SHIM_CHECK(lb, lbmi_lb_phi_to_field(shim_handle(lb), shim_field_data(phi)));
 
   return 0;
@@ -624,6 +691,7 @@ int wall_bbl(wall_t * wall) {
     SHIM_CHECK(wall->lb, lbmi_wall_status_set(h, status));
     SHIM_CHECK(wall->lb, lbmi_wall_velocity_set(h, wall->param->ubot,
 						wall->param->utop));
+    shim_note(S_WALL_BBL, 1);
     SHIM_CHECK(wall->lb, lbmi_wall_bbl(h));
   }
 
@@ -723,6 +791,7 @@ int lb_halo_swap(lb_t * lb, lb_halo_enum_t flag) {
     return lb_halo_swap_ref(lb, flag);
   }
 
+  shim_note(S_LB_HALO_SWAP, 1);
   SHIM_CHECK(lb, lbmi_lb_halo(shim_handle(lb)));
 
   return 0;
@@ -749,6 +818,7 @@ int lb_propagation(lb_t * lb) {
 
   {
     lbmi_t * h = shim_handle(lb);
+    shim_note(S_LB_PROPAGATION, 1);
     SHIM_CHECK(lb, lbmi_lb_propagation(h));
     shim_sync_pointers(lb, h);                   /* lb_model_swapf */
   }
@@ -822,6 +892,7 @@ int lb_io_write(lb_t * lb, int timestep, io_event_t * event) {
     io_event_record(event, IO_EVENT_AGGR);
     io_event_record(event, IO_EVENT_WRITE);
     /* the metadata file (rank at offset 0) and this rank's byte range */
+    shim_note(S_LB_IO_WRITE, 1);
     SHIM_CHECK(lb, lbmi_lb_io_write(shim_handle(lb), ".", timestep, ntotal[X],
 				    noffset[X]));
     shim_sync_pointers(lb, shim_.h);                /* a flush may have swapped */
@@ -850,6 +921,7 @@ int lb_io_read(lb_t * lb, int timestep, io_event_t * event) {
     int ntotal[3], noffset[3];
     cs_ntotal(lb->cs, ntotal);
     cs_nlocal_offset(lb->cs, noffset);
+    shim_note(S_LB_IO_READ, 1);
     SHIM_CHECK(lb, lbmi_lb_io_read(shim_handle(lb), ".", timestep, ntotal[X],
 				   noffset[X]));
     shim_sync_pointers(lb, shim_.h);
@@ -904,6 +976,7 @@ int hydro_u_zero(hydro_t * hydro, const double uzero[3]) {
   assert(hydro);
   h = shim_handle_if_any(hydro->cs);
   if (h == NULL || hydro->nsite != shim_.lb->nsite) return hydro_u_zero_ref(hydro, uzero);
+  shim_note(S_HYDRO_U_ZERO, 1);
   SHIM_CHECK(shim_.lb, lbmi_hydro_field_set(h, shim_field_data(hydro->u), 3, uzero));
   return 0;
 }
@@ -913,6 +986,7 @@ int hydro_f_zero(hydro_t * hydro, const double fzero[3]) {
   assert(hydro);
   h = shim_handle_if_any(hydro->cs);
   if (h == NULL || hydro->nsite != shim_.lb->nsite) return hydro_f_zero_ref(hydro, fzero);
+  shim_note(S_HYDRO_F_ZERO, 1);
   SHIM_CHECK(shim_.lb, lbmi_hydro_field_set(h, shim_field_data(hydro->force), 3, fzero));
   return 0;
 }
@@ -938,6 +1012,7 @@ int field_halo(field_t * field) {
       field->nhcomm > nlocal[Z]) {
     return field_halo_ref(field);
   }
+  shim_note(S_FIELD_HALO, 1);
   SHIM_CHECK(shim_.lb, lbmi_field_halo_n(h, field->nf, field->nhcomm,
 					 shim_field_data(field)));
   return 0;
@@ -960,6 +1035,7 @@ int field_grad_compute(field_grad_t * fgrad) {
       (fgrad->field->le && lees_edw_nplane_total(fgrad->field->le) > 0)) {
     return field_grad_compute_ref(fgrad);
   }
+  shim_note(S_FIELD_GRAD_COMPUTE, 1);
   shim_grad_arrays(fgrad, &grad, &delsq);
   if (npt == 7) {
     SHIM_CHECK(shim_.lb, lbmi_field_grad_7pt(h, shim_field_data(fgrad->field),
@@ -1011,6 +1087,7 @@ int stats_distribution_print(lb_t * lb, map_t * map) {
     pe_mpi_comm(lb->pe, &comm);
     rho = (double *) malloc(sizeof(double)*(size_t) nlocal[X]*nlocal[Y]*nlocal[Z]);
     if (rho == NULL) pe_fatal(lb->pe, "liblbmi: malloc(rho) failed\n");
+    shim_note(S_STATS_DISTRIBUTION_PRINT, 1);
     SHIM_CHECK(lb, lbmi_lb_density(shim_.h, rho));
     shim_sync_pointers(lb, shim_.h);              /* a flush may have swapped */
 
@@ -1062,6 +1139,7 @@ int stats_distribution_momentum(lb_t * lb, map_t * map, double g[3]) {
     MPI_Comm comm;
 
     pe_mpi_comm(lb->pe, &comm);
+    shim_note(S_STATS_DISTRIBUTION_MOMENTUM, 1);
     SHIM_CHECK(lb, lbmi_lb_moments(shim_.h, status, out));
     shim_sync_pointers(lb, shim_.h);
     /* the rank's compensated sums; across ranks a plain sum (the reference
@@ -1144,6 +1222,7 @@ int phi_force_calculation(pe_t * pe, cs_t * cs, lees_edw_t * le, wall_t * wall,
     }
     /* F_a -= d_b P_ab at the interior sites, from the arrays the (bound)
      * field_grad_compute has just filled */
+    shim_note(S_PHI_FORCE_CALCULATION, 1);
     SHIM_CHECK(shim_.lb, lbmi_symmetric_force(shim_.h, param.a, param.b,
 					      param.kappa, shim_field_data(phi),
 					      grad, delsq,
@@ -1205,6 +1284,7 @@ int phi_cahn_hilliard(phi_ch_t * pch, fe_t * fe, field_t * phi,
      * flux and forward step in one kernel; the reference updates phi in
      * place, so the new interior goes back into its array */
     SHIM_CHECK(shim_.lb, lbmi_field_halo_n(shim_.h, 3, 1, u));
+    shim_note(S_PHI_CAHN_HILLIARD, 1);
     SHIM_CHECK(shim_.lb, lbmi_cahn_hilliard(shim_.h, param.a, param.b,
 					    param.kappa, mobility, phid, delsq,
 					    u, scratch));
@@ -1295,6 +1375,7 @@ int cahn_hilliard_stats_time0(phi_ch_t * pch, field_t * phi, map_t * map) {
   if (!shim_phi_stats(pch, phi, map, stats)) {
     return cahn_hilliard_stats_time0_ref(pch, phi, map);
   }
+  shim_note(S_CAHN_HILLIARD_STATS_TIME0, 1);
   pe_mpi_comm(pch->pe, &comm);
   phi->field_init_sum = stats[1];
   MPI_Bcast(&phi->field_init_sum, 1, MPI_DOUBLE, 0, comm);
@@ -1309,6 +1390,7 @@ int cahn_hilliard_stats(phi_ch_t * pch, field_t * phi, map_t * map) {
   if (!shim_phi_stats(pch, phi, map, stats)) {
     return cahn_hilliard_stats_ref(pch, phi, map);
   }
+  shim_note(S_CAHN_HILLIARD_STATS, 1);
   {
     double rvol = 1.0/stats[0];
     double fbar = rvol*stats[1];                 /* mean */

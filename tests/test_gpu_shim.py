@@ -505,3 +505,37 @@ def test_ludwig_runs_the_binding_leaves_to_the_reference(name, tol):
     expected = open(os.path.join(SWEEP, name + ".log")).read()
     bad, worst, first = rs.compare(expected, logs["bound"], 5e-8)
     assert bad == 0, (worst, first)
+
+
+# --- the reference's own unit tests against the binding --------------------------
+
+@pytest.mark.parametrize("nvel", [19, 27])
+def test_reference_unit_suites_with_the_binding(nvel):
+    """tests/unit/test_model.c, test_halo.c, test_prop.c, test_wall.c of the
+    reference (compiled where they lie by oracle/Makefile, assertions on,
+    run by oracle/unit_main.c) linked against the binding: every check its
+    authors wrote for lb_halo / lb_propagation / lb_memcpy holds for the bound
+    functions, and the report shows that the library -- not the original --
+    served them (tools/unit_suites.sh: all fifteen suites, both builds)."""
+    exe = os.path.join(REF, "unit_hip_d3q%d_shim" % nvel)
+    if not os.path.exists(exe):
+        pytest.fail("oracle/_ref/%s is missing: `make -C oracle hip`" % os.path.basename(exe))
+    env = dict(os.environ, LBMI_REPORT="1")
+    env.pop("LBMI_MODE", None)
+    suites = ["model", "halo", "prop", "wall", "lb_bc_inflow_rhou", "lb_bc_outflow_rhou"]
+    with tempfile.TemporaryDirectory() as tmp:
+        r = _sp.run([exe] + suites, cwd=tmp, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    for s in suites:
+        assert "DONE     " + s in r.stdout, (s, r.stdout[-2000:], r.stderr[-2000:])
+    assert "Failed test assertion" not in r.stdout
+    assert r.stdout.count("PASS") >= len(suites)
+    calls = {}
+    for line in r.stderr.splitlines():
+        w = line.split()
+        if line.startswith("liblbmi report:") and len(w) == 5 and w[3].isdigit():
+            calls[w[2]] = (int(w[3]), int(w[4]))
+    # test_prop.c: every lb_halo and lb_propagation is the library's
+    assert calls["lb_propagation"][0] >= 4 and calls["lb_propagation"][1] == 0
+    # test_halo.c: the device scheme is the library's, the host schemes the original's
+    assert calls["lb_halo_swap"][0] >= 16 and calls["lb_halo_swap"][1] >= 1

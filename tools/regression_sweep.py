@@ -193,7 +193,7 @@ def run(args):
                 else:
                     tmp = tempfile.TemporaryDirectory()
                     wd = tmp.name
-                rc, out, err, dt = run_one(name, exe, env, wd, args.limit)
+                rc, out, err, dt = run_one(name, exe, dict(env, LBMI_REPORT="1"), wd, args.limit)
                 if tmp:
                     tmp.cleanup()
                 done = "Ludwig finished normally."
@@ -207,6 +207,15 @@ def run(args):
                 rec[leg] = {"status": "same" if bad == 0 else "differs", "lines": bad,
                             "worst": worst, "seconds": round(dt, 1)}
                 outputs[leg] = out
+                if leg == "bound":
+                    # LBMI_REPORT=1 (integration/ludwig_shim.c): calls the library
+                    # took / calls it handed to the original, per bound symbol
+                    calls = {}
+                    for line in err.splitlines():
+                        w = line.split()
+                        if line.startswith("liblbmi report:") and len(w) == 5 and w[3].isdigit():
+                            calls[w[2]] = [int(w[3]), int(w[4])]
+                    rec["calls"] = calls
                 if leg == "bound" and "unbound" in outputs:
                     # what the binding changes: the two executables on this GPU
                     b2, w2, f2 = compare(outputs["unbound"], out, args.tol)
@@ -249,8 +258,9 @@ def report(args):
         if x["status"] == "not run":
             return "not run: " + x["why"]
         return "did not finish (rc %s)" % x["rc"]
-    print("# %-10s | %-28s | %-28s | %s" % ("input", "unbound vs the kept log", "bound vs the kept log",
-                                          "bound vs unbound"))
+    print("# %-10s | %-28s | %-28s | %-22s | %s" % (
+        "input", "unbound vs the kept log", "bound vs the kept log", "bound vs unbound",
+        "library/original calls: collide halo propagation | others the library took"))
     n_same = n_both = 0
     for name in sorted(rows):
         r = rows[name]
@@ -258,10 +268,14 @@ def report(args):
         if bu is not None:
             n_both += 1
             n_same += (bu["lines"] == 0)
-        print("%-12s | %-28s | %-28s | %s" % (
+        c = r.get("calls") or {}
+        main = " ".join("%d/%d" % tuple(c.get(k, [0, 0])) for k in ("lb_collide", "lb_halo_swap", "lb_propagation"))
+        rest = ",".join(k for k in sorted(c) if k not in ("lb_collide", "lb_halo_swap", "lb_propagation") and c[k][0])
+        print("%-12s | %-28s | %-28s | %-22s | %s" % (
             name[7:], cell(r.get("unbound")), cell(r.get("bound")),
             "-" if bu is None else ("identical, %.1e" % bu["worst"] if bu["lines"] == 0
-                                    else "%d lines, %.1e" % (bu["lines"], bu["worst"]))))
+                                    else "%d lines, %.1e" % (bu["lines"], bu["worst"])),
+            (main + " | " + rest) if c else "-"))
     print("# bound against unbound: %d of %d logs identical (numbers within the tolerance)" % (n_same, n_both))
 
 
