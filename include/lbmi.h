@@ -435,6 +435,21 @@ int lbmi_field_stats(lbmi_t * lb, const double * field, const char * status,
  * by others, until then. Readers of rho / u outside this library call
  * lbmi_lb_hydro_sync first (the binding: INTEGRATION.md). */
 int lbmi_lb_hydro_sync(lbmi_t * lb);
+
+/* Isothermal fluctuations in lbmi_lb_collide (collision.c:476-518 with
+ * lb_fluctuations_var_eta/_bulk/_ghost, _stress, _ghosts, :1745-1920): every
+ * fluid site draws from its own generator (noise.c:397-424, 467-487) a random
+ * stress of the fluctuation-dissipation variance for temperature kt and,
+ * with ghosts_on (lb->param->isghost == LB_GHOST_ON), a random part for each
+ * ghost mode; solid sites draw nothing. state is the reference's
+ * noise->state on the device: 4 unsigned ints per site, component ia of
+ * site i at state[ia*nsites + i] (noise.c:330-366 with ADDR_SOA), read and
+ * advanced by every collision. state = NULL: off (the default).
+ * D3Q19 with one distribution only -- the reference's NNOISE_MAX = 10 cannot
+ * serve the 17 ghost modes of D3Q27 (noise.h:18) -- in LBMI_MODE_EAGER or
+ * LBMI_MODE_FUSED_HALO; LBMI_ERR_STATE from lbmi_lb_collide otherwise. */
+int lbmi_noise_set(lbmi_t * lb, unsigned int * state, long long nsites,
+		   double kt, int ghosts_on);
 int lbmi_hydro_field_dirty(lbmi_t * lb, const double * field);
 
 /* ---- rows "next" of the scope table ----------------------- */

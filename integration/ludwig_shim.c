@@ -127,6 +127,7 @@ int bounce_back_on_links_ref(bbl_t * bbl, lb_t * lb, wall_t * wall,
 int lb_free_ref(lb_t * lb);
 int field_free_ref(field_t * obj);
 int map_free_ref(map_t * obj);
+int noise_free_ref(noise_t * obj);
 int stats_distribution_print_ref(lb_t * lb, map_t * map);
 int stats_distribution_momentum_ref(lb_t * lb, map_t * map, double g[3]);
 int phi_force_calculation_ref(pe_t * pe, cs_t * cs, lees_edw_t * le,
@@ -474,7 +475,13 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
    * energy other than the symmetric one; two
    * distributions only with the symmetric free energy (as the reference,
    * collision.c:160) */
-  if (!shim_supported(lb) || noise->on[NOISE_RHO] ||
+  /* (isothermal fluctuations: the single-fluid D3Q19 collision has them,
+   * lbmi_noise_set; with two distributions, with the stress relaxed, or --
+   * where the reference itself cannot, noise.h:18 -- on D3Q27: the original) */
+  if (!shim_supported(lb) ||
+      (noise->on[NOISE_RHO] && (lb->ndist != 1 || lb->model.nvel != 19 ||
+				(fe && fe->use_stress_relaxation) ||
+				noise->nsites != lb->nsite)) ||
       (visc != NULL && lb->ndist != 1) ||
       (fe && fe->use_stress_relaxation && fe->id != FE_SYMMETRIC) ||
       (lb->ndist == 2 && (fe == NULL || fe->id != FE_SYMMETRIC)) ||
@@ -523,6 +530,26 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
     shim_param_commit(lb);                       /* ... and device (collision.c:157) */
     SHIM_CHECK(lb, lbmi_set_relaxation(h, scheme, rho0, eta, zeta));
     SHIM_CHECK(lb, lbmi_set_body_force(h, fbody));
+
+    if (noise->on[NOISE_RHO]) {
+      /* collision.c:476-518: the generator states live in noise->target->state;
+       * the temperature is the global one (collision.c:1951) */
+      double kt = 0.0;
+      unsigned int * state = (unsigned int *)
+	shim_cached(noise, &noise->target->state, sizeof(unsigned int *));
+      physics_kt(phys, &kt);
+      if (shim_.mode == LBMI_MODE_FUSED) {
+	pe_info(lb->pe, "liblbmi: isothermal fluctuations: LBMI_MODE=fused -> halo\n");
+	SHIM_CHECK(lb, lbmi_lb_mode_set(h, LBMI_MODE_FUSED_HALO));
+	shim_.mode = LBMI_MODE_FUSED_HALO;
+	shim_sync_pointers(lb, h);
+      }
+      SHIM_CHECK(lb, lbmi_noise_set(h, state, noise->nsites, kt,
+				    lb->param->isghost == LB_GHOST_ON));
+    }
+    else {
+      SHIM_CHECK(lb, lbmi_noise_set(h, NULL, 0, 0.0, 0));
+    }
 
     status = (char *) shim_cached(map, &map->target->status, sizeof(char *));
     hy.force  = shim_field_data(hydro->force);
@@ -766,6 +793,12 @@ void field_grad_free(field_grad_t * obj) {
 int map_free(map_t * obj) {
   shim_forget(obj);
   return map_free_ref(obj);
+}
+
+int noise_free(noise_t * obj) {
+  shim_forget(obj);
+  if (shim_.h) lbmi_noise_set(shim_.h, NULL, 0, 0.0, 0);
+  return noise_free_ref(obj);
 }
 
 int wall_free(wall_t * wall) {

@@ -70,6 +70,10 @@ struct lbmi_s {
    * rho, u of the last collision owed to the caller (lbmi_tune "hydro_lazy") */
   const void * known_zero[4];
   int hydro_lazy;
+  unsigned int * noise_state;        /* lbmi_noise_set: the reference's generator state */
+  long long noise_stride;
+  double noise_kt;
+  int noise_ghosts;
   int hydro_stale;
   lbmi_hydro_dev_t lazy_h;
   double lazy_fbody[3];
@@ -565,7 +569,7 @@ int lbmi_relaxation_rates(const lbmi_t * lb, double rtau[4]) {
  *****************************************************************************/
 
 static lbmi_hydro_dev_t lbmi_hydro_dev(const lbmi_hydro_t * hydro) {
-  lbmi_hydro_dev_t h = {NULL, NULL, NULL, NULL, NULL};
+  lbmi_hydro_dev_t h = {NULL, NULL, NULL, NULL, NULL, NULL, 0, 0.0, 0};
   if (hydro) {
     h.force = hydro->force;
     h.status = hydro->status;
@@ -1591,6 +1595,35 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
 
 /*****************************************************************************
  *
+ *  lbmi_noise_set  (noise_t as lb_collide borrows it, collision.c:476-518)
+ *
+ *****************************************************************************/
+
+int lbmi_noise_set(lbmi_t * lb, unsigned int * state, long long nsites,
+		   double kt, int ghosts_on) {
+
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (state != NULL) {
+    if (lb->opts.nvel != 19 || lb->opts.ndist != 1) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "fluctuations: D3Q19, one distribution "
+		       "(noise.h:18, NNOISE_MAX = 10)");
+    }
+    if (nsites < (long long) lb->kp.nsite) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "fluctuations: %lld generator states "
+		       "for %d sites", nsites, lb->kp.nsite);
+    }
+    if (!(kt >= 0.0)) return lbmi_fail(LBMI_ERR_ARGUMENT, "fluctuations: kt < 0");
+  }
+  lb->noise_state = state;
+  lb->noise_stride = nsites;
+  lb->noise_kt = kt;
+  lb->noise_ghosts = (ghosts_on != 0);
+
+  return 0;
+}
+
+/*****************************************************************************
+ *
  *  lbmi_lb_collide  (lb_collide, collision.c:143-163)
  *
  *****************************************************************************/
@@ -1607,6 +1640,21 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
     return lbmi_fail(LBMI_ERR_STATE, "ndist = 2: lbmi_lb_collide_binary");
   }
   HIPCHECK(hipSetDevice(lb->device));
+
+  if (lb->noise_state != NULL) {
+    /* isothermal fluctuations: collide in place, or the pull of FUSED_HALO */
+    if (lb->opts.nvel != 19) {
+      return lbmi_fail(LBMI_ERR_STATE, "fluctuations: D3Q19 only (noise.h:18)");
+    }
+    if (lb->opts.mode != LBMI_MODE_EAGER && lb->opts.mode != LBMI_MODE_FUSED_HALO) {
+      return lbmi_fail(LBMI_ERR_STATE, "fluctuations: LBMI_MODE_EAGER or "
+		       "LBMI_MODE_FUSED_HALO (lbmi_lb_mode_set)");
+    }
+    h.noise = lb->noise_state;
+    h.noise_stride = lb->noise_stride;
+    h.noise_kt = lb->noise_kt;
+    h.noise_ghosts = lb->noise_ghosts;
+  }
 
   /* a force field of zeros is not read (F = the body force, bit for bit) */
   if (lbmi_known_zero(lb, h.force)) h.force = NULL;
@@ -2343,6 +2391,9 @@ int lbmi_lb_collide_fe(lbmi_t * lb, const lbmi_hydro_t * hydro,
   if (lb == NULL || fe == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   if (lb->opts.ndist != 1) return lbmi_fail(LBMI_ERR_STATE, "needs ndist = 1");
+  if (lb->noise_state != NULL) {
+    return lbmi_fail(LBMI_ERR_STATE, "fluctuations: lbmi_lb_collide only");
+  }
   if (!fe->phi || !fe->grad || !fe->delsq) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_lb_collide_fe: phi, grad and "
 		     "delsq are required");

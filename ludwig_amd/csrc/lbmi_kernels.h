@@ -49,6 +49,13 @@ typedef struct lbmi_hydro_dev_s {
   double       * rho;
   double       * u;
   const double * eta;       /* local shear viscosity, or NULL */
+  /* isothermal fluctuations: the reference's generator state (noise->state,
+   * 4 unsigned ints per site, component ia of site i at [ia*stride + i]),
+   * or NULL = off */
+  unsigned int * noise;
+  long long      noise_stride;
+  double         noise_kt;
+  int            noise_ghosts;
 } lbmi_hydro_dev_t;
 
 /* Halo pass description: components (populations) to copy to the low-side

@@ -236,15 +236,50 @@ struct Relax {
   double rtau_s, rtau_b, rtau_e, rtau_o;
 };
 
+/* Isothermal fluctuations (collision.c:476-518): a random stress with the
+ * variance of the fluctuation-dissipation theorem joins the post-collision
+ * stress, and, with ghost modes on, a random part each ghost mode
+ * (lb_fluctuations_var_eta/_bulk/_ghost, _stress, _ghosts, :1745-1920).
+ * The numbers are the reference's: one draw of its per-site generator gives
+ * up to ten three-bit indices into Ladd's eight-entry table (noise.c:72-79,
+ * 397-424, noise_uniform :467-487). D3Q19 only, as in the reference
+ * (NNOISE_MAX = 10 < the 17 ghost modes of D3Q27, noise.h:18). */
+
+struct SiteNoise {
+  double shat[6];          /* xx xy xz yy yz zz */
+  double ghat[9];          /* modes 10 .. 18 */
+};
+
+__device__ __forceinline__ unsigned int noise_uniform(unsigned int (&st)[4]) {
+  st[0] = 69069u*st[0] + 1234567u;
+  unsigned int b = st[1] ^ (st[1] << 17);
+  b ^= (b >> 13);
+  st[1] = b ^ (b << 5);
+  st[2] = 36969u*(st[2] & 0xffffu) + (st[2] >> 16);
+  st[3] = 18000u*(st[3] & 0xffffu) + (st[3] >> 16);
+  b = (st[2] << 16) + st[3];
+  return st[1] + (st[0] ^ b);
+}
+
+__device__ __forceinline__ double noise_table(unsigned int k) {
+  const double a = sqrt(2.0 + sqrt(2.0));
+  const double b = sqrt(2.0 - sqrt(2.0));
+  const double v = (k == 0u || k == 7u) ? a : ((k == 1u || k == 6u) ? b : 0.0);
+  return (k < 2u) ? -v : v;
+}
+
 /* STH: add the thermodynamic stress sth (xx xy xz yy yz zz) to the
  * equilibrium stress, as the two-distribution collision does
  * (collision.c:838-850) */
 
-template <int NVEL, int SCHEME, bool STH>
+template <int NVEL, int SCHEME, bool STH, bool NZ = false>
 __device__ __forceinline__
 void collide_site_impl(double (&f)[NVEL], const double (&frc)[3],
 		       const Relax & rx, const double (&sth)[6],
-		       double & rho, double (&u)[3]) {
+		       double & rho, double (&u)[3],
+		       const SiteNoise * nz = nullptr) {
+
+  static_assert(!NZ || NVEL == 19, "fluctuations: D3Q19 only (noise.h:18)");
 
   using M = Model<NVEL>;
   constexpr bool keepf  = (SCHEME != LBMI_M10);
@@ -326,6 +361,11 @@ void collide_site_impl(double (&f)[NVEL], const double (&frc)[3],
     }
   }
 
+  if constexpr (NZ) {
+    /* mode[4 .. 9] = S' + shat (collision.c:529-536) */
+    static_for<0, 6>([&](auto K) { ds[K] += nz->shat[K]; });
+  }
+
   /* hydrodynamic part of the back projection:
    * w_p [ (drho - 1.5 tr dS) + 3 dg.c + 4.5 dS_aa c_a^2 + 9 dS_ab c_a c_b ] */
   const double keep = keepf ? (1.0 - rx.rtau_e) : 0.0;
@@ -339,8 +379,14 @@ void collide_site_impl(double (&f)[NVEL], const double (&frc)[3],
 
   /* odd ghost modes (TRT, d3q19) and the mode-13 quirk */
   double e[NVEL];
-  if constexpr (NVEL == 19 && keepf) {
+  if constexpr (NVEL == 19 && NZ) {
+    /* ... + ghat (collision.c:540-545) */
+    static_for<10, 19>([&](auto K) { e[K] = nz->ghat[K - 10]; });
+  }
+  else if constexpr (NVEL == 19 && keepf) {
     static_for<10, 19>([&](auto K) { e[K] = 0.0; });
+  }
+  if constexpr (NVEL == 19 && keepf) {
     if constexpr (odd) {
       const double dr = rx.rtau_e - rx.rtau_o;
       static_for<11, 18>([&](auto K) {
@@ -354,7 +400,7 @@ void collide_site_impl(double (&f)[NVEL], const double (&frc)[3],
 	    else if constexpr (c == -1.0) mk -= f[p];
 	    else if constexpr (c != 0.0) mk += c*f[p];
 	  });
-	  e[k] = dr*mk;
+	  e[k] += dr*mk;
 	}
       });
     }
@@ -386,7 +432,14 @@ void collide_site_impl(double (&f)[NVEL], const double (&frc)[3],
     constexpr double wp = M::w(p);
     double fn = wp*t;
     if constexpr (keepf) fn += keep*f[p];
-    if constexpr (NVEL == 19 && keepf) {
+    if constexpr (NVEL == 19 && NZ) {
+      static_for<10, 19>([&](auto K) {
+	constexpr int k = K;
+	constexpr double mipk = M::mi(p,k);
+	if constexpr (mipk != 0.0) fn += mipk*e[k];
+      });
+    }
+    else if constexpr (NVEL == 19 && keepf) {
       if constexpr (odd) {
 	static_for<11, 18>([&](auto K) {
 	  constexpr int k = K;
@@ -446,6 +499,80 @@ void collide_site(double (&f)[NVEL], const double (&frc)[3], const Relax & rx,
   collide_site_impl<NVEL, SCHEME, false>(f, frc, rx, none, rho, u);
 }
 
+/* The random stress and ghost parts of site i, and its generator advanced
+ * (collision.c:491-516: two draws per fluid site and step, the second only
+ * with ghost modes on; solid sites draw nothing). The state is the
+ * reference's array noise->state, four unsigned ints per site, SoA. */
+
+template <int SCHEME>
+__device__ __forceinline__
+void site_noise(const lbmi_hydro_dev_t & h, int i, const Relax & rx,
+		SiteNoise & nz) {
+  using M = Model<19>;
+  const size_t hs = (size_t) h.noise_stride;
+  unsigned int st[4] = {h.noise[i], h.noise[hs + i], h.noise[2*hs + i],
+			h.noise[3*hs + i]};
+  const double kt = h.noise_kt*3.0;              /* kt*rcs2 */
+
+  {
+    /* lb_fluctuations_var_eta, _var_bulk, _stress (collision.c:1753-1887) */
+    const double tau = 1.0/rx.rtau_s;
+    const double taub = 1.0/rx.rtau_b;
+    const double var = sqrt(kt)*sqrt(1.0/9.0)*sqrt((tau + tau - 1.0)/(tau*tau));
+    const double varb = sqrt(kt)*sqrt(2.0/9.0)*sqrt((taub + taub - 1.0)/(taub*taub));
+    unsigned int iu = noise_uniform(st) >> 2;
+    double r[6];
+    static_for<0, 6>([&](auto K) { r[K] = noise_table(iu & 7u); iu >>= 3; });
+    double tr = (1.0/3.0)*(r[0] + r[3] + 1.0*r[5]);
+    r[0] -= tr; r[3] -= tr; r[5] -= tr;
+    const double vd = var*sqrt(2.0);
+    nz.shat[0] = r[0]*vd;  nz.shat[1] = r[1]*var; nz.shat[2] = r[2]*var;
+    nz.shat[3] = r[3]*vd;  nz.shat[4] = r[4]*var; nz.shat[5] = r[5]*vd;
+    tr *= varb;
+    nz.shat[0] += tr; nz.shat[3] += tr; nz.shat[5] += tr;
+  }
+
+  static_for<0, 9>([&](auto K) { nz.ghat[K] = 0.0; });
+  if (h.noise_ghosts) {
+    /* lb_fluctuations_var_ghost, _ghosts (collision.c:1800-1918): the
+     * numbers go to the ghost modes in the order of the basis */
+    unsigned int ig = noise_uniform(st) >> 2;
+    static_for<10, 19>([&](auto K) {
+      constexpr int k = K;
+      constexpr bool oddk = (k >= 11 && k <= 17 && k != 14);
+      double rate = oddk ? rx.rtau_o : rx.rtau_e;
+      if constexpr (SCHEME == LBMI_M10) rate = 1.0;
+      if constexpr (SCHEME == LBMI_BGK) rate = rx.rtau_s;
+      const double taug = 1.0/rate;
+      constexpr double rna = 1.0/M::na(k);
+      const double varg = sqrt(kt*rna)*sqrt((taug + taug - 1.0)/(taug*taug));
+      nz.ghat[k - 10] = varg*noise_table(ig & 7u);
+      ig >>= 3;
+    });
+  }
+
+  h.noise[i] = st[0];
+  h.noise[hs + i] = st[1];
+  h.noise[2*hs + i] = st[2];
+  h.noise[3*hs + i] = st[3];
+}
+
+template <int NVEL, int SCHEME, bool NZ>
+__device__ __forceinline__
+void collide_site_nz(const lbmi_hydro_dev_t & h, int i, double (&f)[NVEL],
+		     const double (&frc)[3], const Relax & rx,
+		     double & rho, double (&u)[3]) {
+  if constexpr (NZ) {
+    const double none[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    SiteNoise nz;
+    site_noise<SCHEME>(h, i, rx, nz);
+    collide_site_impl<NVEL, SCHEME, false, true>(f, frc, rx, none, rho, u, &nz);
+  }
+  else {
+    collide_site<NVEL, SCHEME>(f, frc, rx, rho, u);
+  }
+}
+
 /* ---- helpers -------------------------------------------------------------- */
 
 /* XCD-aware mapping of blockIdx to a logical block: blocks b and b + 8 run
@@ -502,7 +629,7 @@ __device__ __forceinline__ Site decode(const lbmi_kparam_t & kp, int i) {
 
 /* ---- k_collide: in-place collision of interior fluid sites ---------------- */
 
-template <int NVEL, int SCHEME>
+template <int NVEL, int SCHEME, bool NZ = false>
 __global__ __launch_bounds__(BLOCK)
 void k_collide(lbmi_kparam_t kp, double * __restrict__ f,
 	       lbmi_hydro_dev_t h, int i0, int i1, unsigned nblk) {
@@ -529,7 +656,7 @@ void k_collide(lbmi_kparam_t kp, double * __restrict__ f,
 
   Relax rx = site_relax<SCHEME>(kp, h, i);
   double rho, u[3];
-  collide_site<NVEL, SCHEME>(fl, frc, rx, rho, u);
+  collide_site_nz<NVEL, SCHEME, NZ>(h, i, fl, frc, rx, rho, u);
 
   static_for<0, NVEL>([&](auto P) { f[ns*P + i] = fl[P]; });
   if (h.rho) h.rho[i] = rho;
@@ -760,7 +887,7 @@ void pc_pull(const lbmi_kparam_t & kp, const double * __restrict__ f,
  * step has no hydro traffic (no force field to read, rho and u not wanted
  * now): a variant of its own, so that it is also a kernel of its own name in
  * a profile */
-template <int NVEL, int SCHEME, bool WB, bool NTS, bool HIO, bool XB>
+template <int NVEL, int SCHEME, bool WB, bool NTS, bool HIO, bool XB, bool NZ = false>
 __device__ __forceinline__
 void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
 		      const lbmi_hydro_dev_t & h, int i,
@@ -784,7 +911,7 @@ void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
     }
     Relax rx = site_relax<SCHEME>(kp, h, i);
     double rho, u[3];
-    collide_site<NVEL, SCHEME>(ps.fl, frc, rx, rho, u);
+    collide_site_nz<NVEL, SCHEME, NZ>(h, i, ps.fl, frc, rx, rho, u);
     if constexpr (!HIO) {
       /* nothing to store */
     }
@@ -848,7 +975,7 @@ void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
 /* LAY & 3: 0 SoA -> SoA, 1 SoA -> blocked, 2 blocked -> blocked;
  * LAY & 4: nontemporal stores of fprime */
 
-template <int NVEL, int SCHEME, bool WRAP, int LAY, bool HIO, bool XB>
+template <int NVEL, int SCHEME, bool WRAP, int LAY, bool HIO, bool XB, bool NZ = false>
 __global__ __launch_bounds__(BLOCK, LBMI_WAVES)
 void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
 			 double * __restrict__ fp, lbmi_hydro_dev_t h,
@@ -886,7 +1013,7 @@ void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
   static_for<0, SPT>([&](auto K) {
     constexpr int k = K;
     if (i[k] >= i0 && i[k] < i1) {
-      pc_collide_store<NVEL, SCHEME, ORD != 0, (LAY & 4) != 0, HIO, XB>(kp, fp, h, i[k], ps[k], xb);
+      pc_collide_store<NVEL, SCHEME, ORD != 0, (LAY & 4) != 0, HIO, XB, NZ>(kp, fp, h, i[k], ps[k], xb);
     }
   });
 }
@@ -2413,6 +2540,25 @@ int launch_collide(const lbmi_kparam_t & kp, double * f,
   unsigned nblk = (unsigned) ((i1 - i0a + BLOCK - 1)/BLOCK);
   dim3 grid(grid_for(nblk, (unsigned) kp.xcd_group)), block(BLOCK);
   unsigned lds = (kp.lds_cap <= 65536 && nblk > 4096u) ? (unsigned) kp.lds_cap : 0u;
+  if (h.noise != nullptr) {
+    if constexpr (NVEL == 19) {
+      switch (kp.scheme) {
+      case LBMI_M10:
+	hipLaunchKernelGGL((k_collide<19, LBMI_M10, true>), grid, block, 0, st, kp, f, h, i0, i1, nblk);
+	break;
+      case LBMI_BGK:
+	hipLaunchKernelGGL((k_collide<19, LBMI_BGK, true>), grid, block, 0, st, kp, f, h, i0, i1, nblk);
+	break;
+      case LBMI_TRT:
+	hipLaunchKernelGGL((k_collide<19, LBMI_TRT, true>), grid, block, 0, st, kp, f, h, i0, i1, nblk);
+	break;
+      default:
+	return (int) hipErrorInvalidValue;
+      }
+      return (int) hipGetLastError();
+    }
+    return (int) hipErrorInvalidValue;
+  }
   switch (kp.scheme) {
   case LBMI_M10:
     hipLaunchKernelGGL((k_collide<NVEL, LBMI_M10>), grid, block, lds, st,
@@ -2510,11 +2656,46 @@ int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
   return launch_pc_hio<NVEL, WRAP, LAY, false, false>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st, none);
 }
 
+/* with fluctuations: D3Q19, SoA -> SoA without index wrap (the pull of
+ * FUSED_HALO), hydro arrays as they are, no exchange buffers */
+inline int launch_pc_noise(const lbmi_kparam_t & kp, const double * f, double * fp,
+			   const lbmi_hydro_dev_t & h, int i0, int i1, int j0,
+			   int j1, hipStream_t st) {
+  const lbmi_xbuf_t none = {nullptr, nullptr, nullptr, nullptr};
+  const int i0a = (i0/LBMI_ALIGN)*LBMI_ALIGN;
+  const int j0a = (j0/LBMI_ALIGN)*LBMI_ALIGN;
+  unsigned nblk_first = (unsigned) ((i1 - i0a + BLOCK*SPT - 1)/(BLOCK*SPT));
+  unsigned nblk = nblk_first;
+  if (j1 > j0) nblk += (unsigned) ((j1 - j0a + BLOCK*SPT - 1)/(BLOCK*SPT));
+  dim3 grid(grid_for(nblk, (unsigned) kp.xcd_group)), block(BLOCK);
+  switch (kp.scheme) {
+  case LBMI_M10:
+    hipLaunchKernelGGL((k_propagate_collide<19, LBMI_M10, false, 0, true, false, true>), grid,
+		       block, 0, st, kp, f, fp, h, 0, i0, i1, nblk, j0, j1, nblk_first, none);
+    break;
+  case LBMI_BGK:
+    hipLaunchKernelGGL((k_propagate_collide<19, LBMI_BGK, false, 0, true, false, true>), grid,
+		       block, 0, st, kp, f, fp, h, 0, i0, i1, nblk, j0, j1, nblk_first, none);
+    break;
+  case LBMI_TRT:
+    hipLaunchKernelGGL((k_propagate_collide<19, LBMI_TRT, false, 0, true, false, true>), grid,
+		       block, 0, st, kp, f, fp, h, 0, i0, i1, nblk, j0, j1, nblk_first, none);
+    break;
+  default:
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
 template <int NVEL>
 int launch_pc_any(const lbmi_kparam_t & kp, const double * f, double * fp,
 		  const lbmi_hydro_dev_t & h, int wrapmask, int lay, int i0,
 		  int i1, int j0, int j1, hipStream_t st,
 		  const lbmi_xbuf_t * xb) {
+  if (h.noise != nullptr) {
+    if (NVEL != 19 || wrapmask || lay != 0 || xb != nullptr) return (int) hipErrorInvalidValue;
+    return launch_pc_noise(kp, f, fp, h, i0, i1, j0, j1, st);
+  }
   if (!wrapmask) {
     if (lay != 0 || xb != nullptr) return (int) hipErrorInvalidValue;
     return launch_pc<NVEL, false, 0>(kp, f, fp, h, 0, i0, i1, j0, j1, st, nullptr);

@@ -293,6 +293,21 @@ class LB:
         collision (tune hydro_lazy) still owes them."""
         _l.check(self._lib.lbmi_lb_hydro_sync(self._h))
 
+    def noise_set(self, state, kt, ghosts_on=True):
+        """lbmi_noise_set: isothermal fluctuations in lb_collide. state: an
+        int32/uint32 device tensor of shape (4, nsite) -- the reference's
+        noise->state (SoA) -- advanced in place by every collision; None:
+        off. The tensor must stay alive while it is set."""
+        if state is None:
+            _l.check(self._lib.lbmi_noise_set(self._h, None, 0, 0.0, 0))
+            self._noise = None
+            return
+        assert state.dim() == 2 and state.shape[0] == 4 and state.is_contiguous()
+        assert state.element_size() == 4
+        self._noise = state
+        _l.check(self._lib.lbmi_noise_set(self._h, _ptr(state), int(state.shape[1]),
+                                          float(kt), 1 if ghosts_on else 0))
+
     def hydro_field_dirty(self, field):
         """Somebody outside the library has written to this device field."""
         _l.check(self._lib.lbmi_hydro_field_dirty(self._h, _ptr(field)))

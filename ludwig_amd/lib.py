@@ -127,6 +127,7 @@ SYMBOLS = [
     ("lbmi_lb_density", _i, [_vp, _vp]),
     ("lbmi_field_stats", _i, [_vp, _vp, _vp, _pd]),
     ("lbmi_lb_hydro_sync", _i, [_vp]),
+    ("lbmi_noise_set", _i, [_vp, _vp, ctypes.c_longlong, _d, _i]),
     ("lbmi_hydro_field_dirty", _i, [_vp, _vp]),
     ("lbmi_hydro_field_set", _i, [_vp, _vp, _i, _pd]),
     ("lbmi_field_halo_n", _i, [_vp, _i, _i, _vp]),

@@ -251,17 +251,71 @@ static void symm_stress(double a, double b, double kappa, double phi,
  * added to the equilibrium stress. fe = {a, b, kappa}; phi, grad, delsq as
  * field_grad_compute left them. */
 
+typedef struct {
+  uint32_t * state;        /* noise->state: [ia*nsite + index], ia = 0 .. 3 */
+  double kt;
+  int ghosts_on;           /* lb->param->isghost == LB_GHOST_ON */
+} lbo_noise_t;
+
 static int collide_impl(const lbo_param_t * p, double * f,
 			const double * force, const char * status,
 			const double * fe, const double * phi,
 			const double * grad, const double * delsq,
-			const double * eta_site,
+			const double * eta_site, const lbo_noise_t * noise,
 			double * rho_out, double * u_out);
 
 int lbo_collide(const lbo_param_t * p, double * f, const double * force,
 		const char * status, double * rho_out, double * u_out) {
-  return collide_impl(p, f, force, status, NULL, NULL, NULL, NULL, NULL,
+  return collide_impl(p, f, force, status, NULL, NULL, NULL, NULL, NULL, NULL,
 		      rho_out, u_out);
+}
+
+/* With isothermal fluctuations (noise->on[NOISE_RHO], collision.c:476-518):
+ * state is the reference's per-site generator state, advanced here as
+ * lb_collide advances it. eta may be NULL (no viscosity model). */
+
+int lbo_collide_noise(const lbo_param_t * p, double * f, const double * force,
+		      const char * status, const double * eta,
+		      uint32_t * state, double kt, int ghosts_on,
+		      double * rho_out, double * u_out) {
+  lbo_noise_t noise = {state, kt, ghosts_on};
+  if (p->nvel != 19) return -1;      /* NNOISE_MAX = 10 < 17 ghosts, noise.h:18 */
+  return collide_impl(p, f, force, status, NULL, NULL, NULL, NULL, eta, &noise,
+		      rho_out, u_out);
+}
+
+/* noise_uniform (noise.c:467-487): Marsaglia's combination of a congruential
+ * generator, a 3-shift register and two multiply-with-carry generators. */
+
+static uint32_t noise_uniform(uint32_t state[4]) {
+  uint32_t b;
+  state[0] = 69069u*state[0] + 1234567u;
+  b = state[1] ^ (state[1] << 17);
+  b ^= (b >> 13);
+  state[1] = b ^ (b << 5);
+  state[2] = 36969u*(state[2] & 0xffffu) + (state[2] >> 16);
+  state[3] = 18000u*(state[3] & 0xffffu) + (state[3] >> 16);
+  b = (state[2] << 16) + state[3];
+  return state[1] + (state[0] ^ b);
+}
+
+/* noise_reap_n (noise.c:397-424): one draw, its two leading bits dropped,
+ * three bits per number into the table of noise.c:72-79 */
+
+static void noise_reap_n(uint32_t * state, ptrdiff_t nsite, ptrdiff_t index,
+			 int nmax, double * reap) {
+  const double a = sqrt(2.0 + sqrt(2.0));
+  const double b = sqrt(2.0 - sqrt(2.0));
+  const double rtable[8] = {-a, -b, 0.0, 0.0, 0.0, 0.0, +b, +a};
+  uint32_t s[4], iuniform;
+  for (int ia = 0; ia < 4; ia++) s[ia] = state[nsite*ia + index];
+  iuniform = noise_uniform(s);
+  for (int ia = 0; ia < 4; ia++) state[nsite*ia + index] = s[ia];
+  iuniform >>= 2;
+  for (int ia = 0; ia < nmax; ia++) {
+    reap[ia] = rtable[iuniform & 7];
+    iuniform >>= 3;
+  }
 }
 
 /* With a viscosity model (visc != NULL in lb_collide): the local shear
@@ -271,7 +325,7 @@ int lbo_collide(const lbo_param_t * p, double * f, const double * force,
 int lbo_collide_visc(const lbo_param_t * p, double * f, const double * force,
 		     const char * status, const double * eta,
 		     double * rho_out, double * u_out) {
-  return collide_impl(p, f, force, status, NULL, NULL, NULL, NULL, eta,
+  return collide_impl(p, f, force, status, NULL, NULL, NULL, NULL, eta, NULL,
 		      rho_out, u_out);
 }
 
@@ -280,7 +334,7 @@ int lbo_collide_fe(const lbo_param_t * p, double * f, const double * force,
 		   const double * phi, const double * grad,
 		   const double * delsq, double * rho_out, double * u_out) {
   const double fe[3] = {a, b, kappa};
-  return collide_impl(p, f, force, status, fe, phi, grad, delsq, NULL,
+  return collide_impl(p, f, force, status, fe, phi, grad, delsq, NULL, NULL,
 		      rho_out, u_out);
 }
 
@@ -288,7 +342,7 @@ static int collide_impl(const lbo_param_t * p, double * f,
 			const double * force, const char * status,
 			const double * fe, const double * phi,
 			const double * grad, const double * delsq,
-			const double * eta_site,
+			const double * eta_site, const lbo_noise_t * noise,
 			double * rho_out, double * u_out) {
 
   int nall[3];
@@ -403,17 +457,56 @@ static int collide_impl(const lbo_param_t * p, double * f,
 	  }
 	}
 
+	/* fluctuations (collision.c:476-518) */
+	double shat[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+	double ghat[LBO_NVEL_MAX];
+	for (m = 0; m < LBO_NVEL_MAX; m++) ghat[m] = 0.0;
+	if (noise) {
+	  const double rcs2 = 3.0;
+	  double random[10];
+	  double kt = noise->kt*rcs2;
+	  double tr;
+	  /* lb_fluctuations_var_eta, _var_bulk (:1753-1783) */
+	  double tau = 1.0/srtau, tau_b = 1.0/srtau_bulk;
+	  double var = sqrt(kt)*sqrt(1.0/9.0)*sqrt((tau + tau - 1.0)/(tau*tau));
+	  double var_bulk = sqrt(kt)*sqrt(2.0/9.0)
+	    *sqrt((tau_b + tau_b - 1.0)/(tau_b*tau_b));
+	  /* lb_fluctuations_stress (:1826-1887) */
+	  noise_reap_n(noise->state, nsite, index, 6, random);
+	  shat[X][X] = random[0]; shat[X][Y] = random[1]; shat[X][Z] = random[2];
+	  shat[Y][X] = shat[X][Y]; shat[Y][Y] = random[3]; shat[Y][Z] = random[4];
+	  shat[Z][X] = shat[X][Z]; shat[Z][Y] = shat[Y][Z]; shat[Z][Z] = random[5];
+	  tr = (1.0/3)*(shat[X][X] + shat[Y][Y] + (3 - 2.0)*shat[Z][Z]);
+	  shat[X][X] -= tr; shat[Y][Y] -= tr; shat[Z][Z] -= tr;
+	  shat[X][X] *= var*sqrt(2.0); shat[X][Y] *= var; shat[X][Z] *= var;
+	  shat[Y][X] *= var; shat[Y][Y] *= var*sqrt(2.0); shat[Y][Z] *= var;
+	  shat[Z][X] *= var; shat[Z][Y] *= var; shat[Z][Z] *= var*sqrt(2.0);
+	  tr *= var_bulk;
+	  shat[X][X] += tr; shat[Y][Y] += tr; shat[Z][Z] += tr;
+	  if (noise->ghosts_on) {
+	    /* lb_fluctuations_var_ghost, _ghosts (:1800-1918);
+	     * rna[p] = 1/na[p] (model.c:377-379) */
+	    noise_reap_n(noise->state, nsite, index, nvel - NHYDRO, random);
+	    for (m = NHYDRO; m < nvel; m++) {
+	      double tau_g = 1.0/srtau_ghost[m];
+	      double rna = 1.0/model.na[m];
+	      double varg = sqrt(kt*rna)*sqrt((tau_g + tau_g - 1.0)/(tau_g*tau_g));
+	      ghat[m] = varg*random[m - NHYDRO];
+	    }
+	  }
+	}
+
 	/* post-collision modes (collision.c:523-544) */
 	for (int ia = 0; ia < 3; ia++) mode[1+ia] += frc[ia];
 	m = 0;
 	for (int ia = 0; ia < 3; ia++) {
 	  for (int ib = ia; ib < 3; ib++) {
-	    mode[4 + m] = s[ia][ib];
+	    mode[4 + m] = s[ia][ib] + shat[ia][ib];
 	    m++;
 	  }
 	}
 	for (m = NHYDRO; m < nvel; m++) {
-	  mode[m] = mode[m] - srtau_ghost[m]*(mode[m] - 0.0);
+	  mode[m] = mode[m] - srtau_ghost[m]*(mode[m] - 0.0) + ghat[m];
 	}
 
 	/* modes -> f (collision.c:548-559) */

@@ -80,6 +80,10 @@ int lbo_wall_bbl_slip(const lbo_param_t * p, double * f, int nlink,
 		      const int * linkk, const int * linkq, const int * links,
 		      const double stab[19], double fnet[3],
 		      const char * status);
+int lbo_collide_noise(const lbo_param_t * p, double * f, const double * force,
+		      const char * status, const double * eta,
+		      uint32_t * state, double kt, int ghosts_on,
+		      double * rho_out, double * u_out);
 int lbo_collide_visc(const lbo_param_t * p, double * f, const double * force,
 		     const char * status, const double * eta,
 		     double * rho_out, double * u_out);

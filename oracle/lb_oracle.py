@@ -265,6 +265,20 @@ def collide_visc(p, f, force, status, eta, rho=None, u=None):
     assert rc == 0
 
 
+def collide_noise(p, f, force, status, state, kt, ghosts_on=True, eta=None,
+                  rho=None, u=None):
+    """lb_collide with isothermal fluctuations: state (4,) + nall uint32, the
+    reference's noise->state, advanced in place."""
+    assert state.dtype == np.uint32 and state.shape == (4,) + nall(p)
+    fn = lib().lbo_collide_noise
+    fn.argtypes = None
+    rc = fn(ctypes.byref(p), _ptr(f), _ptr(force), _ptr(status), _ptr(eta),
+            _ptr(state), ctypes.c_double(kt), ctypes.c_int(1 if ghosts_on else 0),
+            _ptr(rho), _ptr(u))
+    if rc != 0:
+        raise ValueError("lbo_collide_noise: D3Q19 only")
+
+
 def collide_fe(p, f, force, status, a, b, kappa, phi, grad, delsq, rho=None,
                u=None):
     """lb_collide with fe->use_stress_relaxation (symmetric free energy)."""

@@ -55,7 +55,18 @@ VISC_CASES = [
 ]
 
 
-def run_case(case, tmp, visc=0, exe=None, env=None):
+# the same tuple + (visc, kt, ghosts): isothermal fluctuations
+# (noise->on[NOISE_RHO], temperature kt); keys noise0, noise_final = the
+# generator states (4, nall) uint32 before the first and after the last step
+NOISE_CASES = [
+    (("noise_q19_m10", 19, (6, 5, 4), 1, "m10", 0.1, 0.3, (0, 0, 0), 0, 0, 4, False), 0, 1e-4, 1),
+    (("noise_q19_trt_solid", 19, (6, 5, 4), 1, "trt", 0.05, 0.2, (1e-5, 0, 0), 1, 1, 4, False), 0, 2e-4, 1),
+    (("noise_q19_bgk_visc", 19, (6, 5, 4), 1, "bgk", 0.2, 0.2, (0, 0, 0), 0, 0, 4, False), 1, 1e-4, 1),
+    (("noise_q19_m10_noghost", 19, (5, 4, 6), 1, "m10", 0.1, 0.3, (0, 0, 0), 0, 0, 4, False), 0, 1e-4, 0),
+]
+
+
+def run_case(case, tmp, visc=0, exe=None, env=None, noise=None):
     """exe, env: another build of the same driver (tests/test_gpu_shim.py runs
     the reference's HIP target, with and without the binding, this way)."""
     (name, nvel, n, nhalo, scheme, eta, zeta, fb, ff, solid, nsteps,
@@ -66,8 +77,10 @@ def run_case(case, tmp, visc=0, exe=None, env=None):
     args = [exe, "dump", prefix, *map(str, n), str(nhalo), scheme,
             repr(eta), repr(zeta), *[repr(float(x)) for x in fb],
             str(ff), str(solid), str(nsteps)]
-    if visc:
-        args.append("1")
+    if visc or noise:
+        args.append("1" if visc else "0")
+    if noise:
+        args += [repr(float(noise[0])), str(int(noise[1]))]
     subprocess.run(args, check=True, env=env)
     meta = json.load(open(prefix + ".json"))
     meta["name"] = name
@@ -92,6 +105,10 @@ def run_case(case, tmp, visc=0, exe=None, env=None):
     out["f_final"] = load("f_final", (nvel,))
     if visc:
         out["eta"] = load("eta", ())
+    if noise:
+        for key in ("noise0", "noise_final"):
+            a = np.fromfile("%s.%s.i32" % (prefix, key), dtype="<u4")
+            out[key] = a.reshape((4,) + nall)
     return out
 
 
@@ -293,6 +310,11 @@ def main():
             print("wrote", fn, os.path.getsize(fn))
         for case in VISC_CASES:
             out = run_case(case, tmp, visc=1)
+            fn = os.path.join(GOLD, case[0] + ".npz")
+            np.savez_compressed(fn, **out)
+            print("wrote", fn, os.path.getsize(fn))
+        for case, visc, kt, ghosts in NOISE_CASES:
+            out = run_case(case, tmp, visc=visc, noise=(kt, ghosts))
             fn = os.path.join(GOLD, case[0] + ".npz")
             np.savez_compressed(fn, **out)
             print("wrote", fn, os.path.getsize(fn))

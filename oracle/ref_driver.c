@@ -25,7 +25,9 @@
  *
  *  Usage:
  *    ref_driver dump <prefix> nx ny nz nhalo scheme eta zeta fx fy fz \
- *               fieldforce solid nsteps [visc]
+ *               fieldforce solid nsteps [visc [kt ghosts]]
+ *               (kt > 0: isothermal fluctuations, noise->on[NOISE_RHO];
+ *               the generator states before and after are dumped as well)
  *    ref_driver time nx ny nz scheme eta zeta nsteps
  *    ref_driver fe <prefix> nx ny nz a b kappa mobility [gradnpt advorder]
  *               (symmetric free energy: field_halo, field_grad_compute with
@@ -93,6 +95,8 @@ typedef struct {
   int solid;            /* a block of MAP_BOUNDARY sites on/off */
   int nsteps;
   int visc;             /* viscosity model: local eta from hydro->eta */
+  double kt;            /* > 0: isothermal fluctuations at this temperature */
+  int ghosts;           /* 0: ghost modes off (lb_collision_ghost_modes_off) */
 } case_t;
 
 static uint32_t lcg_state = 12345u;
@@ -864,7 +868,8 @@ int main(int argc, char ** argv) {
     return run_io(argc, argv);
   }
 
-  if (argc >= 2 && strcmp(argv[1], "dump") == 0 && (argc == 16 || argc == 17)) {
+  if (argc >= 2 && strcmp(argv[1], "dump") == 0 &&
+      (argc == 16 || argc == 17 || argc == 19)) {
     int a = 2;
     strncpy(prefix, argv[a++], sizeof(prefix) - 1);
     c.ntotal[X] = atoi(argv[a++]);
@@ -880,7 +885,12 @@ int main(int argc, char ** argv) {
     c.fieldforce = atoi(argv[a++]);
     c.solid = atoi(argv[a++]);
     c.nsteps = atoi(argv[a++]);
-    if (argc == 17) c.visc = atoi(argv[a++]);
+    c.ghosts = 1;
+    if (argc >= 17) c.visc = atoi(argv[a++]);
+    if (argc == 19) {
+      c.kt = atof(argv[a++]);
+      c.ghosts = atoi(argv[a++]);
+    }
   }
   else if (argc >= 2 && strcmp(argv[1], "time") == 0 && argc == 9) {
     int a = 2;
@@ -930,6 +940,13 @@ int main(int argc, char ** argv) {
   noise_create(pe, cs, &noise);
   noise_init(noise, 0);
   assert(noise->on[NOISE_RHO] == 0);
+  if (c.kt > 0.0) {
+    /* isothermal_fluctuations on; temperature kt (ludwig.c, physics_rt.c) */
+    physics_kt_set(phys, c.kt);
+    noise_present_set(noise, NOISE_RHO, 1);
+    if (c.ghosts == 0) lb_collision_ghost_modes_off(lb);
+    noise_memcpy(noise, tdpMemcpyHostToDevice);
+  }
 
   init_f(cs, lb, &c);
   init_force(cs, hydro, &c);
@@ -970,6 +987,10 @@ int main(int argc, char ** argv) {
       dump(prefix, "f0", lb->f, nf);
       dump(prefix, "force", hydro->force->data, 3*ns);
       if (c.visc) dump(prefix, "eta", hydro->eta->data, ns);
+      if (c.kt > 0.0) {
+	dump_i32(prefix, "noise0", (const int *) noise->state,
+		 (size_t) NNOISE_STATE*noise->nsites);
+      }
 
       for (int n = 0; n < c.nsteps; n++) {
 	lb_collide(lb, hydro, map, noise, NULL, visc);
@@ -993,6 +1014,11 @@ int main(int argc, char ** argv) {
       }
       lb_memcpy(lb, tdpMemcpyDeviceToHost);
       dump(prefix, "f_final", lb->f, nf);
+      if (c.kt > 0.0) {
+	noise_memcpy(noise, tdpMemcpyDeviceToHost);
+	dump_i32(prefix, "noise_final", (const int *) noise->state,
+		 (size_t) NNOISE_STATE*noise->nsites);
+      }
       {
 	/* The on-disk record stream of lb_io_aggr_pack (model.c:1479-1510):
 	 * lb_write_buf for every interior site in (ic, jc, kc) order */
@@ -1029,11 +1055,12 @@ int main(int argc, char ** argv) {
 		" \"eta\": %.17g, \"zeta\": %.17g, \"rho0\": 1.0,"
 		" \"fbody\": [%.17g, %.17g, %.17g], \"fieldforce\": %d,"
 		" \"solid\": %d, \"nsteps\": %d, \"visc\": %d,"
+		" \"kt\": %.17g, \"ghosts\": %d,"
 		" \"layout\": \"soa\"}\n",
 		NVEL, c.ntotal[X], c.ntotal[Y], c.ntotal[Z], c.nhalo,
 		nall[X], nall[Y], nall[Z], lb->nsite, (int) c.nrelax,
 		c.eta, c.zeta, c.fbody[X], c.fbody[Y], c.fbody[Z],
-		c.fieldforce, c.solid, c.nsteps, c.visc);
+		c.fieldforce, c.solid, c.nsteps, c.visc, c.kt, c.ghosts);
 	fclose(fp);
       }
     }
