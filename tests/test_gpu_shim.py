@@ -539,3 +539,33 @@ def test_reference_unit_suites_with_the_binding(nvel):
     assert calls["lb_propagation"][0] >= 4 and calls["lb_propagation"][1] == 0
     # test_halo.c: the device scheme is the library's, the host schemes the original's
     assert calls["lb_halo_swap"][0] >= 16 and calls["lb_halo_swap"][1] >= 1
+
+
+@pytest.mark.parametrize("name,ncollide", [
+    ("serial-auto-c02", 40),      # a Brownian colloid: fluctuations + bounce-back on links
+    ("serial-spin-n02", 10),      # spinodal quench, finite-difference order parameter, noise in both
+    ("serial-wall-st1", 10),      # fluctuating fluid between walls
+])
+def test_ludwig_fluctuating_runs_with_the_binding(name, ncollide):
+    """isothermal_fluctuations on: the reference's generator states
+    (noise->target->state) are advanced by the library's collision exactly as
+    the original advances them -- otherwise no statistic of these logs would
+    survive ten steps -- and LBMI_REPORT shows that every collision was the
+    library's."""
+    rs = _sweep_tool()
+    env = dict(os.environ, LBMI_REPORT="1")
+    for k in ("LBMI_MODE", "LBMI_FE", "LBMI_HYDRO"):
+        env.pop(k, None)
+    exe = os.path.join(REF, "ludwig_hip_d3q19_shim")
+    with tempfile.TemporaryDirectory() as tmp:
+        rc, out, err, _ = rs.run_one(name, exe, env, tmp, 300)
+    assert rc == 0 and "Ludwig finished normally." in out, (rc, out[-2000:], err[-2000:])
+    calls = {}
+    for line in err.splitlines():
+        w = line.split()
+        if line.startswith("liblbmi report:") and len(w) == 5 and w[3].isdigit():
+            calls[w[2]] = (int(w[3]), int(w[4]))
+    assert calls["lb_collide"] == (ncollide, 0), calls
+    expected = open(os.path.join(SWEEP, name + ".log")).read()
+    bad, worst, first = rs.compare(expected, out, 5e-8)
+    assert bad == 0, (worst, first)
