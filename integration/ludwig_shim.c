@@ -475,12 +475,12 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
    * energy other than the symmetric one; two
    * distributions only with the symmetric free energy (as the reference,
    * collision.c:160) */
-  /* (isothermal fluctuations: the single-fluid D3Q19 collision has them,
-   * lbmi_noise_set; with two distributions, with the stress relaxed, or --
-   * where the reference itself cannot, noise.h:18 -- on D3Q27: the original) */
+  /* (isothermal fluctuations: the D3Q19 collisions have them, lbmi_noise_set;
+   * with one distribution and the stress relaxed, or -- where the reference
+   * itself cannot, noise.h:18 -- on D3Q27: the original) */
   if (!shim_supported(lb) ||
-      (noise->on[NOISE_RHO] && (lb->ndist != 1 || lb->model.nvel != 19 ||
-				(fe && fe->use_stress_relaxation) ||
+      (noise->on[NOISE_RHO] && (lb->model.nvel != 19 ||
+				(lb->ndist == 1 && fe && fe->use_stress_relaxation) ||
 				noise->nsites != lb->nsite)) ||
       (visc != NULL && lb->ndist != 1) ||
       (fe && fe->use_stress_relaxation && fe->id != FE_SYMMETRIC) ||
@@ -538,7 +538,7 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
       unsigned int * state = (unsigned int *)
 	shim_cached(noise, &noise->target->state, sizeof(unsigned int *));
       physics_kt(phys, &kt);
-      if (shim_.mode == LBMI_MODE_FUSED) {
+      if (shim_.mode == LBMI_MODE_FUSED && lb->ndist == 1) {
 	pe_info(lb->pe, "liblbmi: isothermal fluctuations: LBMI_MODE=fused -> halo\n");
 	SHIM_CHECK(lb, lbmi_lb_mode_set(h, LBMI_MODE_FUSED_HALO));
 	shim_.mode = LBMI_MODE_FUSED_HALO;

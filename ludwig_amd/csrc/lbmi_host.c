@@ -1604,8 +1604,8 @@ int lbmi_noise_set(lbmi_t * lb, unsigned int * state, long long nsites,
 
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (state != NULL) {
-    if (lb->opts.nvel != 19 || lb->opts.ndist != 1) {
-      return lbmi_fail(LBMI_ERR_ARGUMENT, "fluctuations: D3Q19, one distribution "
+    if (lb->opts.nvel != 19) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "fluctuations: D3Q19 only "
 		       "(noise.h:18, NNOISE_MAX = 10)");
     }
     if (nsites < (long long) lb->kp.nsite) {
@@ -2440,6 +2440,13 @@ int lbmi_lb_collide_binary(lbmi_t * lb, const lbmi_hydro_t * hydro,
   h.rho = NULL;
   h.status = NULL;
   h.eta = NULL;                    /* fixed rates, collision.c:862-876 */
+  if (lb->noise_state != NULL) {
+    /* lb_collision_fluctuations at every site (collision.c:884-900) */
+    h.noise = lb->noise_state;
+    h.noise_stride = lb->noise_stride;
+    h.noise_kt = lb->noise_kt;
+    h.noise_ghosts = lb->noise_ghosts;
+  }
   HIPCHECK(hipSetDevice(lb->device));
   if (lb->pending_halo && !lb->pending_prop) {
     return lbmi_fail(LBMI_ERR_STATE, "lb_collide after lb_halo without "

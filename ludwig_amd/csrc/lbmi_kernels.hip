@@ -2185,7 +2185,7 @@ void k_phi_from_g(lbmi_kparam_t kp, const double * __restrict__ f2,
  * fused in: populations pulled from src (the post-collision array with its
  * halo), results written to f2 (the other array), as k_propagate_collide
  * does for one distribution. */
-template <int NVEL, int SCHEME, bool PULL>
+template <int NVEL, int SCHEME, bool PULL, bool NZ = false>
 __global__ __launch_bounds__(BLOCK)
 void k_collide_binary(lbmi_kparam_t kp, const double * src, double * f2,
 		      lbmi_hydro_dev_t h, Symm q, double rtau2,
@@ -2233,7 +2233,17 @@ void k_collide_binary(lbmi_kparam_t kp, const double * src, double * f2,
 
   Relax rx = {kp.rtau_shear, kp.rtau_bulk, kp.rtau_even, kp.rtau_odd};
   double rho, u[3];
-  collide_site_impl<NVEL, SCHEME, true>(fl, frc, rx, sth, rho, u);
+  if constexpr (NZ) {
+    /* lb_collision_fluctuations (collision.c:884-900, 1663-1745): every
+     * site draws (no status test in lb_collision_mrt2_site); the variances
+     * are those of the global relaxation times (lb_collision_noise_var_set) */
+    SiteNoise nz;
+    site_noise<SCHEME>(h, i, rx, nz);
+    collide_site_impl<NVEL, SCHEME, true, true>(fl, frc, rx, sth, rho, u, &nz);
+  }
+  else {
+    collide_site_impl<NVEL, SCHEME, true>(fl, frc, rx, sth, rho, u);
+  }
 
   static_for<0, NVEL>([&](auto P) { f2[ns*P + i] = fl[P]; });
   if (h.u) {
@@ -3436,6 +3446,28 @@ static int launch_collide_binary(const lbmi_kparam_t & kp, const double * src,
 				 int wrapmask, hipStream_t st) {
   Range1D r = interior_range(kp);
   dim3 grid(r.grid), block(BLOCK);
+  if (h.noise != nullptr) {
+    if constexpr (NVEL == 19) {
+      switch (kp.scheme) {
+      case LBMI_M10:
+	hipLaunchKernelGGL((k_collide_binary<19, LBMI_M10, PULL, true>), grid, block, 0, st,
+			   kp, src, f2, h, q, rtau2, phi, grad, delsq, wrapmask, r.i0, r.i1, r.nblk);
+	break;
+      case LBMI_BGK:
+	hipLaunchKernelGGL((k_collide_binary<19, LBMI_BGK, PULL, true>), grid, block, 0, st,
+			   kp, src, f2, h, q, rtau2, phi, grad, delsq, wrapmask, r.i0, r.i1, r.nblk);
+	break;
+      case LBMI_TRT:
+	hipLaunchKernelGGL((k_collide_binary<19, LBMI_TRT, PULL, true>), grid, block, 0, st,
+			   kp, src, f2, h, q, rtau2, phi, grad, delsq, wrapmask, r.i0, r.i1, r.nblk);
+	break;
+      default:
+	return (int) hipErrorInvalidValue;
+      }
+      return (int) hipGetLastError();
+    }
+    return (int) hipErrorInvalidValue;
+  }
   switch (kp.scheme) {
   case LBMI_M10:
     hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_M10, PULL>), grid, block, 0, st,

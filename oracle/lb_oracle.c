@@ -318,6 +318,51 @@ static void noise_reap_n(uint32_t * state, ptrdiff_t nsite, ptrdiff_t index,
   }
 }
 
+/* The random stress and ghost-mode parts of one site. mrt2 = 0:
+ * lb_fluctuations_var_eta, _var_bulk, _stress, _var_ghost, _ghosts as
+ * lb_collision_mrt1_site calls them (collision.c:491-516, 1753-1918);
+ * mrt2 = 1: lb_collision_fluctuations of the two-distribution collision
+ * (:1663-1745), the same numbers with the ghost variance written as
+ * sqrt(rna*rcs2*kt). rna[p] = 1/na[p] (model.c:377-379). */
+
+static void site_fluctuations(const lbo_noise_t * noise, const lbo_model_t * model,
+			      int nvel, ptrdiff_t nsite, ptrdiff_t index,
+			      double rtau, double rtau_bulk,
+			      const double * rtau_ghost, int mrt2,
+			      double shat[3][3], double * ghat) {
+  const double rcs2 = 3.0;
+  double random[10];
+  double kt = noise->kt*rcs2;
+  double tr;
+  double tau = 1.0/rtau, tau_b = 1.0/rtau_bulk;
+  double var = sqrt(kt)*sqrt(1.0/9.0)*sqrt((tau + tau - 1.0)/(tau*tau));
+  double var_bulk = sqrt(kt)*sqrt(2.0/9.0)
+    *sqrt((tau_b + tau_b - 1.0)/(tau_b*tau_b));
+
+  noise_reap_n(noise->state, nsite, index, 6, random);
+  shat[X][X] = random[0]; shat[X][Y] = random[1]; shat[X][Z] = random[2];
+  shat[Y][X] = shat[X][Y]; shat[Y][Y] = random[3]; shat[Y][Z] = random[4];
+  shat[Z][X] = shat[X][Z]; shat[Z][Y] = shat[Y][Z]; shat[Z][Z] = random[5];
+  tr = (1.0/3)*(shat[X][X] + shat[Y][Y] + (3 - 2.0)*shat[Z][Z]);
+  shat[X][X] -= tr; shat[Y][Y] -= tr; shat[Z][Z] -= tr;
+  shat[X][X] *= var*sqrt(2.0); shat[X][Y] *= var; shat[X][Z] *= var;
+  shat[Y][X] *= var; shat[Y][Y] *= var*sqrt(2.0); shat[Y][Z] *= var;
+  shat[Z][X] *= var; shat[Z][Y] *= var; shat[Z][Z] *= var*sqrt(2.0);
+  tr *= var_bulk;
+  shat[X][X] += tr; shat[Y][Y] += tr; shat[Z][Z] += tr;
+
+  if (noise->ghosts_on) {
+    noise_reap_n(noise->state, nsite, index, nvel - NHYDRO, random);
+    for (int m = NHYDRO; m < nvel; m++) {
+      double tau_g = 1.0/rtau_ghost[m];
+      double rna = 1.0/model->na[m];
+      double varg = mrt2 ? sqrt(rna*rcs2*noise->kt) : sqrt(kt*rna);
+      varg = varg*sqrt((tau_g + tau_g - 1.0)/(tau_g*tau_g));
+      ghat[m] = varg*random[m - NHYDRO];
+    }
+  }
+}
+
 /* With a viscosity model (visc != NULL in lb_collide): the local shear
  * viscosity comes from hydro->eta and the bulk viscosity keeps the
  * Newtonian ratio, (eta_bulk/eta_shear) eta (collision.c:386-404). */
@@ -462,38 +507,8 @@ static int collide_impl(const lbo_param_t * p, double * f,
 	double ghat[LBO_NVEL_MAX];
 	for (m = 0; m < LBO_NVEL_MAX; m++) ghat[m] = 0.0;
 	if (noise) {
-	  const double rcs2 = 3.0;
-	  double random[10];
-	  double kt = noise->kt*rcs2;
-	  double tr;
-	  /* lb_fluctuations_var_eta, _var_bulk (:1753-1783) */
-	  double tau = 1.0/srtau, tau_b = 1.0/srtau_bulk;
-	  double var = sqrt(kt)*sqrt(1.0/9.0)*sqrt((tau + tau - 1.0)/(tau*tau));
-	  double var_bulk = sqrt(kt)*sqrt(2.0/9.0)
-	    *sqrt((tau_b + tau_b - 1.0)/(tau_b*tau_b));
-	  /* lb_fluctuations_stress (:1826-1887) */
-	  noise_reap_n(noise->state, nsite, index, 6, random);
-	  shat[X][X] = random[0]; shat[X][Y] = random[1]; shat[X][Z] = random[2];
-	  shat[Y][X] = shat[X][Y]; shat[Y][Y] = random[3]; shat[Y][Z] = random[4];
-	  shat[Z][X] = shat[X][Z]; shat[Z][Y] = shat[Y][Z]; shat[Z][Z] = random[5];
-	  tr = (1.0/3)*(shat[X][X] + shat[Y][Y] + (3 - 2.0)*shat[Z][Z]);
-	  shat[X][X] -= tr; shat[Y][Y] -= tr; shat[Z][Z] -= tr;
-	  shat[X][X] *= var*sqrt(2.0); shat[X][Y] *= var; shat[X][Z] *= var;
-	  shat[Y][X] *= var; shat[Y][Y] *= var*sqrt(2.0); shat[Y][Z] *= var;
-	  shat[Z][X] *= var; shat[Z][Y] *= var; shat[Z][Z] *= var*sqrt(2.0);
-	  tr *= var_bulk;
-	  shat[X][X] += tr; shat[Y][Y] += tr; shat[Z][Z] += tr;
-	  if (noise->ghosts_on) {
-	    /* lb_fluctuations_var_ghost, _ghosts (:1800-1918);
-	     * rna[p] = 1/na[p] (model.c:377-379) */
-	    noise_reap_n(noise->state, nsite, index, nvel - NHYDRO, random);
-	    for (m = NHYDRO; m < nvel; m++) {
-	      double tau_g = 1.0/srtau_ghost[m];
-	      double rna = 1.0/model.na[m];
-	      double varg = sqrt(kt*rna)*sqrt((tau_g + tau_g - 1.0)/(tau_g*tau_g));
-	      ghat[m] = varg*random[m - NHYDRO];
-	    }
-	  }
+	  site_fluctuations(noise, &model, nvel, nsite, index, srtau, srtau_bulk,
+			    srtau_ghost, 0, shat, ghat);
 	}
 
 	/* post-collision modes (collision.c:523-544) */
@@ -579,11 +594,41 @@ int lbo_phi_from_g(const lbo_param_t * p, const double * f2, double * phi) {
 static void symm_stress(double a, double b, double kappa, double phi,
 			const double g[3], double delsq, double s[3][3]);
 
+static int collide_binary_impl(const lbo_param_t * p, double * f2,
+			       const double * force, double a, double b, double kappa,
+			       double mobility, const double * phi,
+			       const double * grad, const double * delsq,
+			       const lbo_noise_t * noise, double * u_out);
+
 int lbo_collide_binary(const lbo_param_t * p, double * f2,
 		       const double * force, double a, double b, double kappa,
 		       double mobility, const double * phi,
 		       const double * grad, const double * delsq,
 		       double * u_out) {
+  return collide_binary_impl(p, f2, force, a, b, kappa, mobility, phi, grad,
+			     delsq, NULL, u_out);
+}
+
+/* ... with isothermal fluctuations: lb_collision_fluctuations at every site
+ * (collision.c:884-900; no status test in lb_collision_mrt2_site) */
+
+int lbo_collide_binary_noise(const lbo_param_t * p, double * f2,
+			     const double * force, double a, double b,
+			     double kappa, double mobility, const double * phi,
+			     const double * grad, const double * delsq,
+			     uint32_t * state, double kt, int ghosts_on,
+			     double * u_out) {
+  lbo_noise_t noise = {state, kt, ghosts_on};
+  if (p->nvel != 19) return -1;
+  return collide_binary_impl(p, f2, force, a, b, kappa, mobility, phi, grad,
+			     delsq, &noise, u_out);
+}
+
+static int collide_binary_impl(const lbo_param_t * p, double * f2,
+			       const double * force, double a, double b, double kappa,
+			       double mobility, const double * phi,
+			       const double * grad, const double * delsq,
+			       const lbo_noise_t * noise, double * u_out) {
 
   int nall[3];
   ptrdiff_t str[3];
@@ -665,16 +710,23 @@ int lbo_collide_binary(const lbo_param_t * p, double * f2,
 	    s[ia][ib] += (2.0 - rtau)*(u[ia]*frc[ib] + frc[ia]*u[ib]);
 	  }
 	}
+	double shat[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+	double ghat[LBO_NVEL_MAX];
+	for (m = 0; m < LBO_NVEL_MAX; m++) ghat[m] = 0.0;
+	if (noise) {
+	  site_fluctuations(noise, &model, nvel, nsite, index, rtau, rtau_bulk,
+			    rtau_ghost, 1, shat, ghat);
+	}
 	for (int ia = 0; ia < 3; ia++) mode[1+ia] += frc[ia];
 	m = 0;
 	for (int ia = 0; ia < 3; ia++) {
 	  for (int ib = ia; ib < 3; ib++) {
-	    mode[4 + m] = s[ia][ib];
+	    mode[4 + m] = s[ia][ib] + shat[ia][ib];
 	    m++;
 	  }
 	}
 	for (m = NHYDRO; m < nvel; m++) {
-	  mode[m] = mode[m] - rtau_ghost[m]*(mode[m] - 0.0);
+	  mode[m] = mode[m] - rtau_ghost[m]*(mode[m] - 0.0) + ghat[m];
 	}
 	for (int q = 0; q < nvel; q++) {
 	  double sum = 0.0;

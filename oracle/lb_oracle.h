@@ -84,6 +84,12 @@ int lbo_collide_noise(const lbo_param_t * p, double * f, const double * force,
 		      const char * status, const double * eta,
 		      uint32_t * state, double kt, int ghosts_on,
 		      double * rho_out, double * u_out);
+int lbo_collide_binary_noise(const lbo_param_t * p, double * f2,
+			     const double * force, double a, double b,
+			     double kappa, double mobility, const double * phi,
+			     const double * grad, const double * delsq,
+			     uint32_t * state, double kt, int ghosts_on,
+			     double * u_out);
 int lbo_collide_visc(const lbo_param_t * p, double * f, const double * force,
 		     const char * status, const double * eta,
 		     double * rho_out, double * u_out);

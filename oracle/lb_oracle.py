@@ -305,6 +305,21 @@ def collide_binary(p, f2, force, a, b, kappa, mobility, phi, grad, delsq, u=None
     assert rc == 0
 
 
+def collide_binary_noise(p, f2, force, a, b, kappa, mobility, phi, grad, delsq,
+                         state, kt, ghosts_on=True, u=None):
+    """lb_collision_binary with isothermal fluctuations (every site draws)."""
+    assert f2.shape[0] == 2 * p.nvel
+    assert state.dtype == np.uint32 and state.shape == (4,) + nall(p)
+    fn = lib().lbo_collide_binary_noise
+    fn.argtypes = None
+    c = ctypes.c_double
+    rc = fn(ctypes.byref(p), _ptr(f2), _ptr(force), c(a), c(b), c(kappa), c(mobility),
+            _ptr(phi), _ptr(grad), _ptr(delsq), _ptr(state), c(kt),
+            ctypes.c_int(1 if ghosts_on else 0), _ptr(u))
+    if rc != 0:
+        raise ValueError("lbo_collide_binary_noise: D3Q19 only")
+
+
 def step_binary(p, f2, fp2, a, b, kappa, mobility, force=None, u=None, npt=27):
     """One symmetric_lb step (ludwig.c:558-578, 802-860): phi from g, halo,
     gradients, binary collision, halo and propagation of both distributions.

@@ -185,7 +185,13 @@ def run_relax_case(case, tmp, exe=None, env=None):
             "f_final": load("f_final", (nvel,))}
 
 
-def run_binary_case(case, tmp, exe=None, env=None):
+# the same tuple + kt: the two-distribution step with isothermal fluctuations
+NOISE_BINARY_CASES = [
+    (("noise_bin_q19_a", 19, (6, 5, 4), -0.0625, 0.0625, 0.04, 0.15, 0.1, 0.1, 1e-5, 4), 1e-4),
+]
+
+
+def run_binary_case(case, tmp, exe=None, env=None, kt=None):
     """The two-distribution (symmetric_lb) step: lb_collision_binary with
     27-point gradients, lb_halo and lb_propagation of both distributions.
     Arrays (2*nvel, nall) are n-major: [0:nvel] density, [nvel:] order
@@ -196,7 +202,7 @@ def run_binary_case(case, tmp, exe=None, env=None):
     prefix = os.path.join(tmp, name)
     subprocess.run([exe, "binary", prefix, *map(str, n), repr(a), repr(b),
                     repr(kappa), repr(mob), repr(eta), repr(zeta), repr(fx),
-                    str(nsteps)], check=True, env=env)
+                    str(nsteps)] + ([repr(float(kt))] if kt else []), check=True, env=env)
     meta = json.load(open(prefix + ".json"))
     meta["name"] = name
     nall = tuple(meta["nall"])
@@ -204,10 +210,15 @@ def run_binary_case(case, tmp, exe=None, env=None):
     def load(key, lead):
         return np.fromfile("%s.%s.f64" % (prefix, key), dtype="<f8").reshape(lead + nall)
 
-    return {"meta": np.array(json.dumps(meta)), "f0": load("f0", (2 * nvel,)),
-            "phi": load("phi", ()), "grad": load("grad", (3,)),
-            "delsq": load("delsq", ()), "f_collide": load("f_collide", (2 * nvel,)),
-            "u": load("u", (3,)), "f_final": load("f_final", (2 * nvel,))}
+    out = {"meta": np.array(json.dumps(meta)), "f0": load("f0", (2 * nvel,)),
+           "phi": load("phi", ()), "grad": load("grad", (3,)),
+           "delsq": load("delsq", ()), "f_collide": load("f_collide", (2 * nvel,)),
+           "u": load("u", (3,)), "f_final": load("f_final", (2 * nvel,))}
+    if kt:
+        for key in ("noise0", "noise_final"):
+            a = np.fromfile("%s.%s.i32" % (prefix, key), dtype="<u4")
+            out[key] = a.reshape((4,) + nall)
+    return out
 
 
 # name, nvel, (nx, ny, nz), isboundary, ubot_y, utop_y, solid block, nsteps
@@ -325,6 +336,11 @@ def main():
             print("wrote", fn, os.path.getsize(fn))
         for case in BINARY_CASES:
             out = run_binary_case(case, tmp)
+            fn = os.path.join(GOLD, case[0] + ".npz")
+            np.savez_compressed(fn, **out)
+            print("wrote", fn, os.path.getsize(fn))
+        for case, kt in NOISE_BINARY_CASES:
+            out = run_binary_case(case, tmp, kt=kt)
             fn = os.path.join(GOLD, case[0] + ".npz")
             np.savez_compressed(fn, **out)
             print("wrote", fn, os.path.getsize(fn))

@@ -35,8 +35,9 @@
  *               pth_force_fluid_driver, then phi_cahn_hilliard with advection
  *               of order 1..4 in a prescribed velocity field; nhalo = 2)
  *
- *    ref_driver binary <prefix> nx ny nz a b kappa mobility eta zeta fx nsteps
- *               (two-distribution symmetric_lb step, collision.c:610-1027)
+ *    ref_driver binary <prefix> nx ny nz a b kappa mobility eta zeta fx nsteps [kt]
+ *               (two-distribution symmetric_lb step, collision.c:610-1027;
+ *               kt > 0: with isothermal fluctuations, generator states dumped)
  *    ref_driver relax <prefix> nx ny nz a b kappa mobility eta zeta fx nsteps
  *               (ONE distribution, fe->use_stress_relaxation: collision.c:413)
  *    ref_driver wall <prefix> nx ny nz bx by bz uboty utopy solid nsteps
@@ -111,6 +112,9 @@ static double wtime(void) {
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return ts.tv_sec + 1.0e-9*ts.tv_nsec;
 }
+
+static void dump_i32(const char * prefix, const char * name, const int * a,
+		     size_t n);
 
 static void dump(const char * prefix, const char * name, const double * a,
 		 size_t n) {
@@ -381,6 +385,7 @@ static int run_binary(int argc, char ** argv) {
   double mobility = atof(argv[9]);
   double fzero[3] = {0.0, 0.0, 0.0};
   int nsteps = atoi(argv[13]);
+  double kt = (argc == 15) ? atof(argv[14]) : 0.0;
 
   pe_t * pe = NULL;
   cs_t * cs = NULL;
@@ -451,6 +456,11 @@ static int run_binary(int argc, char ** argv) {
   map_create(pe, cs, 0, &map);
   noise_create(pe, cs, &noise);
   noise_init(noise, 0);
+  if (kt > 0.0) {
+    physics_kt_set(phys, kt);
+    noise_present_set(noise, NOISE_RHO, 1);
+    noise_memcpy(noise, tdpMemcpyHostToDevice);
+  }
 
   init_f(cs, lb, &c);
   init_map(cs, map, &c);
@@ -486,6 +496,10 @@ static int run_binary(int argc, char ** argv) {
     FILE * fp = NULL;
 
     dump(prefix, "f0", lb->f, nf);
+    if (kt > 0.0) {
+      dump_i32(prefix, "noise0", (const int *) noise->state,
+	       (size_t) NNOISE_STATE*noise->nsites);
+    }
     /* device builds (no-ops on the CPU): the state goes over, dumps come back */
     lb_memcpy(lb, tdpMemcpyHostToDevice);
     field_memcpy(phi, tdpMemcpyHostToDevice);
@@ -514,6 +528,11 @@ static int run_binary(int argc, char ** argv) {
     }
     lb_memcpy(lb, tdpMemcpyDeviceToHost);
     dump(prefix, "f_final", lb->f, nf);
+    if (kt > 0.0) {
+      noise_memcpy(noise, tdpMemcpyDeviceToHost);
+      dump_i32(prefix, "noise_final", (const int *) noise->state,
+	       (size_t) NNOISE_STATE*noise->nsites);
+    }
 
     cs_nall(cs, nall);
     snprintf(fn, sizeof(fn), "%s.json", prefix);
@@ -522,11 +541,11 @@ static int run_binary(int argc, char ** argv) {
 	    " \"nhalo\": 1, \"nall\": [%d, %d, %d], \"nsite\": %d,"
 	    " \"a\": %.17g, \"b\": %.17g, \"kappa\": %.17g,"
 	    " \"mobility\": %.17g, \"eta\": %.17g, \"zeta\": %.17g,"
-	    " \"fbody\": [%.17g, 0.0, 0.0], \"nsteps\": %d,"
+	    " \"fbody\": [%.17g, 0.0, 0.0], \"nsteps\": %d, \"kt\": %.17g,"
 	    " \"layout\": \"soa\"}\n",
 	    NVEL, relax ? 1 : 2, c.ntotal[X], c.ntotal[Y], c.ntotal[Z],
 	    nall[X], nall[Y], nall[Z], lb->nsite, param.a, param.b,
-	    param.kappa, mobility, c.eta, c.zeta, c.fbody[X], nsteps);
+	    param.kappa, mobility, c.eta, c.zeta, c.fbody[X], nsteps, kt);
     fclose(fp);
   }
 
@@ -859,7 +878,7 @@ int main(int argc, char ** argv) {
   if ((argc == 13 || argc == 19) && strcmp(argv[1], "wall") == 0) {
     return run_wall(argc, argv);
   }
-  if (argc == 14 && (strcmp(argv[1], "binary") == 0 ||
+  if ((argc == 14 || argc == 15) && (strcmp(argv[1], "binary") == 0 ||
 		     strcmp(argv[1], "relax") == 0)) {
     return run_binary(argc, argv);
   }

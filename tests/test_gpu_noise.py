@@ -140,3 +140,45 @@ def test_what_fluctuations_do_not_cover_is_refused():
         with pytest.raises(ludwig_amd.LbmiError):
             lb.lb_collide(hy)
         lb.free()
+
+
+# --- the two-distribution collision with fluctuations (collision.c:884-900) ---
+
+@pytest.mark.parametrize("mode", [0, 3, 1], ids=["eager", "fused_halo", "fused"])
+def test_binary_steps_with_fluctuations_vs_reference(mode):
+    """free_energy symmetric_lb + isothermal_fluctuations: lb_collision_binary
+    draws at every site (no status test); every execution mode."""
+    import torch
+    import ludwig_amd
+    g = load_golden("noise_bin_q19_a")
+    meta = g["meta"]
+    lb = ludwig_amd.LB(19, tuple(meta["nlocal"]), 1, ndist=2, mode=mode)
+    lb.relaxation_set("m10", meta["eta"], meta["zeta"])
+    lb.body_force_set(meta["fbody"])
+    hy = ludwig_amd.Hydro(lb.nall, lb.device)
+    lb.fe_scheme_set(27, 1)
+    nsite = int(np.prod(lb.nall))
+    state = torch.from_numpy(g["noise0"].reshape(4, nsite).view(np.int32).copy()).to(lb.device)
+    phi = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    grad = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+    delsq = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    torch.cuda.synchronize(lb.device)
+    lb.noise_set(state, meta["kt"], True)
+    lb.lb_memcpy_h2d(g["f0"])
+    for n in range(meta["nsteps"]):
+        lb.phi_to_field(phi)
+        lb.field_halo_n(phi, 1)
+        lb.field_grad(phi, grad, delsq)
+        lb.hydro_field_set(hy.u, (0, 0, 0))
+        lb.lb_collide_binary(hy, meta["a"], meta["b"], meta["kappa"], meta["mobility"],
+                             phi, grad, delsq)
+        if n == 0 and mode == 0:
+            f = lb.lb_memcpy_d2h()
+            assert relmax(interior(f, 1), interior(g["f_collide"], 1)) < RTOL_F
+        lb.lb_halo()
+        lb.lb_propagation()
+    f = lb.lb_memcpy_d2h()
+    assert relmax(interior(f, 1), interior(g["f_final"], 1)) < RTOL_F
+    assert np.array_equal(interior(_state_host(lb, state, lb.nall), 1),
+                          interior(g["noise_final"], 1))
+    lb.free()

@@ -96,3 +96,38 @@ def test_d3q27_is_refused():
     state = np.ones((4,) + f.shape[1:], dtype=np.uint32)
     with pytest.raises(ValueError):
         lbo.collide_noise(p, f, None, None, state, 1e-4)
+
+
+# --- the two-distribution collision with fluctuations (collision.c:884-900) ---
+
+def test_binary_collision_and_steps_with_fluctuations():
+    g = load_golden("noise_bin_q19_a")
+    meta = g["meta"]
+    assert meta["kt"] > 0.0 and meta["ndist"] == 2
+    p = lbo.make_param(19, meta["nlocal"], 1, "m10", meta["eta"], meta["zeta"], 1.0, meta["fbody"])
+    nv = 19
+    f2 = np.ascontiguousarray(g["f0"]).copy()
+    u = np.zeros((3,) + f2.shape[1:])
+    state = g["noise0"].copy()
+    lbo.collide_binary_noise(p, f2, None, meta["a"], meta["b"], meta["kappa"], meta["mobility"],
+                             np.ascontiguousarray(g["phi"]), np.ascontiguousarray(g["grad"]),
+                             np.ascontiguousarray(g["delsq"]), state, meta["kt"], True, u)
+    assert relmax(interior(f2[:nv], 1), interior(g["f_collide"][:nv], 1)) < TOL
+    assert relmax(interior(f2[nv:], 1), interior(g["f_collide"][nv:], 1)) < TOL
+    assert relmax(interior(u, 1), interior(g["u"], 1)) < TOL
+    # whole steps; the generator states bit for bit (two draws per site and step)
+    f2 = np.ascontiguousarray(g["f0"]).copy()
+    fp2 = np.zeros_like(f2)
+    state = g["noise0"].copy()
+    for _ in range(meta["nsteps"]):
+        phi = lbo.phi_from_g(p, f2)
+        lbo.field_halo(p, phi, 1)
+        gr, d2 = lbo.grad(p, phi, 27)
+        lbo.collide_binary_noise(p, f2, None, meta["a"], meta["b"], meta["kappa"],
+                                 meta["mobility"], phi, gr, d2, state, meta["kt"], True)
+        lbo.halo(p, f2)
+        lbo.propagate(p, f2[:nv], fp2[:nv])
+        lbo.propagate(p, f2[nv:], fp2[nv:])
+        f2, fp2 = fp2, f2
+    assert relmax(interior(f2, 1), interior(g["f_final"], 1)) < 1e-13
+    assert np.array_equal(interior(state, 1), interior(g["noise_final"], 1))
