@@ -96,6 +96,22 @@ def test_steps_and_generator_states_vs_reference(name, mode):
     lb.free()
 
 
+def test_the_c_loop_of_the_library_with_fluctuations():
+    """lbmi_lb_run (the three calls of every step issued from C): the same
+    states and distributions as the calls one by one."""
+    import ludwig_amd
+    g = load_golden("noise_q19_trt_solid")
+    meta = g["meta"]
+    h = meta["nhalo"]
+    lb, hy, state, st = _setup(g, ludwig_amd.FUSED_HALO)
+    lb.run(hy, meta["nsteps"])
+    f = lb.lb_memcpy_d2h()
+    assert relmax(interior(f, h), interior(g["f_final"], h)) < RTOL_F
+    assert np.array_equal(interior(_state_host(lb, state, lb.nall), h),
+                          interior(g["noise_final"], h))
+    lb.free()
+
+
 def test_switching_off_and_on_again():
     """lbmi_noise_set(NULL): the plain collision again, generator untouched."""
     import ludwig_amd
