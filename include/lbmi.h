@@ -154,6 +154,14 @@ typedef struct lbmi_hydro_s {
 			       with visc != NULL, collision.c:386-404; the
 			       bulk viscosity keeps the ratio of
 			       lbmi_set_relaxation); NULL = constant         */
+  long long      nsite;     /* hydro->nsite: the distance between the
+			       components of force and of u, in doubles;
+			       0 = the lattice's own nsite. (With Lees-
+			       Edwards planes the reference's hydro arrays
+			       carry buffer planes, lees_edw_nsites, and the
+			       distributions do not: hydro.c:75-88,
+			       model.c:295.) Honoured by lbmi_lb_collide,
+			       its lazy rho/u and lbmi_lb_collide_binary.    */
 } lbmi_hydro_t;
 
 /* ---- life cycle: lb_data_create / lb_free (model.c:56-213) -------------- */

@@ -485,10 +485,13 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
       (visc != NULL && lb->ndist != 1) ||
       (fe && fe->use_stress_relaxation && fe->id != FE_SYMMETRIC) ||
       (lb->ndist == 2 && (fe == NULL || fe->id != FE_SYMMETRIC)) ||
-      hydro->nsite != lb->nsite) {
-    /* (the last: with Lees-Edwards planes the hydro arrays carry buffer
-     * planes, lees_edw_nsites: their components are hydro->nsite apart, the
-     * distributions lb->nsite) */
+      (hydro->nsite != lb->nsite &&
+       (lb->ndist == 2 || (fe && fe->use_stress_relaxation)))) {
+    /* (the last: with Lees-Edwards planes the hydro arrays and every field
+     * carry buffer planes, lees_edw_nsites: their components are
+     * hydro->nsite apart, the distributions' lb->nsite. lbmi_hydro_t::nsite
+     * tells the single-fluid collision; the collisions that also read
+     * phi, grad phi take the lattice's stride for those) */
     if (shim_.h && shim_.lb == lb) {
       SHIM_CHECK(lb, lbmi_lb_flush(shim_.h));
       shim_sync_pointers(lb, shim_.h);
@@ -559,6 +562,7 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
     /* a viscosity model has left the local viscosity in hydro->eta
      * (collision.c:386-404, 1947) */
     hy.eta    = visc ? shim_field_data(hydro->eta) : NULL;
+    hy.nsite  = hydro->nsite;                    /* component stride of force, u */
 
     /* hydro_f_zero below tells the library that hydro->force holds zeros,
      * and a force field of zeros is not read. That holds until somebody

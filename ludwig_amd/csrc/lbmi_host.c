@@ -569,8 +569,9 @@ int lbmi_relaxation_rates(const lbmi_t * lb, double rtau[4]) {
  *****************************************************************************/
 
 static lbmi_hydro_dev_t lbmi_hydro_dev(const lbmi_hydro_t * hydro) {
-  lbmi_hydro_dev_t h = {NULL, NULL, NULL, NULL, NULL, NULL, 0, 0.0, 0};
+  lbmi_hydro_dev_t h = {NULL, NULL, NULL, NULL, NULL, 0, NULL, 0, 0.0, 0};
   if (hydro) {
+    h.stride = hydro->nsite;
     h.force = hydro->force;
     h.status = hydro->status;
     h.rho = hydro->rho;

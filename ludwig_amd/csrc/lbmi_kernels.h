@@ -52,6 +52,7 @@ typedef struct lbmi_hydro_dev_s {
   /* isothermal fluctuations: the reference's generator state (noise->state,
    * 4 unsigned ints per site, component ia of site i at [ia*stride + i]),
    * or NULL = off */
+  long long      stride;    /* components of force and u: 0 = kp.nsite */
   unsigned int * noise;
   long long      noise_stride;
   double         noise_kt;

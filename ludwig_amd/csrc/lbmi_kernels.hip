@@ -458,6 +458,16 @@ void collide_site_impl(double (&f)[NVEL], const double (&frc)[3],
   });
 }
 
+/* Component stride of the hydro arrays force and u (hydro->nsite): the
+ * lattice's own nsite unless the caller says otherwise -- with Lees-Edwards
+ * planes the reference allocates them with buffer planes (lees_edw_nsites,
+ * hydro.c:75-88), the distributions without (model.c:295). */
+
+__device__ __forceinline__
+size_t hstride(const lbmi_kparam_t & kp, const lbmi_hydro_dev_t & h) {
+  return (h.stride > 0) ? (size_t) h.stride : (size_t) kp.nsite;
+}
+
 /* Relaxation rates of a site: the constants of lbmi_set_relaxation, or,
  * with a viscosity model, those of the local shear viscosity hydro->eta
  * (collision.c:386-404 with lb_relaxation_time_shear_v, _bulk_v, _ghosts_v,
@@ -650,8 +660,8 @@ void k_collide(lbmi_kparam_t kp, double * __restrict__ f,
   double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
   if (h.force) {
     frc[0] += h.force[i];
-    frc[1] += h.force[ns + i];
-    frc[2] += h.force[2*ns + i];
+    frc[1] += h.force[hstride(kp, h) + i];
+    frc[2] += h.force[2*hstride(kp, h) + i];
   }
 
   Relax rx = site_relax<SCHEME>(kp, h, i);
@@ -662,8 +672,8 @@ void k_collide(lbmi_kparam_t kp, double * __restrict__ f,
   if (h.rho) h.rho[i] = rho;
   if (h.u) {
     h.u[i] = u[0];
-    h.u[ns + i] = u[1];
-    h.u[2*ns + i] = u[2];
+    h.u[hstride(kp, h) + i] = u[1];
+    h.u[2*hstride(kp, h) + i] = u[2];
   }
 }
 
@@ -696,8 +706,8 @@ void k_collide_fe(lbmi_kparam_t kp, double * __restrict__ f,
   double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
   if (h.force) {
     frc[0] += h.force[i];
-    frc[1] += h.force[ns + i];
-    frc[2] += h.force[2*ns + i];
+    frc[1] += h.force[hstride(kp, h) + i];
+    frc[2] += h.force[2*hstride(kp, h) + i];
   }
 
   Relax rx = site_relax<SCHEME>(kp, h, i);
@@ -720,8 +730,8 @@ void k_collide_fe(lbmi_kparam_t kp, double * __restrict__ f,
   if (h.rho) h.rho[i] = rho;
   if (h.u) {
     h.u[i] = u[0];
-    h.u[ns + i] = u[1];
-    h.u[2*ns + i] = u[2];
+    h.u[hstride(kp, h) + i] = u[1];
+    h.u[2*hstride(kp, h) + i] = u[2];
   }
 }
 
@@ -905,8 +915,8 @@ void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
     if constexpr (HIO) {
       if (h.force) {
 	frc[0] += h.force[i];
-	frc[1] += h.force[ns + i];
-	frc[2] += h.force[2*ns + i];
+	frc[1] += h.force[hstride(kp, h) + i];
+	frc[2] += h.force[2*hstride(kp, h) + i];
       }
     }
     Relax rx = site_relax<SCHEME>(kp, h, i);
@@ -920,16 +930,16 @@ void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
       if (h.rho) __builtin_nontemporal_store(rho, &h.rho[i]);
       if (h.u) {
 	__builtin_nontemporal_store(u[0], &h.u[i]);
-	__builtin_nontemporal_store(u[1], &h.u[ns + i]);
-	__builtin_nontemporal_store(u[2], &h.u[2*ns + i]);
+	__builtin_nontemporal_store(u[1], &h.u[hstride(kp, h) + i]);
+	__builtin_nontemporal_store(u[2], &h.u[2*hstride(kp, h) + i]);
       }
     }
     else {
       if (h.rho) h.rho[i] = rho;
       if (h.u) {
 	h.u[i] = u[0];
-	h.u[ns + i] = u[1];
-	h.u[2*ns + i] = u[2];
+	h.u[hstride(kp, h) + i] = u[1];
+	h.u[2*hstride(kp, h) + i] = u[2];
       }
     }
   }
@@ -1081,15 +1091,15 @@ void k_hydro_from_f(lbmi_kparam_t kp, const double * __restrict__ f,
   double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
   if (h.force) {
     frc[0] += h.force[i];
-    frc[1] += h.force[ns + i];
-    frc[2] += h.force[2*ns + i];
+    frc[1] += h.force[hstride(kp, h) + i];
+    frc[2] += h.force[2*hstride(kp, h) + i];
   }
   const double rrho = 1.0/rho;
   if (h.rho) h.rho[i] = rho;
   if (h.u) {
     h.u[i] = rrho*(g[0] - 0.5*frc[0]);
-    h.u[ns + i] = rrho*(g[1] - 0.5*frc[1]);
-    h.u[2*ns + i] = rrho*(g[2] - 0.5*frc[2]);
+    h.u[hstride(kp, h) + i] = rrho*(g[1] - 0.5*frc[1]);
+    h.u[2*hstride(kp, h) + i] = rrho*(g[2] - 0.5*frc[2]);
   }
 }
 
@@ -1148,8 +1158,8 @@ void site_collide_hydro(const lbmi_kparam_t & kp, const lbmi_hydro_dev_t & h,
   double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
   if (h.force) {
     frc[0] += h.force[i];
-    frc[1] += h.force[ns + i];
-    frc[2] += h.force[2*ns + i];
+    frc[1] += h.force[hstride(kp, h) + i];
+    frc[2] += h.force[2*hstride(kp, h) + i];
   }
   Relax rx = site_relax<SCHEME>(kp, h, i);
   double rho, u[3];
@@ -1157,8 +1167,8 @@ void site_collide_hydro(const lbmi_kparam_t & kp, const lbmi_hydro_dev_t & h,
   if (h.rho) h.rho[i] = rho;
   if (h.u) {
     h.u[i] = u[0];
-    h.u[ns + i] = u[1];
-    h.u[2*ns + i] = u[2];
+    h.u[hstride(kp, h) + i] = u[1];
+    h.u[2*hstride(kp, h) + i] = u[2];
   }
 }
 
@@ -2219,8 +2229,8 @@ void k_collide_binary(lbmi_kparam_t kp, const double * src, double * f2,
   double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
   if (h.force) {
     frc[0] += h.force[i];
-    frc[1] += h.force[ns + i];
-    frc[2] += h.force[2*ns + i];
+    frc[1] += h.force[hstride(kp, h) + i];
+    frc[2] += h.force[2*hstride(kp, h) + i];
   }
 
   const double ph = phi[i];
@@ -2248,8 +2258,8 @@ void k_collide_binary(lbmi_kparam_t kp, const double * src, double * f2,
   static_for<0, NVEL>([&](auto P) { f2[ns*P + i] = fl[P]; });
   if (h.u) {
     h.u[i] = u[0];
-    h.u[ns + i] = u[1];
-    h.u[2*ns + i] = u[2];
+    h.u[hstride(kp, h) + i] = u[1];
+    h.u[2*hstride(kp, h) + i] = u[2];
   }
 
   /* order-parameter distribution, collision.c:955-1024 */

@@ -80,6 +80,10 @@ class Hydro:
         h.rho = _ptr(self.rho)
         h.u = _ptr(self.u)
         h.eta = _ptr(self.eta)
+        # lbmi_hydro_t::nsite: the distance between the components of force
+        # and u when it is not the lattice's nsite (attribute `stride`, set by
+        # a caller who has allocated them that way; 0 = the lattice's)
+        h.nsite = int(getattr(self, "stride", 0) or 0)
         return h
 
 

@@ -36,6 +36,7 @@ class HydroPtrs(ctypes.Structure):
         ("rho", ctypes.c_void_p),
         ("u", ctypes.c_void_p),
         ("eta", ctypes.c_void_p),
+        ("nsite", ctypes.c_longlong),
     ]
 
 

@@ -229,3 +229,53 @@ def test_reference_step_order_with_u_zero_and_f_zero_every_step():
                   interior(u_ref, 1)[:, fl[1:-1, 1:-1, 1:-1]]) < 1e-12
     assert np.all(u[:, ~fl] == 0.0)
     lb.free()
+
+
+@pytest.mark.parametrize("lazy", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3], ids=["eager", "fused", "inplace", "fused_halo"])
+@pytest.mark.parametrize("nvel", [19, 27])
+def test_hydro_arrays_with_their_own_component_stride(nvel, mode, lazy):
+    """lbmi_hydro_t::nsite: force and u whose components lie further apart
+    than the lattice's nsite (with Lees-Edwards planes the reference allocates
+    the hydro arrays with buffer planes, hydro.c:75-88). Same results as with
+    the plain arrays; the padding between the components is never touched."""
+    import ludwig_amd
+    import torch
+    nsteps = 3
+    nall = tuple(n + 2 for n in NLOCAL)
+    nsite = int(np.prod(nall))
+    stride = nsite + 4 * nall[1] * nall[2] + 3          # buffer planes and an odd tail
+    force = _force_field(nall)
+    status = _status(nall)
+    p, f_o, rho_o, u_o = _oracle_run(nvel, nsteps, force, status)
+
+    lb = ludwig_amd.LB(nvel, NLOCAL, 1, mode=mode)
+    lb.relaxation_set("m10", 0.1, 0.3)
+    lb.body_force_set(FBODY)
+    hy = ludwig_amd.Hydro(nall, lb.device, status=status)
+    marker = -7.25
+    fpad = np.full((3, stride), marker)
+    fpad[:, :nsite] = force.reshape(3, nsite)
+    hy.force = torch.from_numpy(fpad).to(lb.device)
+    hy.u = torch.full((3, stride), marker, dtype=torch.float64, device=lb.device)
+    hy.stride = stride
+    torch.cuda.synchronize(lb.device)
+    if lazy and mode in (1, 3):
+        lb.tune("hydro_lazy", 1)
+    lb.lb_memcpy_h2d(lbo.init_synthetic(p))
+    for _ in range(nsteps):
+        lb.lb_collide(hy)
+        lb.lb_halo()
+        lb.lb_propagation()
+    lb.hydro_sync()
+    f = lb.lb_memcpy_d2h()
+    lb.synchronize()
+    assert relmax(interior(f, 1), interior(f_o, 1)) < 1e-12
+    fl = _fluid(status, nall)
+    u = hy.u.cpu().numpy()
+    ug = u[:, :nsite].reshape((3,) + nall)
+    assert relmax(interior(ug, 1)[:, fl], interior(u_o, 1)[:, fl]) < 1e-12
+    assert relmax(interior(hy.rho.cpu().numpy(), 1)[fl], interior(rho_o, 1)[fl]) < 1e-12
+    # nothing between the components has been written, nor read as a force
+    assert np.all(u[:, nsite:] == marker)
+    lb.free()
