@@ -389,6 +389,12 @@ typedef struct lbmi_fe_symm_s {
   const double * phi;        /* device, nsite */
   const double * grad;       /* device, 3*nsite */
   const double * delsq;      /* device, nsite */
+  long long nsite;           /* distance between the components of grad, in
+				doubles (field_grad_t of a field with Lees-
+				Edwards buffer planes); 0 = the lattice's
+				nsite. Honoured by lbmi_lb_collide_fe and
+				lbmi_lb_collide_binary. Zero-initialise the
+				struct: members may be added at its end.     */
 } lbmi_fe_symm_t;
 int lbmi_lb_phi_to_field(lbmi_t * lb, double * phi);
 /* lb_collide with fe->use_stress_relaxation (collision.c:413-429; force

@@ -484,14 +484,11 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
 				noise->nsites != lb->nsite)) ||
       (visc != NULL && lb->ndist != 1) ||
       (fe && fe->use_stress_relaxation && fe->id != FE_SYMMETRIC) ||
-      (lb->ndist == 2 && (fe == NULL || fe->id != FE_SYMMETRIC)) ||
-      (hydro->nsite != lb->nsite &&
-       (lb->ndist == 2 || (fe && fe->use_stress_relaxation)))) {
-    /* (the last: with Lees-Edwards planes the hydro arrays and every field
-     * carry buffer planes, lees_edw_nsites: their components are
-     * hydro->nsite apart, the distributions' lb->nsite. lbmi_hydro_t::nsite
-     * tells the single-fluid collision; the collisions that also read
-     * phi, grad phi take the lattice's stride for those) */
+      (lb->ndist == 2 && (fe == NULL || fe->id != FE_SYMMETRIC))) {
+    /* (with Lees-Edwards planes the hydro arrays and every field carry
+     * buffer planes, lees_edw_nsites: their components are hydro->nsite
+     * apart, the distributions' lb->nsite: lbmi_hydro_t::nsite and
+     * lbmi_fe_symm_t::nsite below say so) */
     if (shim_.h && shim_.lb == lb) {
       SHIM_CHECK(lb, lbmi_lb_flush(shim_.h));
       shim_sync_pointers(lb, shim_.h);
@@ -608,6 +605,7 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
       bin.b = param.b;
       bin.kappa = param.kappa;
       physics_mobility(phys, &bin.mobility);
+      bin.nsite = fs->phi->nsites;                /* component stride of grad phi */
       bin.phi = shim_field_data(fs->phi);
       shim_grad_arrays(fs->dphi, (double **) &bin.grad, (double **) &bin.delsq);
       if (lb->ndist == 2) {

@@ -569,7 +569,7 @@ int lbmi_relaxation_rates(const lbmi_t * lb, double rtau[4]) {
  *****************************************************************************/
 
 static lbmi_hydro_dev_t lbmi_hydro_dev(const lbmi_hydro_t * hydro) {
-  lbmi_hydro_dev_t h = {NULL, NULL, NULL, NULL, NULL, 0, NULL, 0, 0.0, 0};
+  lbmi_hydro_dev_t h = {NULL, NULL, NULL, NULL, NULL, 0, 0, NULL, 0, 0.0, 0};
   if (hydro) {
     h.stride = hydro->nsite;
     h.force = hydro->force;
@@ -2390,6 +2390,7 @@ int lbmi_lb_collide_fe(lbmi_t * lb, const lbmi_hydro_t * hydro,
   lbmi_hydro_dev_t h = lbmi_hydro_dev(hydro);
   int ifail;
   if (lb == NULL || fe == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  h.gstride = fe->nsite;
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   if (lb->opts.ndist != 1) return lbmi_fail(LBMI_ERR_STATE, "needs ndist = 1");
   if (lb->noise_state != NULL) {
@@ -2429,6 +2430,7 @@ int lbmi_lb_collide_binary(lbmi_t * lb, const lbmi_hydro_t * hydro,
 			   const lbmi_fe_symm_t * fe) {
   lbmi_hydro_dev_t h = lbmi_hydro_dev(hydro);
   if (lb == NULL || fe == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  h.gstride = fe->nsite;
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   if (lb->opts.ndist != 2) return lbmi_fail(LBMI_ERR_STATE, "needs ndist = 2");
   if (!fe->phi || !fe->grad || !fe->delsq) {

@@ -53,6 +53,8 @@ typedef struct lbmi_hydro_dev_s {
    * 4 unsigned ints per site, component ia of site i at [ia*stride + i]),
    * or NULL = off */
   long long      stride;    /* components of force and u: 0 = kp.nsite */
+  long long      gstride;   /* components of grad phi (collisions that read
+			       it): 0 = kp.nsite */
   unsigned int * noise;
   long long      noise_stride;
   double         noise_kt;

@@ -716,7 +716,8 @@ void k_collide_fe(lbmi_kparam_t kp, double * __restrict__ f,
   {
     /* P_ab = p0 delta_ab + kappa d_a phi d_b phi (symmetric.c:371-420) */
     const double ph = phi[i], d2 = delsq[i];
-    const double g0 = grad[i], g1 = grad[ns + i], g2 = grad[2*ns + i];
+    const size_t gs = (h.gstride > 0) ? (size_t) h.gstride : ns;
+    const double g0 = grad[i], g1 = grad[gs + i], g2 = grad[2*gs + i];
     const double p0 = 0.5*qa*ph*ph + 0.75*qb*ph*ph*ph*ph - qkappa*ph*d2
       - 0.5*qkappa*(g0*g0 + g1*g1 + g2*g2);
     sth[0] = p0 + qkappa*g0*g0; sth[1] = qkappa*g0*g1; sth[2] = qkappa*g0*g2;
@@ -2235,7 +2236,8 @@ void k_collide_binary(lbmi_kparam_t kp, const double * src, double * f2,
 
   const double ph = phi[i];
   const double d2 = delsq[i];
-  const double gr[3] = {grad[i], grad[ns + i], grad[2*ns + i]};
+  const size_t gs = (h.gstride > 0) ? (size_t) h.gstride : ns;
+  const double gr[3] = {grad[i], grad[gs + i], grad[2*gs + i]};
   double pth[3][3];
   symm_stress(q, ph, gr, d2, pth);
   const double sth[6] = {pth[0][0], pth[0][1], pth[0][2],

@@ -512,11 +512,15 @@ class LB:
         """phi_lb_to_field (ndist = 2): phi = sum_p g_p."""
         _l.check(self._lib.lbmi_lb_phi_to_field(self._h, _ptr(phi)))
 
-    def lb_collide_binary(self, hydro, a, b, kappa, mobility, phi, grad, delsq):
-        """lb_collide with ndist = 2 (lb_collision_binary)."""
+    def lb_collide_binary(self, hydro, a, b, kappa, mobility, phi, grad, delsq,
+                          grad_stride=0):
+        """lb_collide with ndist = 2 (lb_collision_binary). grad_stride:
+        lbmi_fe_symm_t::nsite, the distance between the components of grad
+        when it is not the lattice's nsite."""
         fe = _l.FeSymm()
         fe.a, fe.b, fe.kappa, fe.mobility = a, b, kappa, mobility
         fe.phi, fe.grad, fe.delsq = _ptr(phi), _ptr(grad), _ptr(delsq)
+        fe.nsite = int(grad_stride)
         if hydro is None:
             _l.check(self._lib.lbmi_lb_collide_binary(self._h, None,
                                                       ctypes.byref(fe)))
@@ -525,11 +529,12 @@ class LB:
             _l.check(self._lib.lbmi_lb_collide_binary(self._h, ctypes.byref(h),
                                                       ctypes.byref(fe)))
 
-    def lb_collide_fe(self, hydro, a, b, kappa, phi, grad, delsq):
+    def lb_collide_fe(self, hydro, a, b, kappa, phi, grad, delsq, grad_stride=0):
         """lb_collide with fe->use_stress_relaxation (symmetric free energy)."""
         fe = _l.FeSymm()
         fe.a, fe.b, fe.kappa, fe.mobility = a, b, kappa, 0.0
         fe.phi, fe.grad, fe.delsq = _ptr(phi), _ptr(grad), _ptr(delsq)
+        fe.nsite = int(grad_stride)
         h = hydro.ptrs()
         _l.check(self._lib.lbmi_lb_collide_fe(self._h, ctypes.byref(h),
                                               ctypes.byref(fe)))

@@ -61,6 +61,7 @@ class FeSymm(ctypes.Structure):
         ("phi", ctypes.c_void_p),
         ("grad", ctypes.c_void_p),
         ("delsq", ctypes.c_void_p),
+        ("nsite", ctypes.c_longlong),
     ]
 
 

@@ -308,3 +308,46 @@ def test_binary_fused_halo_is_eager_at_every_observation():
     assert len(obs[0]) == len(obs[1])
     for a, b in zip(obs[0], obs[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("which", ["binary", "relax"])
+def test_collisions_with_strided_gradient_and_hydro_arrays(which):
+    """lbmi_fe_symm_t::nsite and lbmi_hydro_t::nsite: grad phi, force and u
+    whose components lie further apart than the lattice's nsite (fields with
+    Lees-Edwards buffer planes, field.c / hydro.c): the reference's results,
+    the padding untouched."""
+    import ludwig_amd
+    import torch
+    from tests.common import golden_relax_names
+    name = "bin_q19_a" if which == "binary" else golden_relax_names()[0]
+    g = load_golden(name)
+    meta = g["meta"]
+    nv = meta["nvel"]
+    lb = _lb(meta) if which == "binary" else None
+    if lb is None:
+        lb = ludwig_amd.LB(nv, tuple(meta["nlocal"]), 1)
+        lb.relaxation_set("m10", meta["eta"], meta["zeta"])
+        lb.body_force_set(meta["fbody"])
+    nsite = int(np.prod(lb.nall))
+    stride = nsite + 3 * lb.nall[1] * lb.nall[2] + 5
+    marker = -3.5
+    hy = ludwig_amd.Hydro(lb.nall, lb.device)
+    hy.u = torch.full((3, stride), marker, dtype=torch.float64, device=lb.device)
+    hy.stride = stride
+    gpad = np.full((3, stride), 1e30)                  # poison between the components
+    gpad[:, :nsite] = g["grad"].reshape(3, nsite)
+    grad = torch.from_numpy(gpad).to(lb.device)
+    torch.cuda.synchronize(lb.device)
+    lb.lb_memcpy_h2d(g["f0"])
+    if which == "binary":
+        lb.lb_collide_binary(hy, meta["a"], meta["b"], meta["kappa"], meta["mobility"],
+                             _dev(lb, g["phi"]), grad, _dev(lb, g["delsq"]), grad_stride=stride)
+    else:
+        lb.lb_collide_fe(hy, meta["a"], meta["b"], meta["kappa"], _dev(lb, g["phi"]), grad,
+                         _dev(lb, g["delsq"]), grad_stride=stride)
+    f = lb.lb_memcpy_d2h()
+    assert relmax(interior(f, 1), interior(g["f_collide"], 1)) < 1e-12
+    u = _host(lb, hy.u)
+    assert relmax(interior(u[:, :nsite].reshape((3,) + lb.nall), 1), interior(g["u"], 1)) < 1e-12
+    assert np.all(u[:, nsite:] == marker)
+    lb.free()
