@@ -244,3 +244,57 @@ def test_d3q27_config5_slab_conserves_and_modes_agree():
         mo.append(m1)
         lb.free()
     assert np.max(np.abs(mo[0] - mo[1])) < 1e-13 * mo[1][1]
+
+
+@pytest.mark.parametrize("mode", ["eager", "fused_halo"])
+def test_fluctuations_256(mode):
+    """Isothermal fluctuations at 256^3. Size-independent properties: the
+    generator of a site depends on nothing but its own state, so after n steps
+    every interior state is noise_uniform applied 2n times to where it started
+    (replayed here with numpy on all 16.8 M sites, bit for bit; halo sites
+    untouched); the random stress and ghost parts carry neither mass nor
+    momentum; and the two execution modes agree."""
+    import torch
+    import ludwig_amd
+    nsteps = 3
+    m = {"eager": ludwig_amd.EAGER, "fused_halo": ludwig_amd.FUSED_HALO}[mode]
+    lb = _setup(m)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device)
+    nsite = int(np.prod(lb.nall))
+    rng = np.random.default_rng(20261004)
+    s0 = rng.integers(1, 2**32 - 1, size=(4, nsite), dtype=np.uint32)
+    state = torch.from_numpy(s0.view(np.int32).copy()).to(lb.device)
+    torch.cuda.synchronize(lb.device)
+    lb.noise_set(state, 1.0e-5, True)
+    mo0 = lb.moments()
+    for _ in range(nsteps):
+        lb.lb_collide(hy)
+        lb.lb_halo()
+        lb.lb_propagation()
+    mo1 = lb.moments()
+    # mass exactly conserved to rounding, momentum unchanged (no force)
+    assert abs(mo1[1] - mo0[1]) < 1e-12 * mo0[1]
+    scale = mo0[1]
+    for a in (5, 6, 7):
+        assert abs(mo1[a] - mo0[a]) < 1e-12 * scale
+    lb.synchronize()
+    s1 = state.cpu().numpy().view(np.uint32).reshape((4,) + tuple(lb.nall))
+
+    def uniform(st):                     # noise.c:467-487 on whole arrays
+        st[0] = st[0] * np.uint32(69069) + np.uint32(1234567)
+        b = st[1] ^ (st[1] << np.uint32(17))
+        b ^= b >> np.uint32(13)
+        st[1] = b ^ (b << np.uint32(5))
+        st[2] = np.uint32(36969) * (st[2] & np.uint32(0xffff)) + (st[2] >> np.uint32(16))
+        st[3] = np.uint32(18000) * (st[3] & np.uint32(0xffff)) + (st[3] >> np.uint32(16))
+
+    ref = s0.reshape((4,) + tuple(lb.nall)).copy()
+    inner = [ref[k][1:-1, 1:-1, 1:-1].copy() for k in range(4)]
+    with np.errstate(over="ignore"):
+        for _ in range(2 * nsteps):
+            uniform(inner)
+    for k in range(4):
+        assert np.array_equal(s1[k][1:-1, 1:-1, 1:-1], inner[k])
+        ref[k][1:-1, 1:-1, 1:-1] = inner[k]
+        assert np.array_equal(s1[k], ref[k])           # halo sites never draw
+    lb.free()
