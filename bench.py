@@ -110,6 +110,9 @@ def parse():
                     help="1 GPU only: route the X halo through a 1-rank RCCL "
                     "ring (exercises the N>1 step path: pack, send/recv, "
                     "unpack, interior/boundary split)")
+    ap.add_argument("--noise", type=float, default=0.0,
+                    help="kT > 0: isothermal fluctuations (lbmi_noise_set; D3Q19, "
+                    "--mode eager or fused_halo): +32 B/site of generator state per step")
     ap.add_argument("--tune", default="", help="key=value,... (lbmi_tune)")
     ap.add_argument("--timing-period", type=int, default=0,
                     help="HIP-event timing of every k-th kernel launch inside "
@@ -348,6 +351,16 @@ def main():
         lb.comm_init(ids[0])
     elif args.selfring:
         lb.comm_init(ludwig_amd.LB.comm_unique_id())
+
+    noise_state = None
+    if args.noise > 0.0:
+        g = torch.Generator(device=lb.device)
+        g.manual_seed(4321 + rank)
+        nsite = lb.nall[0] * lb.nall[1] * lb.nall[2]
+        noise_state = torch.randint(1, 2**31 - 1, (4, nsite), dtype=torch.int32,
+                                    device=lb.device, generator=g)
+        torch.cuda.synchronize()
+        lb.noise_set(noise_state, args.noise, True)
 
     m = ludwig_amd.lb.model(args.nvel)
     synthetic.fill_device(lb, m["cv"], m["wv"], ntotal,
