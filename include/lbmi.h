@@ -460,8 +460,8 @@ int lbmi_lb_hydro_sync(lbmi_t * lb);
  * site i at state[ia*nsites + i] (noise.c:330-366 with ADDR_SOA), read and
  * advanced by every collision. state = NULL: off (the default).
  * D3Q19 only -- the reference's NNOISE_MAX = 10 cannot serve the 17 ghost
- * modes of D3Q27 (noise.h:18). lbmi_lb_collide: in LBMI_MODE_EAGER or
- * LBMI_MODE_FUSED_HALO, LBMI_ERR_STATE otherwise; lbmi_lb_collide_binary
+ * modes of D3Q27 (noise.h:18). lbmi_lb_collide: every mode but
+ * LBMI_MODE_INPLACE (LBMI_ERR_STATE); lbmi_lb_collide_binary
  * (lb_collision_fluctuations, collision.c:884-900, 1663-1745: every site
  * draws, no status test): every mode; lbmi_lb_collide_fe: LBMI_ERR_STATE. */
 int lbmi_noise_set(lbmi_t * lb, unsigned int * state, long long nsites,

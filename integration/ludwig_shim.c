@@ -538,12 +538,6 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
       unsigned int * state = (unsigned int *)
 	shim_cached(noise, &noise->target->state, sizeof(unsigned int *));
       physics_kt(phys, &kt);
-      if (shim_.mode == LBMI_MODE_FUSED && lb->ndist == 1) {
-	pe_info(lb->pe, "liblbmi: isothermal fluctuations: LBMI_MODE=fused -> halo\n");
-	SHIM_CHECK(lb, lbmi_lb_mode_set(h, LBMI_MODE_FUSED_HALO));
-	shim_.mode = LBMI_MODE_FUSED_HALO;
-	shim_sync_pointers(lb, h);
-      }
       SHIM_CHECK(lb, lbmi_noise_set(h, state, noise->nsites, kt,
 				    lb->param->isghost == LB_GHOST_ON));
     }

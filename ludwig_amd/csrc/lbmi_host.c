@@ -1516,7 +1516,9 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
        * the send buffers, so a steady-state step is: interior launch beside
        * (messages, then ONE boundary launch) -- no pack, no unpack kernel.
        * Otherwise: pack, messages, unpack into the halo planes of f. */
-      const int direct = (lb->x_direct && lb->x_packed);
+      /* (a fluctuating collision has no variant against the exchange
+       * buffers: pack, messages, unpack) */
+      const int direct = (lb->x_direct && lb->x_packed && h->noise == NULL);
       const int detail = (lb->timing_now && lb->nd < LBMI_NDETAIL);
       const lbmi_xbuf_t xbuf = {lb->fx[2], lb->fx[3], lb->fx[0], lb->fx[1]};
       const lbmi_xbuf_t * xb = direct ? &xbuf : NULL;
@@ -1647,9 +1649,9 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
     if (lb->opts.nvel != 19) {
       return lbmi_fail(LBMI_ERR_STATE, "fluctuations: D3Q19 only (noise.h:18)");
     }
-    if (lb->opts.mode != LBMI_MODE_EAGER && lb->opts.mode != LBMI_MODE_FUSED_HALO) {
-      return lbmi_fail(LBMI_ERR_STATE, "fluctuations: LBMI_MODE_EAGER or "
-		       "LBMI_MODE_FUSED_HALO (lbmi_lb_mode_set)");
+    if (lbmi_inplace(lb)) {
+      return lbmi_fail(LBMI_ERR_STATE, "fluctuations: not in LBMI_MODE_INPLACE "
+		       "(lbmi_lb_mode_set)");
     }
     h.noise = lb->noise_state;
     h.noise_stride = lb->noise_stride;

@@ -2678,30 +2678,32 @@ int launch_pc(const lbmi_kparam_t & kp, const double * f, double * fp,
   return launch_pc_hio<NVEL, WRAP, LAY, false, false>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st, none);
 }
 
-/* with fluctuations: D3Q19, SoA -> SoA without index wrap (the pull of
- * FUSED_HALO), hydro arrays as they are, no exchange buffers */
-inline int launch_pc_noise(const lbmi_kparam_t & kp, const double * f, double * fp,
-			   const lbmi_hydro_dev_t & h, int i0, int i1, int j0,
-			   int j1, hipStream_t st) {
+/* with fluctuations: D3Q19, the hydro arrays as they are (the variant with
+ * hydro traffic tests every pointer), no exchange buffers */
+template <bool WRAP, int LAY>
+int launch_pc_noise(const lbmi_kparam_t & kp, const double * f, double * fp,
+		    const lbmi_hydro_dev_t & h, int wrapmask, int i0, int i1,
+		    int j0, int j1, hipStream_t st) {
   const lbmi_xbuf_t none = {nullptr, nullptr, nullptr, nullptr};
-  const int i0a = (i0/LBMI_ALIGN)*LBMI_ALIGN;
-  const int j0a = (j0/LBMI_ALIGN)*LBMI_ALIGN;
+  constexpr int ALIGNV = ((LAY & 3) == 0) ? LBMI_ALIGN : LBW;
+  const int i0a = (i0/ALIGNV)*ALIGNV;
+  const int j0a = (j0/ALIGNV)*ALIGNV;
   unsigned nblk_first = (unsigned) ((i1 - i0a + BLOCK*SPT - 1)/(BLOCK*SPT));
   unsigned nblk = nblk_first;
   if (j1 > j0) nblk += (unsigned) ((j1 - j0a + BLOCK*SPT - 1)/(BLOCK*SPT));
   dim3 grid(grid_for(nblk, (unsigned) kp.xcd_group)), block(BLOCK);
   switch (kp.scheme) {
   case LBMI_M10:
-    hipLaunchKernelGGL((k_propagate_collide<19, LBMI_M10, false, 0, true, false, true>), grid,
-		       block, 0, st, kp, f, fp, h, 0, i0, i1, nblk, j0, j1, nblk_first, none);
+    hipLaunchKernelGGL((k_propagate_collide<19, LBMI_M10, WRAP, LAY, true, false, true>), grid,
+		       block, 0, st, kp, f, fp, h, wrapmask, i0, i1, nblk, j0, j1, nblk_first, none);
     break;
   case LBMI_BGK:
-    hipLaunchKernelGGL((k_propagate_collide<19, LBMI_BGK, false, 0, true, false, true>), grid,
-		       block, 0, st, kp, f, fp, h, 0, i0, i1, nblk, j0, j1, nblk_first, none);
+    hipLaunchKernelGGL((k_propagate_collide<19, LBMI_BGK, WRAP, LAY, true, false, true>), grid,
+		       block, 0, st, kp, f, fp, h, wrapmask, i0, i1, nblk, j0, j1, nblk_first, none);
     break;
   case LBMI_TRT:
-    hipLaunchKernelGGL((k_propagate_collide<19, LBMI_TRT, false, 0, true, false, true>), grid,
-		       block, 0, st, kp, f, fp, h, 0, i0, i1, nblk, j0, j1, nblk_first, none);
+    hipLaunchKernelGGL((k_propagate_collide<19, LBMI_TRT, WRAP, LAY, true, false, true>), grid,
+		       block, 0, st, kp, f, fp, h, wrapmask, i0, i1, nblk, j0, j1, nblk_first, none);
     break;
   default:
     return (int) hipErrorInvalidValue;
@@ -2715,8 +2717,17 @@ int launch_pc_any(const lbmi_kparam_t & kp, const double * f, double * fp,
 		  int i1, int j0, int j1, hipStream_t st,
 		  const lbmi_xbuf_t * xb) {
   if (h.noise != nullptr) {
-    if (NVEL != 19 || wrapmask || lay != 0 || xb != nullptr) return (int) hipErrorInvalidValue;
-    return launch_pc_noise(kp, f, fp, h, i0, i1, j0, j1, st);
+    if (NVEL != 19 || xb != nullptr) return (int) hipErrorInvalidValue;
+    if (!wrapmask) {
+      if (lay != 0) return (int) hipErrorInvalidValue;
+      return launch_pc_noise<false, 0>(kp, f, fp, h, 0, i0, i1, j0, j1, st);
+    }
+    if (lay == 0) return launch_pc_noise<true, 0>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
+#if LBMI_BLOCK*LBMI_SPT == 256
+    if (lay == 1) return launch_pc_noise<true, 1>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
+    if (lay == 2) return launch_pc_noise<true, 2>(kp, f, fp, h, wrapmask, i0, i1, j0, j1, st);
+#endif
+    return (int) hipErrorInvalidValue;
   }
   if (!wrapmask) {
     if (lay != 0 || xb != nullptr) return (int) hipErrorInvalidValue;

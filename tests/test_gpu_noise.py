@@ -3,8 +3,9 @@ noise.c:397-487) on the MI355X against the compiled reference: fixtures
 noise_q19_* (M10, TRT with a solid block and a force field, BGK with a
 viscosity model, M10 with ghost modes off). Distributions to 1e-12; the
 generator states -- integer arithmetic -- bit for bit. EAGER (collision in
-place) and FUSED_HALO (the binding's default: the pull of the previous step's
-propagation folded into the fluctuating collision)."""
+place), FUSED_HALO (the binding's default: the pull of the previous step's
+propagation folded into the fluctuating collision), FUSED (the halo swap
+folded in as well) and the slab step of FUSED on a one-rank ring."""
 
 import glob
 import os
@@ -77,14 +78,21 @@ def test_first_collision_vs_reference(name):
     lb.free()
 
 
-@pytest.mark.parametrize("mode", ["eager", "fused_halo"])
+@pytest.mark.parametrize("mode", ["eager", "fused_halo", "fused", "fused_ring"])
 @pytest.mark.parametrize("name", noise_names())
 def test_steps_and_generator_states_vs_reference(name, mode):
+    """fused: halo swap and propagation folded into the fluctuating collision
+    (index wrap; the deferred state in the blocked order where the lattice
+    allows it); fused_ring: the same through a one-rank RCCL ring, i.e. the
+    slab step (interior and boundary launches, pack / messages / unpack)."""
     import ludwig_amd
     g = load_golden(name)
     meta = g["meta"]
     h = meta["nhalo"]
-    lb, hy, state, st = _setup(g, {"eager": ludwig_amd.EAGER, "fused_halo": ludwig_amd.FUSED_HALO}[mode])
+    lb, hy, state, st = _setup(g, {"eager": ludwig_amd.EAGER, "fused_halo": ludwig_amd.FUSED_HALO,
+                                   "fused": ludwig_amd.FUSED, "fused_ring": ludwig_amd.FUSED}[mode])
+    if mode == "fused_ring":
+        lb.comm_init(ludwig_amd.LB.comm_unique_id())
     for _ in range(meta["nsteps"]):
         lb.lb_collide(hy)
         lb.lb_halo()
@@ -145,8 +153,8 @@ def test_what_fluctuations_do_not_cover_is_refused():
     with pytest.raises(ludwig_amd.LbmiError):
         lb.noise_set(state[:, :10].contiguous(), 1e-4)
     lb.free()
-    # FUSED (index wrap, blocked order) and INPLACE: lb_collide says so
-    for mode in (ludwig_amd.FUSED, ludwig_amd.INPLACE):
+    # INPLACE (the AA pair): lb_collide says so
+    for mode in (ludwig_amd.INPLACE,):
         lb = ludwig_amd.LB(19, (4, 4, 4), 1, mode=mode)
         lb.relaxation_set("m10", 0.1, 0.3)
         hy = ludwig_amd.Hydro(lb.nall, lb.device)
