@@ -417,6 +417,13 @@ int lbmi_lb_state(lbmi_t * lb, int state[3]);
  * nvel*nsite doubles and the current f. */
 int lbmi_lb_memcpy_h2d(lbmi_t * lb, const double * f_host);
 int lbmi_lb_memcpy_d2h(lbmi_t * lb, double * f_host);
+/* The caller has overwritten the current f on the device itself (the
+ * reference's lb_memcpy host -> device, e.g. after the Lees-Edwards
+ * reprojection on the host, model_le.c:72-83): the handle drops what it
+ * derived from the old contents (planes of a slab already under way to the
+ * neighbours for the next fused step, rho / u still owed). The state must be
+ * canonical (lbmi_lb_flush first; LBMI_ERR_STATE otherwise). */
+int lbmi_lb_dirty(lbmi_t * lb);
 int lbmi_lb_moments(lbmi_t * lb, const char * status, double out[9]);
 /* lb_0th_moment (model.c:817-832) of every interior site of the first
  * distribution, summed in p order as there, to a HOST array of

@@ -108,6 +108,8 @@
 #include "advection.h"
 #include "cahn_hilliard_stats.h"
 #include "fe_force_method.h"
+#include "lb_bc_inflow_rhou.h"
+#include "lb_bc_outflow_rhou.h"
 
 #include "lbmi.h"
 
@@ -142,6 +144,12 @@ int hydro_u_zero_ref(hydro_t * hydro, const double uzero[3]);
 int hydro_f_zero_ref(hydro_t * hydro, const double fzero[3]);
 int hydro_memcpy_ref(hydro_t * hydro, tdpMemcpyKind flag);
 int field_halo_ref(field_t * field);
+int lb_bc_inflow_rhou_create_ref(pe_t * pe, cs_t * cs,
+				 const lb_bc_inflow_opts_t * options,
+				 lb_bc_inflow_rhou_t ** inflow);
+int lb_bc_outflow_rhou_create_ref(pe_t * pe, cs_t * cs,
+				  const lb_bc_outflow_opts_t * options,
+				  lb_bc_outflow_rhou_t ** outflow);
 int field_grad_compute_ref(field_grad_t * fgrad);
 void field_grad_free_ref(field_grad_t * obj);
 
@@ -171,7 +179,11 @@ static const char * const shim_sym_[S_NSYM] = {
   "cahn_hilliard_stats_time0"};
 static long shim_calls_[S_NSYM][2];              /* [.][1]: liblbmi, [.][0]: original */
 
+static const char * shim_mode_name(int mode);
+static void shim_report_policy(void);
+
 static void shim_report(void) {
+  shim_report_policy();
   fprintf(stderr, "liblbmi report: %-28s %10s %10s\n", "symbol", "liblbmi", "original");
   for (int n = 0; n < S_NSYM; n++) {
     if (shim_calls_[n][0] + shim_calls_[n][1] == 0) continue;
@@ -220,11 +232,37 @@ typedef struct shim_s {
   int wall_nlink;
   int colloids;                   /* bounce_back_on_links has seen colloids */
   int ncollide;                   /* bound collisions so far */
+  int nlazy;                      /* ... of which left rho, u on demand */
+  int automode;                   /* LBMI_MODE unset: fused until a consumer of
+				     the state between lb_collide and
+				     lb_propagation shows up */
   int param_valid;                /* param_committed is what the device has */
   lb_collide_param_t param_committed;
 } shim_t;
 
 static shim_t shim_;              /* zero: no handle, LBMI_MODE_EAGER */
+static int shim_openbc_ = 0;      /* open-boundary objects created (below) */
+
+static const char * shim_mode_name(int mode) {
+  if (mode == LBMI_MODE_FUSED) return "fused";
+  if (mode == LBMI_MODE_FUSED_HALO) return "halo";
+  if (mode == LBMI_MODE_INPLACE) return "inplace";
+  return "eager";
+}
+
+/* LBMI_REPORT=1: how the run ended up being executed (what the policy of
+ * shim_handle / lb_collide below made of it) */
+
+static shim_t shim_ended_;        /* what shim_ was when lb_free dropped the handle */
+
+static void shim_report_policy(void) {
+  const shim_t * sh = (shim_.h != NULL) ? &shim_ : &shim_ended_;
+  if (sh->lb == NULL) return;
+  fprintf(stderr, "liblbmi report: execution mode %s (%s); rho, u on demand in "
+	  "%d of %d collisions\n", shim_mode_name(sh->mode),
+	  sh->automode ? "chosen by the binding" : "LBMI_MODE",
+	  sh->nlazy, sh->ncollide);
+}
 
 #define SHIM_CHECK(lb, call)						\
   do {									\
@@ -349,16 +387,21 @@ static lbmi_t * shim_handle(lb_t * lb) {
     int cartsz[3], coords[3];
     double * f = NULL;
     double * fprime = NULL;
-        /* LBMI_MODE = halo (the default: after lb_collide and lb_halo f is the
-     * reference's, so walls, colloids and anything else that acts between
-     * lb_halo and lb_propagation find what they expect; only the propagation
-     * is deferred into the next collision, and every reader this file knows
-     * of -- lb_memcpy, the statistics, lb_io_write, phi_lb_to_field -- flushes
-     * it first), eager (f as the reference after every call, three passes
-     * over f per step) or fused (halo swap and propagation both deferred:
-     * nothing may touch f between lb_collide and lb_propagation; a run that
-     * turns out to have wall links or colloids drops to halo at the first
-     * wall_set_wall_distributions / bounce_back_on_links that would see it) */
+    /* LBMI_MODE unset (the default): the run starts in LBMI_MODE_FUSED -- halo
+     * swap and propagation both deferred into the next collision, one pass
+     * over f per step -- and stays there as long as nothing works on f between
+     * lb_collide and lb_propagation. Everything in the reference that does
+     * comes through this file and moves the handle to `halo`
+     * (LBMI_MODE_FUSED_HALO: lb_collide and lb_halo leave exactly the
+     * reference's state, only the propagation is deferred) when it has work
+     * to do: wall_set_wall_distributions / wall_bbl with links,
+     * bounce_back_on_links with colloids, open boundaries (their impose step,
+     * ludwig.c:823-832), Lees-Edwards planes (lb_le_apply_boundary_conditions
+     * goes through lb_memcpy both ways every step, model_le.c:72-83). Every
+     * reader of f AFTER lb_propagation that the reference has -- lb_memcpy,
+     * the statistics, lb_io_write, phi_lb_to_field -- is bound and flushes
+     * first. LBMI_MODE = halo | eager | fused overrides: halo and eager start
+     * (and stay) there; fused is the default with its name spelt out. */
     const char * mode = getenv("LBMI_MODE");
 
     lbmi_options_default(&opts);
@@ -372,9 +415,9 @@ static lbmi_t * shim_handle(lb_t * lb) {
     opts.cartrank = coords[X];
     opts.device = -1;                            /* ludwig.c:467-492 chose it */
     opts.halo_scheme = LBMI_HALO_FULL;           /* halo_swap_packed semantics */
-        opts.mode = LBMI_MODE_FUSED_HALO;              /* ndist 1 or 2 */
+    opts.mode = LBMI_MODE_FUSED;                 /* ndist 1 or 2 */
     if (mode && mode[0] == 'e') opts.mode = LBMI_MODE_EAGER;
-    if (mode && mode[0] == 'f') opts.mode = LBMI_MODE_FUSED;   /* ndist 1 or 2 */
+    if (mode && mode[0] == 'h') opts.mode = LBMI_MODE_FUSED_HALO;
     if (mode && mode[0] != 'e' && mode[0] != 'f' && mode[0] != 'h') {
       pe_fatal(lb->pe, "liblbmi: LBMI_MODE=%s (halo, eager or fused)\n", mode);
     }
@@ -391,6 +434,8 @@ static lbmi_t * shim_handle(lb_t * lb) {
     shim_.param_valid = 0;
     shim_.colloids = 0;
     shim_.ncollide = 0;
+    shim_.nlazy = 0;
+    shim_.automode = (mode == NULL);
 
     shim_device_f(lb, &f, &fprime);
     SHIM_CHECK(lb, lbmi_lb_bind(shim_.h, f, fprime));
@@ -456,6 +501,8 @@ static void shim_hydro_foreign(hydro_t * hydro) {
   SHIM_CHECK(shim_.lb, lbmi_hydro_field_dirty(shim_.h, shim_field_data(hydro->u)));
   SHIM_CHECK(shim_.lb, lbmi_hydro_field_dirty(shim_.h, shim_field_data(hydro->rho)));
 }
+
+static void shim_needs_canonical_f(lb_t * lb, const char * who);
 
 /*****************************************************************************
  *
@@ -545,6 +592,15 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
       SHIM_CHECK(lb, lbmi_noise_set(h, NULL, 0, 0.0, 0));
     }
 
+    /* work on f between lb_collide and lb_propagation that is known here
+     * (the rest announces itself: shim_needs_canonical_f) */
+    if (shim_.mode == LBMI_MODE_FUSED && shim_.automode) {
+      if (hydro->le && lees_edw_nplane_total(hydro->le) > 0) {
+	shim_needs_canonical_f(lb, "lb_le_apply_boundary_conditions");
+      }
+      if (shim_openbc_ > 0) shim_needs_canonical_f(lb, "an open boundary");
+    }
+
     status = (char *) shim_cached(map, &map->target->status, sizeof(char *));
     hy.force  = shim_field_data(hydro->force);
     hy.status = status;
@@ -570,22 +626,40 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
     }
     shim_.ncollide += 1;
 
-    /* LBMI_HYDRO=lazy: the plain single-fluid run, where nobody on the
-     * device reads hydro->rho, u between two collisions (no free energy, no
-     * viscosity model, no colloids, no Lees-Edwards planes): the collision
-     * does not store them; hydro_memcpy (statistics, output) and hydro_u_halo
-     * get them formed first. 32 B/site per step. */
+    /* hydro->rho, u on demand. The reference's collision stores them at every
+     * site every step (collision.c:563-596); who reads them on the device
+     * before the next collision overwrites them? In ludwig.c's loop:
+     *   phi_cahn_hilliard / ch_solver -> advection (advection.c:517-951),
+     *   phi_force_colloid (:158-302), phi_grad_mu (:76-270), lc_droplet
+     *   (:787), blue_phase_beris_edwards (:515, 1043), leslie_ericksen
+     *   (:133, 303), nernst_planck, psi_force_*        all need a free energy;
+     *   visc_arrhenius (:169) and the other models     a visc_t;
+     *   subgrid, stats_calibration, build              colloids (and go through
+     *                                                  hydro_memcpy, bound);
+     *   lb_bc_inflow/outflow_rhou update + impose      open boundaries;
+     *   Lees-Edwards buffer planes of u                le planes.
+     * Without any of them -- each is known here: fe, visc, what
+     * bounce_back_on_links and the open-boundary constructors have seen,
+     * hydro->le -- the only readers left are hydro_memcpy (statistics, output)
+     * and hydro_u_halo, both bound: they get rho, u formed first
+     * (lbmi_lb_hydro_sync), equal to rounding. So that is the default;
+     * LBMI_HYDRO=store keeps the reference's stores in every run,
+     * LBMI_HYDRO=lazy is the default spelt out. 32 B/site per step. */
     {
       static int wanted = -1;
       int lazy;
       if (wanted < 0) {
 	const char * e = getenv("LBMI_HYDRO");
-	wanted = (e != NULL && e[0] == 'l');
+	wanted = (e == NULL || e[0] == 'l');
+	if (e != NULL && e[0] != 'l' && e[0] != 's') {
+	  pe_fatal(lb->pe, "liblbmi: LBMI_HYDRO=%s (lazy or store)\n", e);
+	}
       }
       lazy = (wanted && fe == NULL && visc == NULL && !shim_.colloids &&
-	      lb->ndist == 1 &&
+	      lb->ndist == 1 && shim_openbc_ == 0 &&
 	      !(hydro->le && lees_edw_nplane_total(hydro->le) > 0));
       SHIM_CHECK(lb, lbmi_tune(h, "hydro_lazy", lazy));
+      shim_.nlazy += lazy;
     }
 
     if (lb->ndist == 2 || (fe && fe->use_stress_relaxation)) {
@@ -684,8 +758,8 @@ static void shim_wall_links(wall_t * wall, lbmi_t * h) {
 static void shim_needs_canonical_f(lb_t * lb, const char * who) {
   if (shim_.h == NULL || shim_.lb != lb) return;
   if (shim_.mode != LBMI_MODE_FUSED) return;
-  pe_info(lb->pe, "liblbmi: %s acts on the distributions between lb_halo and "
-	  "lb_propagation: LBMI_MODE=fused -> halo\n", who);
+  pe_info(lb->pe, "liblbmi: %s acts on the distributions between lb_collide "
+	  "and lb_propagation: execution mode fused -> halo\n", who);
   SHIM_CHECK(lb, lbmi_lb_mode_set(shim_.h, LBMI_MODE_FUSED_HALO));
   shim_.mode = LBMI_MODE_FUSED_HALO;
   shim_sync_pointers(lb, shim_.h);
@@ -747,11 +821,41 @@ int bounce_back_on_links(bbl_t * bbl, lb_t * lb, wall_t * wall,
 
   colloids_info_ntotal(cinfo, &ntotal);
   if (ntotal > 0) {
+    if (!shim_.colloids && shim_.h != NULL && shim_.lb == lb) {
+      /* the collision of this step may have left rho, u on demand: from now
+       * on they are stored (lb_collide), and this once they are formed */
+      SHIM_CHECK(lb, lbmi_lb_hydro_sync(shim_.h));
+    }
     shim_.colloids = 1;
     shim_needs_canonical_f(lb, "bounce_back_on_links");
   }
 
   return bounce_back_on_links_ref(bbl, lb, wall, cinfo);
+}
+
+/*****************************************************************************
+ *
+ *  lb_bc_inflow_rhou_create, lb_bc_outflow_rhou_create (lb_bc_open_rt.c:119,
+ *  160): the originals. Their update / impose steps read hydro->rho, u and
+ *  set distributions between lb_halo and lb_propagation (ludwig.c:600-605,
+ *  823-832) through function tables this file cannot bind: a run that has
+ *  created one keeps the reference's state at that point (halo) and stores
+ *  rho, u in every collision.
+ *
+ *****************************************************************************/
+
+int lb_bc_inflow_rhou_create(pe_t * pe, cs_t * cs,
+			     const lb_bc_inflow_opts_t * options,
+			     lb_bc_inflow_rhou_t ** inflow) {
+  shim_openbc_ += 1;
+  return lb_bc_inflow_rhou_create_ref(pe, cs, options, inflow);
+}
+
+int lb_bc_outflow_rhou_create(pe_t * pe, cs_t * cs,
+			      const lb_bc_outflow_opts_t * options,
+			      lb_bc_outflow_rhou_t ** outflow) {
+  shim_openbc_ += 1;
+  return lb_bc_outflow_rhou_create_ref(pe, cs, options, outflow);
 }
 
 /*****************************************************************************
@@ -766,6 +870,7 @@ int lb_free(lb_t * lb) {
   if (shim_.lb == lb) {
     /* the handle borrows lb->target->f / fprime: it goes first */
     if (shim_.h) lbmi_free(shim_.h);
+    shim_ended_ = shim_;                         /* for the report at exit */
     memset(&shim_, 0, sizeof(shim_));
     last_f = NULL;
     last_fprime = NULL;
@@ -774,6 +879,15 @@ int lb_free(lb_t * lb) {
 }
 
 int field_free(field_t * obj) {
+  if (shim_.h != NULL && obj != NULL) {
+    /* "known to hold zeros" is kept by device address: the next allocation
+     * may get this one */
+    for (int n = 0; n < shim_ncache_; n++) {
+      if (shim_cache_[n].obj == obj) {
+	lbmi_hydro_field_dirty(shim_.h, (const double *) shim_cache_[n].data);
+      }
+    }
+  }
   shim_forget(obj);
   return field_free_ref(obj);
 }
@@ -879,7 +993,16 @@ int lb_memcpy(lb_t * lb, tdpMemcpyKind flag) {
     shim_sync_pointers(lb, shim_.h);
   }
 
-  return lb_memcpy_ref(lb, flag);
+  {
+    int ifail = lb_memcpy_ref(lb, flag);
+    if (flag == tdpMemcpyHostToDevice && shim_.h && shim_.lb == lb) {
+      /* f rewritten behind the library's back (the first copy of ludwig.c:507,
+       * the Lees-Edwards reprojection model_le.c:72-83, a restart): planes a
+       * slab has already sent ahead for its next fused step are stale */
+      SHIM_CHECK(lb, lbmi_lb_dirty(shim_.h));
+    }
+    return ifail;
+  }
 }
 
 
@@ -993,11 +1116,20 @@ static lbmi_t * shim_handle_if_any(cs_t * cs) {
 
 int hydro_memcpy(hydro_t * hydro, tdpMemcpyKind flag) {
   assert(hydro);
-  if (shim_.h != NULL && flag == tdpMemcpyDeviceToHost) {
+  if (shim_.h != NULL) {
+    /* device -> host: rho, u still owed by a lazy collision are formed first;
+     * host -> device (subgrid_force_from_particles subgrid.c:200, a restart):
+     * settled as well, or they would later be formed over what arrives now */
     SHIM_CHECK(shim_.lb, lbmi_lb_hydro_sync(shim_.h));
     SHIM_CHECK(shim_.lb, lbmi_synchronize(shim_.h));
   }
-  return hydro_memcpy_ref(hydro, flag);
+  {
+    int ifail = hydro_memcpy_ref(hydro, flag);
+    /* ... and the arrays have been written outside the library: nothing it
+     * remembers about their contents (a force field of zeros) holds */
+    if (flag == tdpMemcpyHostToDevice) shim_hydro_foreign(hydro);
+    return ifail;
+  }
 }
 
 int hydro_u_zero(hydro_t * hydro, const double uzero[3]) {

@@ -125,6 +125,7 @@ struct lbmi_s {
     lbmi_hydro_dev_t h;
     lbmi_kparam_t kp;
     int nt_store_mode;
+    int hydro_lazy;
     hipStream_t stream;
   } run_key;
   int slip_active;                   /* wall_slip_t */
@@ -569,7 +570,8 @@ int lbmi_relaxation_rates(const lbmi_t * lb, double rtau[4]) {
  *****************************************************************************/
 
 static lbmi_hydro_dev_t lbmi_hydro_dev(const lbmi_hydro_t * hydro) {
-  lbmi_hydro_dev_t h = {NULL, NULL, NULL, NULL, NULL, 0, 0, NULL, 0, 0.0, 0};
+  lbmi_hydro_dev_t h;
+  memset(&h, 0, sizeof(h));          /* padding too: the struct is compared */
   if (hydro) {
     h.stride = hydro->nsite;
     h.force = hydro->force;
@@ -586,6 +588,8 @@ static lbmi_hydro_dev_t lbmi_hydro_dev(const lbmi_hydro_t * hydro) {
  * or the caller says so (lbmi_hydro_field_dirty). A force array on the list
  * is not read by the collision, and zeroing it again is not a launch. */
 
+static void lbmi_run_graph_release(lbmi_t * lb);
+
 static int lbmi_known_zero(const lbmi_t * lb, const void * p) {
   if (p == NULL) return 0;
   for (int n = 0; n < 4; n++) {
@@ -596,7 +600,11 @@ static int lbmi_known_zero(const lbmi_t * lb, const void * p) {
 
 static void lbmi_known_zero_drop(lbmi_t * lb, const void * p) {
   for (int n = 0; n < 4; n++) {
-    if (p != NULL && lb->known_zero[n] == p) lb->known_zero[n] = NULL;
+    if (p != NULL && lb->known_zero[n] == p) {
+      lb->known_zero[n] = NULL;
+      /* a captured lbmi_lb_run (tune "graph") skipped this array */
+      lbmi_run_graph_release(lb);
+    }
   }
 }
 
@@ -605,10 +613,12 @@ static void lbmi_known_zero_add(lbmi_t * lb, const void * p) {
   for (int n = 0; n < 4; n++) {
     if (lb->known_zero[n] == NULL) {
       lb->known_zero[n] = p;
+      lbmi_run_graph_release(lb);    /* captured launches still read it */
       return;
     }
   }
   lb->known_zero[0] = p;             /* full: forget the oldest entry */
+  lbmi_run_graph_release(lb);
 }
 
 /* hydro_lazy: the rho and u a collision would have stored are formed from the
@@ -786,6 +796,7 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
       ifail = lbmi_hydro_materialise(lb);
       if (ifail) return ifail;
     }
+    if (lb->hydro_lazy != (value != 0)) lbmi_run_graph_release(lb);
     lb->hydro_lazy = (value != 0);
     return 0;
   }
@@ -1343,9 +1354,13 @@ int lbmi_lb_bind(lbmi_t * lb, double * f, double * fprime) {
     hipFree(lb->fprime);
     lb->owns_f = 0;
   }
-    lb->f = NULL;
+  lb->f = NULL;
   lb->fprime = NULL;
   lb->hydro_stale = 0;
+  /* other arrays, another allocation: what was known about addresses seen
+   * with the old pair need not hold for what lives at them now */
+  memset(lb->known_zero, 0, sizeof(lb->known_zero));
+  lbmi_run_graph_release(lb);
   lb->xsend_valid = 0;
   lb->pending_halo = 0;
   lb->pending_prop = 0;
@@ -1617,6 +1632,11 @@ int lbmi_noise_set(lbmi_t * lb, unsigned int * state, long long nsites,
     }
     if (!(kt >= 0.0)) return lbmi_fail(LBMI_ERR_ARGUMENT, "fluctuations: kt < 0");
   }
+  if (lb->noise_state != state || lb->noise_stride != nsites ||
+      lb->noise_kt != kt || lb->noise_ghosts != (ghosts_on != 0)) {
+    /* a captured lbmi_lb_run carries the old generator / temperature */
+    lbmi_run_graph_release(lb);
+  }
   lb->noise_state = state;
   lb->noise_stride = nsites;
   lb->noise_kt = kt;
@@ -1633,11 +1653,29 @@ int lbmi_noise_set(lbmi_t * lb, unsigned int * state, long long nsites,
 
 static int lbmi_lb_collide_dev(lbmi_t * lb, const lbmi_hydro_dev_t * hp);
 
+/* What lbmi_lb_collide hands to the kernels for a hydro object: the generator
+ * of lbmi_noise_set joined, a force array known to hold zeros left out (F =
+ * the body force, bit for bit). Also the key of a captured lbmi_lb_run. */
+
+static lbmi_hydro_dev_t lbmi_hydro_effective(const lbmi_t * lb,
+					     const lbmi_hydro_t * hydro) {
+  lbmi_hydro_dev_t h = lbmi_hydro_dev(hydro);
+  if (lb->noise_state != NULL) {
+    h.noise = lb->noise_state;
+    h.noise_stride = lb->noise_stride;
+    h.noise_kt = lb->noise_kt;
+    h.noise_ghosts = lb->noise_ghosts;
+  }
+  if (lbmi_known_zero(lb, h.force)) h.force = NULL;
+  return h;
+}
+
 int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
 
-  lbmi_hydro_dev_t h = lbmi_hydro_dev(hydro);
+  lbmi_hydro_dev_t h;
 
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  h = lbmi_hydro_effective(lb, hydro);
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
   if (lb->opts.ndist != 1) {
     return lbmi_fail(LBMI_ERR_STATE, "ndist = 2: lbmi_lb_collide_binary");
@@ -1653,14 +1691,8 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
       return lbmi_fail(LBMI_ERR_STATE, "fluctuations: not in LBMI_MODE_INPLACE "
 		       "(lbmi_lb_mode_set)");
     }
-    h.noise = lb->noise_state;
-    h.noise_stride = lb->noise_stride;
-    h.noise_kt = lb->noise_kt;
-    h.noise_ghosts = lb->noise_ghosts;
   }
 
-  /* a force field of zeros is not read (F = the body force, bit for bit) */
-  if (lbmi_known_zero(lb, h.force)) h.force = NULL;
   /* whatever an earlier collision still owed is superseded by this one */
   lb->hydro_stale = 0;
   if (lb->hydro_lazy && lbmi_deferred(lb) && !lbmi_inplace(lb) &&
@@ -2696,7 +2728,9 @@ static void lbmi_run_graph_release(lbmi_t * lb) {
 
 static int lbmi_run_graph_pairs(lbmi_t * lb, const lbmi_hydro_t * hydro,
 				int npairs) {
-  lbmi_hydro_dev_t h = lbmi_hydro_dev(hydro);
+  /* (what the captured launches carry: after the substitutions of
+   * lbmi_lb_collide, and whether they store rho, u) */
+  lbmi_hydro_dev_t h = lbmi_hydro_effective(lb, hydro);
   /* the legacy default stream cannot be captured: borrow the private one */
   hipStream_t user = lb->stream;
   hipStream_t cs = (user != NULL) ? user : lb->own_stream;
@@ -2707,6 +2741,7 @@ static int lbmi_run_graph_pairs(lbmi_t * lb, const lbmi_hydro_t * hydro,
   if (lb->run_graph == NULL || lb->run_key.f != lb->f ||
       lb->run_key.fprime != lb->fprime || lb->run_key.stream != cs ||
       lb->run_key.nt_store_mode != lb->nt_store_mode ||
+      lb->run_key.hydro_lazy != lb->hydro_lazy ||
       memcmp(&lb->run_key.h, &h, sizeof(h)) != 0 ||
       memcmp(&lb->run_key.kp, &lb->kp, sizeof(lb->kp)) != 0) {
     hipGraph_t graph = NULL;
@@ -2716,6 +2751,7 @@ static int lbmi_run_graph_pairs(lbmi_t * lb, const lbmi_hydro_t * hydro,
     lb->run_key.fprime = lb->fprime;
     lb->run_key.h = h;
     lb->run_key.nt_store_mode = lb->nt_store_mode;
+    lb->run_key.hydro_lazy = lb->hydro_lazy;
     lb->run_key.stream = cs;
     HIPCHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     lb->stream = cs;
@@ -2820,6 +2856,26 @@ int lbmi_lb_memcpy_h2d(lbmi_t * lb, const double * f_host) {
   lb->xsend_valid = 0;
   HIPCHECK(hipMemcpyAsync(lb->f, f_host, sz, hipMemcpyHostToDevice, lb->stream));
   HIPCHECK(hipStreamSynchronize(lb->stream));
+  return 0;
+}
+
+/* The caller has rewritten the current f on the device by means of its own
+ * (the reference's lb_memcpy host -> device after a Lees-Edwards reprojection
+ * on the host, model_le.c:72-83; a foreign kernel between two steps): nothing
+ * the handle derived from the old contents survives -- the planes a slab left
+ * in its send buffers for messages already under way, rho and u still owed.
+ * Needs the canonical state (lbmi_lb_flush first), as the writer did. */
+
+int lbmi_lb_dirty(lbmi_t * lb) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+  if (lb->pending_prop || lb->blocked || lb->layout_swapped || lb->early_prop ||
+      (lb->pending_halo && !lb->halo_done)) {
+    return lbmi_fail(LBMI_ERR_STATE, "lbmi_lb_dirty: a deferred state cannot "
+		     "have been rewritten by the caller (lbmi_lb_flush first)");
+  }
+  lb->xsend_valid = 0;
+  lb->hydro_stale = 0;
   return 0;
 }
 

@@ -841,6 +841,10 @@ void pc_pull(const lbmi_kparam_t & kp, const double * __restrict__ f,
   }
 
 #if LBMI_HALO_LANES_COPY
+  /* (the ablation variant has no pull against the exchange buffers of a slab:
+   * it would read halo planes nobody has filled) */
+  static_assert(!XB, "LBMI_HALO_LANES_COPY has no x_direct (XB) variant: build "
+		"the ablation with the boundary launch off, lbmi_tune x_direct 0");
   static_for<0, NVEL>([&](auto P) {
     constexpr int p = P;
     constexpr int cx = M::c(p,0), cy = M::c(p,1), cz = M::c(p,2);

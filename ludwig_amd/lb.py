@@ -14,6 +14,7 @@ Array convention (the reference's SoA order, see include/lbmi.h):
 """
 
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -102,6 +103,7 @@ class LB:
         torch = _torch()
         self._lib = _l.library()
         self._h = ctypes.c_void_p()
+        self._zeroed = {}          # data_ptr -> (weakref, version): _zeros_still_hold
         opts = _l.Options()
         _l.check(self._lib.lbmi_options_default(ctypes.byref(opts)))
         opts.nvel = nvel
@@ -183,6 +185,11 @@ class LB:
         _l.check(self._lib.lbmi_lb_memcpy_h2d(
             self._h, f_host.ctypes.data_as(ctypes.c_void_p)))
 
+    def lb_dirty(self):
+        """lbmi_lb_dirty: the caller has overwritten the current f on the
+        device itself (the canonical state, e.g. through lb.f after a flush)."""
+        _l.check(self._lib.lbmi_lb_dirty(self._h))
+
     def lb_memcpy_d2h(self):
         out = np.empty((self.ndist * self.nvel,) + self.nall, dtype=np.float64)
         _l.check(self._lib.lbmi_lb_memcpy_d2h(
@@ -191,7 +198,24 @@ class LB:
 
     # -- the time step (ludwig.c:802-860) ----------------------------------
 
+    def _zeros_still_hold(self):
+        """The library remembers arrays zeroed through hydro_field_set by
+        ADDRESS and does not read a force field it knows to hold zeros
+        (include/lbmi.h: any other writer reports its write). torch writes
+        without telling, and its caching allocator hands the address of a dead
+        tensor to a new one: every such array is checked here before a
+        collision -- the tensor must still be the one that was zeroed and no
+        in-place operation of torch may have touched it since (its version
+        counter); otherwise the library is told (lbmi_hydro_field_dirty)."""
+        for ptr, (ref, version) in list(self._zeroed.items()):
+            t = ref()
+            if t is None or t.data_ptr() != ptr or t._version != version:
+                _l.check(self._lib.lbmi_hydro_field_dirty(
+                    self._h, ctypes.c_void_p(ptr)))
+                del self._zeroed[ptr]
+
     def lb_collide(self, hydro=None):
+        self._zeros_still_hold()
         h = hydro.ptrs() if hydro is not None else None
         _l.check(self._lib.lbmi_lb_collide(
             self._h, ctypes.byref(h) if h is not None else None))
@@ -212,6 +236,7 @@ class LB:
 
     def run(self, hydro=None, nsteps=1):
         """nsteps x (lb_collide, lb_halo, lb_propagation) in one foreign call."""
+        self._zeros_still_hold()
         h = hydro.ptrs() if hydro is not None else None
         _l.check(self._lib.lbmi_lb_run(
             self._h, ctypes.byref(h) if h is not None else None, int(nsteps)))
@@ -276,6 +301,10 @@ class LB:
         ncomp = 1 if field.dim() == 3 else field.shape[0]
         a = (ctypes.c_double * 3)(*([float(v) for v in values] + [0.0] * 3)[:3])
         _l.check(self._lib.lbmi_hydro_field_set(self._h, _ptr(field), ncomp, a))
+        if all(float(v) == 0.0 for v in values[:ncomp]):
+            self._zeroed[field.data_ptr()] = (weakref.ref(field), field._version)
+        else:
+            self._zeroed.pop(field.data_ptr(), None)
 
     def density(self):
         """lbmi_lb_density: rho of the interior sites, (nlocal) array."""
@@ -314,6 +343,7 @@ class LB:
 
     def hydro_field_dirty(self, field):
         """Somebody outside the library has written to this device field."""
+        self._zeroed.pop(field.data_ptr(), None)
         _l.check(self._lib.lbmi_hydro_field_dirty(self._h, _ptr(field)))
 
     def field_halo_n(self, data, nswap):

@@ -125,6 +125,7 @@ SYMBOLS = [
                                 ctypes.POINTER(FeSymm)]),
     ("lbmi_lb_memcpy_h2d", _i, [_vp, _vp]),
     ("lbmi_lb_memcpy_d2h", _i, [_vp, _vp]),
+    ("lbmi_lb_dirty", _i, [_vp]),
     ("lbmi_lb_moments", _i, [_vp, _vp, _pd]),
     ("lbmi_lb_density", _i, [_vp, _vp]),
     ("lbmi_field_stats", _i, [_vp, _vp, _vp, _pd]),

@@ -1090,7 +1090,13 @@ int main(int argc, char ** argv) {
 #ifdef _OPENMP
       nthreads = omp_get_max_threads();
 #endif
+      /* the hydro housekeeping of ludwig.c's loop belongs to the step: the
+       * force field is zeroed at its start (ludwig.c:537), the velocity before
+       * the collision (ludwig.c:791) */
+      const double zero3[3] = {0.0, 0.0, 0.0};
       /* one untimed warm-up step */
+      hydro_f_zero(hydro, zero3);
+      hydro_u_zero(hydro, zero3);
       lb_collide(lb, hydro, map, noise, NULL, NULL);
       lb_halo(lb);
       lb_propagation(lb);
@@ -1098,6 +1104,8 @@ int main(int argc, char ** argv) {
       double tall = wtime();
       for (int n = 0; n < c.nsteps; n++) {
 	t0 = wtime();
+	hydro_f_zero(hydro, zero3);
+	hydro_u_zero(hydro, zero3);
 	lb_collide(lb, hydro, map, noise, NULL, NULL);
 	t1 = wtime(); tc += t1 - t0; t0 = t1;
 	lb_halo(lb);

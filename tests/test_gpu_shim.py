@@ -51,6 +51,19 @@ def _compare(out, g, nhalo):
 M10_CASES = [c for c in mg.CASES if c[4] == "m10"]
 
 
+def _env(mode, **extra):
+    """The child's environment: LBMI_MODE = mode, or unset for None (the
+    binding chooses: fused until something needs the reference's state between
+    lb_collide and lb_propagation); no other LBMI_* switch unless given."""
+    env = dict(os.environ)
+    for k in ("LBMI_MODE", "LBMI_FE", "LBMI_HYDRO", "LBMI_REPORT"):
+        env.pop(k, None)
+    if mode is not None:
+        env["LBMI_MODE"] = mode
+    env.update(extra)
+    return env
+
+
 @pytest.mark.parametrize("case", M10_CASES, ids=[c[0] for c in M10_CASES])
 def test_reference_hip_target_reproduces_its_cpu_fixtures(case):
     """No binding: the reference's TargetDP kernels on the MI355X against the
@@ -67,15 +80,17 @@ def test_reference_hip_target_reproduces_its_cpu_fixtures(case):
     _compare(out, load_golden(case[0]), case[3])
 
 
-@pytest.mark.parametrize("mode", ["eager", "halo", "fused"])
+@pytest.mark.parametrize("mode", ["eager", "halo", "fused", None])
 @pytest.mark.parametrize("case", mg.CASES, ids=[c[0] for c in mg.CASES])
 def test_shim_bound_reference_reproduces_the_fixtures(case, mode):
     """liblbmi behind lb_collide / lb_halo / lb_propagation / lb_memcpy of the
     reference, in every LBMI_MODE: the driver's dumps after the first collide,
     halo, propagation and after all steps equal the fixtures (the copies to
-    the host go through the binding's flush)."""
+    the host go through the binding's flush). None: no LBMI_* variable set --
+    fused, rho and u on demand (the dumps of hydro->rho, u come through the
+    bound hydro_memcpy, which has them formed first)."""
     exe = _exe(case[1], shim=True)
-    env = dict(os.environ, LBMI_MODE=mode)
+    env = _env(mode)
     with tempfile.TemporaryDirectory() as tmp:
         out = mg.run_case(case, tmp, exe=exe, env=env)
     _compare(out, load_golden(case[0]), case[3])
@@ -84,7 +99,7 @@ def test_shim_bound_reference_reproduces_the_fixtures(case, mode):
 @pytest.mark.parametrize("case", mg.VISC_CASES, ids=[c[0] for c in mg.VISC_CASES])
 def test_shim_with_viscosity_model(case):
     exe = _exe(case[1], shim=True)
-    env = dict(os.environ, LBMI_MODE="fused")
+    env = _env(None)
     with tempfile.TemporaryDirectory() as tmp:
         out = mg.run_case(case, tmp, visc=1, exe=exe, env=env)
     _compare(out, load_golden(case[0]), case[3])
@@ -93,7 +108,7 @@ def test_shim_with_viscosity_model(case):
 WALLS = mg.WALL_CASES + mg.SLIP_CASES
 
 
-@pytest.mark.parametrize("mode", ["eager", "halo"])
+@pytest.mark.parametrize("mode", ["eager", "halo", None])
 @pytest.mark.parametrize("case", WALLS, ids=[c[0] for c in WALLS])
 def test_shim_wall_bbl(case, mode):
     """wall_bbl of the binding -- no-slip with moving walls, partial slip, the
@@ -101,7 +116,7 @@ def test_shim_wall_bbl(case, mode):
     the binding's lb_halo and lb_propagation."""
     nvel = case[1]
     exe = _exe(nvel, shim=True)
-    env = dict(os.environ, LBMI_MODE=mode)
+    env = _env(mode)
     with tempfile.TemporaryDirectory() as tmp:
         out = mg.run_wall_case(case, tmp, exe=exe, env=env)
     g = load_golden(case[0])
@@ -128,7 +143,7 @@ def test_shim_lb_io_write_and_read(case, tmp_path):
     nvel, n, timestep = case[1], case[2], case[3]
     ndist = case[4] if len(case) > 4 else 1
     exe = _exe(nvel, shim=True)
-    env = dict(os.environ, LBMI_MODE="fused")
+    env = _env(None)
     out = mg.run_io_case(case, str(tmp_path), exe=exe, env=env)
     g = np.load(os.path.join(HERE, "golden", case[0] + ".npz"))
     assert str(out["metadata"]) == str(g["metadata"])
@@ -150,26 +165,27 @@ def _compare_fe(out, g):
         assert relmax(interior(out[key], 1), interior(g[key], 1)) < 1e-12, key
 
 
-@pytest.mark.parametrize("mode", ["eager", "halo", "fused"])
+@pytest.mark.parametrize("mode", ["eager", "halo", None])
 @pytest.mark.parametrize("case", mg.BINARY_CASES, ids=[c[0] for c in mg.BINARY_CASES])
 def test_shim_two_distribution_step(case, mode):
     """free_energy symmetric_lb inside the reference: phi_lb_to_field,
     field_halo, field_grad_compute, hydro_u_zero, lb_collide (binary), lb_halo,
     lb_propagation -- all through the binding (halo: the propagation of both
-    distributions is folded into the next collision)."""
+    distributions is folded into the next collision; None = no LBMI_* variable
+    set: fused, the halo swap of both deferred as well)."""
     exe = _exe(case[1], shim=True)
-    env = dict(os.environ, LBMI_MODE=mode)
+    env = _env(mode)
     with tempfile.TemporaryDirectory() as tmp:
         out = mg.run_binary_case(case, tmp, exe=exe, env=env)
     _compare_fe(out, load_golden(case[0]))
 
 
-@pytest.mark.parametrize("mode", ["eager", "halo", "fused"])
+@pytest.mark.parametrize("mode", ["eager", "halo", None])
 @pytest.mark.parametrize("case", mg.RELAX_CASES, ids=[c[0] for c in mg.RELAX_CASES])
 def test_shim_stress_relaxation(case, mode):
     """lb_collide with fe->use_stress_relaxation (symmetric free energy)."""
     exe = _exe(case[1], shim=True)
-    env = dict(os.environ, LBMI_MODE=mode)
+    env = _env(mode)
     with tempfile.TemporaryDirectory() as tmp:
         out = mg.run_relax_case(case, tmp, exe=exe, env=env)
     _compare_fe(out, load_golden(case[0]))
@@ -231,7 +247,7 @@ def _last(log, tag):
     return _floats(lines[-1])
 
 
-@pytest.mark.parametrize("mode", ["eager", "halo", "fused"])
+@pytest.mark.parametrize("mode", ["eager", "halo", None])
 @pytest.mark.parametrize("name", ["dist_1dp", "dist_3du"])
 def test_ludwig_application_with_the_binding(name, mode):
     """The reference's executable (main.c, ludwig.c main loop, its input
@@ -255,7 +271,7 @@ def test_ludwig_application_with_the_binding(name, mode):
             assert abs(a - b) <= 2e-8 * abs(b) + 1e-16
 
 
-@pytest.mark.parametrize("mode", ["eager", "halo", "fused"])
+@pytest.mark.parametrize("mode", ["eager", "halo", None])
 def test_ludwig_binary_fluid_droplet_with_the_binding(mode):
     """free_energy symmetric (finite difference, 27-point gradients, second
     order advection): one step of the relaxing droplet serial-symm-dr1. The
@@ -275,7 +291,7 @@ def test_ludwig_binary_fluid_droplet_with_the_binding(mode):
             assert abs(a - b) <= 2e-8 * abs(b) + 1e-16
 
 
-@pytest.mark.parametrize("mode", ["eager", "halo", "fused"])
+@pytest.mark.parametrize("mode", ["eager", "halo", "fused", None])
 @pytest.mark.parametrize("name", ["spin_lb1", "symm_dr2", "spin_fd1", "symm_pat"])
 def test_ludwig_application_more_regressions(name, mode):
     """spin_lb1: free_energy symmetric_lb (two distributions, ghost modes
@@ -311,15 +327,15 @@ def test_ludwig_duct_flow_between_walls(mode):
     reference's host link arrays, momentum into wall->target->fnet) and
     lb_propagation through the binding, the reference's own
     wall_set_wall_distributions in between; fluid and wall momentum and the
-    velocity extrema of the reference's log. None: LBMI_MODE unset (= halo).
-    fused: the binding notices the wall links at the first
-    wall_set_wall_distributions and continues in halo mode.
+    velocity extrema of the reference's log. fused, and None (LBMI_MODE unset:
+    the binding starts in fused by itself): the binding notices the wall links
+    at the first wall_set_wall_distributions and continues in halo mode.
     (Round 1 skipped this case after one GPU memory fault; the cause --
     lb->target->param never uploaded, so wall_setu_kernel wrote in front of
     f -- is in DESIGN.md section 8 and tests/test_duct_fault_replay.py.)"""
     ref = _json.load(open(os.path.join(HERE, "golden", "regression_app_extra.json")))["rect_ct1"]
     log = _ludwig("rect_ct1.inp", mode)
-    assert ("LBMI_MODE=fused -> halo" in log) == (mode == "fused")
+    assert ("execution mode fused -> halo" in log) == (mode in ("fused", None))
     rho = _last(log, "[rho]")
     assert rho[0] == ref["rho"][0]
     assert abs(rho[3] - ref["rho"][3]) < 2e-11 and abs(rho[4] - ref["rho"][4]) < 2e-11
@@ -332,7 +348,7 @@ def test_ludwig_duct_flow_between_walls(mode):
             assert abs(a - b) <= 2e-7 * abs(b) + 1e-14
 
 
-@pytest.mark.parametrize("mode", ["eager", "halo", "fused"])
+@pytest.mark.parametrize("mode", ["eager", "halo", None])
 def test_ludwig_droplet_twenty_coupled_steps(mode):
     """d3q19-io/iodrop-mpi1-io1: twenty coupled steps of the relaxing droplet
     (the free-energy force and the Cahn-Hilliard update are the reference's
@@ -431,6 +447,48 @@ def test_the_free_energy_binding_leaves_other_cases_to_the_reference():
     assert "bound (LBMI_FE=1)" not in log
     rho = _last(log, "[rho]")
     assert rho[0] == ref["rho"][0] and abs(rho[2] - ref["rho"][2]) <= 1e-12
+
+
+def _policy(inp, extra_env=None):
+    """(mode at exit, who chose it, lazy collisions, collisions) of an
+    application run, from the LBMI_REPORT=1 line of the binding."""
+    exe = os.path.join(REF, "ludwig_hip_d3q19_shim")
+    env = _env(None, LBMI_REPORT="1", **(extra_env or {}))
+    import shutil
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(os.path.join(INPUTS, inp), os.path.join(tmp, "input"))
+        r = _sp.run([exe], cwd=tmp, env=env, capture_output=True, text=True,
+                    timeout=600)
+    assert r.returncode == 0 and "Ludwig finished normally." in r.stdout, r.stderr[-2000:]
+    m = _re.search(r"liblbmi report: execution mode (\w+) \(([^)]*)\); rho, u on "
+                   r"demand in (\d+) of (\d+) collisions", r.stderr)
+    assert m, r.stderr[-2000:]
+    return m.group(1), m.group(2), int(m.group(3)), int(m.group(4)), r.stdout
+
+
+@pytest.mark.parametrize("inp,mode,lazy", [
+    ("dist_3du.inp", "fused", "all"),    # plain single fluid: the headline path
+    ("rect_ct1.inp", "halo", "all"),     # wall links: halo; nobody reads rho, u on the device
+    ("symm_dr1.inp", "fused", "none"),   # free energy: advection reads u every step
+    ("symm_dr2.inp", "fused", "none"),   # + a viscosity model
+    ("spin_lb1.inp", "fused", "none"),   # two distributions
+])
+def test_an_unconfigured_run_is_fused_and_lazy_until_a_consumer_shows(inp, mode, lazy):
+    """No LBMI_* variable but LBMI_REPORT: the binding starts every run in
+    fused with rho, u on demand and demotes itself per consumer it detects
+    (walls -> halo; free energy, viscosity model, two distributions -> rho, u
+    stored by every collision). The statistics are checked by the application
+    tests above with the same environment; here: what the run ended up as."""
+    got_mode, who, nlazy, ncollide, _ = _policy(inp)
+    assert who == "chosen by the binding"
+    assert got_mode == mode
+    assert ncollide > 0
+    assert nlazy == (ncollide if lazy == "all" else 0)
+
+
+def test_lbmi_hydro_store_overrides_the_default():
+    got_mode, who, nlazy, ncollide, _ = _policy("dist_3du.inp", {"LBMI_HYDRO": "store"})
+    assert got_mode == "fused" and nlazy == 0 and ncollide > 0
 
 
 @pytest.mark.parametrize("mode", ["halo", "fused"])
