@@ -99,9 +99,13 @@ def parse():
                     help="fd_gradient_calculation 3d_7pt_fluid | 3d_27pt_fluid")
     ap.add_argument("--fe-order", type=int, default=1, choices=[1, 2, 3, 4],
                     help="fd_advection_scheme_order")
-    ap.add_argument("--fe-route", default="phi", choices=["phi", "grad"],
-                    help="phi: force + Cahn-Hilliard in one pass straight from "
-                    "phi; grad: gradient arrays first (lbmi_field_grad), then "
+    ap.add_argument("--fe-route", default="step", choices=["step", "phi", "grad"],
+                    help="step: lbmi_symmetric_lb_step, the whole coupled step "
+                    "in one call (one kernel in the steady state: the force "
+                    "never leaves the registers; needs 7-point gradients, one "
+                    "GPU; falls back to phi otherwise); phi: force + "
+                    "Cahn-Hilliard in one pass straight from phi, then the LB "
+                    "step; grad: gradient arrays first (lbmi_field_grad), then "
                     "the one pass reading them")
     ap.add_argument("--fe-halos", type=int, default=0,
                     help="1: keep the field halo swaps of phi and u (the "
@@ -415,8 +419,17 @@ def main():
             fe["delsq"] = torch.zeros(lb.nall, dtype=torch.float64,
                                       device=lb.device)
         lb.fe_scheme_set(args.fe_grad, args.fe_order)
+        if args.fe_route == "step" and (world > 1 or args.selfring or args.fe_halos
+                                        or args.mode != "fused"):
+            args.fe_route = "phi"
         fe["periodic"] = (world == 1 and not args.selfring
-                          and args.fe_route == "phi" and not args.fe_halos)
+                          and args.fe_route in ("phi", "step") and not args.fe_halos)
+        if args.fe_route == "step":
+            # u of the previous collision / of this one: two arrays, swapped
+            fe["u2"] = torch.zeros_like(hydro.u)
+            # the thermodynamic force is the only contribution and stays in
+            # registers: the array is zeroed through the library (not read)
+            lb.hydro_field_set(hydro.force, (0.0, 0.0, 0.0))
         torch.cuda.synchronize()
 
     def fe_step():
@@ -448,6 +461,15 @@ def main():
         fe["phi"], fe["phi2"] = fe["phi2"], fe["phi"]
 
     def one_step():
+        if fe is not None and args.fe_route == "step":
+            # ludwig.c:537-860 in one call: force, Cahn-Hilliard, lb_collide,
+            # lb_halo, lb_propagation
+            uprev = hydro.u
+            hydro.u, fe["u2"] = fe["u2"], hydro.u
+            lb.symmetric_lb_step(hydro, uprev, fe["a"], fe["b"], fe["kappa"],
+                                 fe["mobility"], fe["phi"], fe["phi2"])
+            fe["phi"], fe["phi2"] = fe["phi2"], fe["phi"]
+            return
         if fe is not None:
             fe_step()
         lb.step(hydro)
@@ -584,7 +606,15 @@ def main():
                 "launches_sampled": "every %d-th of %d" % (args.timing_period,
                                                           args.steps),
             }
-            if args.hydro == "1":
+            if fe is not None and args.fe_route == "step":
+                # the one kernel of the binary-fluid step: beside the
+                # distributions rho, u stored (32 B), u of the previous step
+                # (24 B) and phi in and out (16 B)
+                roofline["kernel"] = "k_symm_lb_step"
+                roofline["achieved_with_hydro_io"] = round(
+                    1e-9 * (pop_bytes + 72) * local_sites / t_launch, 1)
+                roofline["bytes_per_lup_with_hydro_io"] = pop_bytes + 72
+            elif args.hydro == "1":
                 roofline["achieved_with_hydro_io"] = round(
                     1e-9 * (pop_bytes + 56) * local_sites / t_launch, 1)
                 roofline["bytes_per_lup_with_hydro_io"] = pop_bytes + 56
@@ -641,7 +671,10 @@ def main():
                              "0": "no hydro arrays"}[args.hydro],
                 "free_energy": args.fe if args.fe == "none" else
                 "%s (%d-point gradients, advection order %d, from %s%s)"
-                % (args.fe, args.fe_grad, args.fe_order, args.fe_route,
+                % (args.fe, args.fe_grad, args.fe_order,
+                   {"step": "phi inside the LB kernel: force, Cahn-Hilliard "
+                    "update and collision of a site by one thread "
+                    "(lbmi_symmetric_lb_step)"}.get(args.fe_route, args.fe_route),
                    ", periodic wrap by index instead of field halos"
                    if fe["periodic"] else ""),
                 "decomposition": "x-slab %d_1_1" % world

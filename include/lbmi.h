@@ -572,6 +572,32 @@ int lbmi_symmetric_step_periodic(lbmi_t * lb, double a, double b,
 				 double * force, double * phi_out,
 				 int accumulate);
 
+/* One whole time step of the binary fluid with the finite-difference order
+ * parameter, as ludwig.c:537-860 runs it for free_energy symmetric:
+ *   hydro_f_zero, phi_force_calculation (phi_force.c:74-136),
+ *   phi_cahn_hilliard (phi_cahn_hilliard.c:206-284; advects with the u of
+ *   the previous collision), lb_collide, lb_halo, lb_propagation
+ * on ONE rank with periodic boundaries. phi -> phi_out as in
+ * lbmi_symmetric_step; u_prev (3*nsite) = the velocities the previous
+ * collision stored, hydro->u (another array) receives those of this one --
+ * the caller swaps the two like phi and phi_out -- and hydro->rho the
+ * densities (NULL: not stored). hydro->force must be NULL or known to hold
+ * zeros (lbmi_hydro_field_set): the thermodynamic force is the only
+ * contribution and is not stored anywhere. Neither phi nor u needs a halo.
+ * In the steady state of LBMI_MODE_FUSED (D3Q19, M10 or BGK, 7-point
+ * gradients of lbmi_fe_scheme_set, any advection order 1..4, no
+ * fluctuations, nlocal >= 4) the step is ONE kernel: the thread that
+ * collides a site evaluates its force and its Cahn-Hilliard update from the
+ * 25 values of phi around it while its distributions are on their way --
+ * 376 B per site and step instead of 424 B in two dependent passes. In any
+ * other state or configuration the same results come from the separate calls
+ * (identical to rounding, tests/test_gpu_fe.py). Afterwards the handle is
+ * where lbmi_lb_propagation leaves it. */
+int lbmi_symmetric_lb_step(lbmi_t * lb, const lbmi_hydro_t * hydro,
+			   const double * u_prev, double a, double b,
+			   double kappa, double mobility, const double * phi,
+			   double * phi_out);
+
 /* The same single pass, with the gradients taken from the arrays grad and
  * delsq of lbmi_field_grad (valid on the interior and one layer around it)
  * instead of re-evaluated from phi: the cheaper route for the 27-point

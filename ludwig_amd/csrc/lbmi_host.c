@@ -99,6 +99,8 @@ struct lbmi_s {
   /* free-energy sector: gradient stencil (7 | 27), advection order (1..4) */
   int grad_npt;
   int adv_order;
+  double * fe_force;                 /* lbmi_symmetric_lb_step off the fused
+					route: the thermodynamic force */
 
   /* walls: links (device), their host copy, momentum accounting */
   int nlink;
@@ -447,6 +449,7 @@ int lbmi_free(lbmi_t * lb) {
   }
   if (lb->mom_work) hipFree(lb->mom_work);
   if (lb->mom_out) hipFree(lb->mom_out);
+  if (lb->fe_force) hipFree(lb->fe_force);
   lbmi_wall_release(lb);
   if (lb->wall_err) hipHostFree(lb->wall_err);
   lbmi_run_graph_release(lb);
@@ -3201,6 +3204,118 @@ int lbmi_symmetric_step_periodic(lbmi_t * lb, double a, double b,
 			     kappa, mobility, phi, NULL, NULL, u, force,
 			     phi_out, accumulate, 1, lb->stream));
   return 0;
+}
+
+/* One complete step of the binary fluid with the finite-difference order
+ * parameter (ludwig.c:537-860 for free_energy symmetric): thermodynamic force,
+ * Cahn-Hilliard update, lb_collide, lb_halo, lb_propagation. In the steady
+ * state of LBMI_MODE_FUSED on one rank that is ONE launch (k_symm_lb_step);
+ * anywhere else the same results come from the separate calls. */
+
+int lbmi_symmetric_lb_step(lbmi_t * lb, const lbmi_hydro_t * hydro,
+			   const double * u_prev, double a, double b,
+			   double kappa, double mobility, const double * phi,
+			   double * phi_out) {
+  lbmi_hydro_t hy;
+  int fused;
+  if (lb == NULL || hydro == NULL || !u_prev || !phi || !phi_out) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  }
+  if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+  if (phi_out == phi) return lbmi_fail(LBMI_ERR_ARGUMENT, "phi_out aliases phi");
+  if (hydro->u == NULL || hydro->u == u_prev) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_symmetric_lb_step: hydro->u must "
+		     "be an array other than u_prev (the neighbours' old "
+		     "velocities are read while the new ones are written)");
+  }
+  if (lb->opts.ndist != 1) return lbmi_fail(LBMI_ERR_STATE, "needs ndist = 1");
+  if (lb->kp.nhalo < 2) return lbmi_fail(LBMI_ERR_ARGUMENT, "needs nhalo >= 2");
+  if (lb->opts.cartsz > 1 || lb->have_comm) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "lbmi_symmetric_lb_step: one rank "
+		     "(slabs: field halos, lbmi_symmetric_step, the LB calls)");
+  }
+  for (int d = 0; d < 3; d++) {
+    if (lb->kp.nlocal[d] < lb->kp.nhalo) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "nlocal[%d] < nhalo", d);
+    }
+  }
+  if (hydro->force != NULL && !lbmi_known_zero(lb, hydro->force)) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_symmetric_lb_step: hydro->force "
+		     "must be NULL or known to hold zeros (lbmi_hydro_field_set): "
+		     "the thermodynamic force goes from the registers of the "
+		     "thread that evaluates it into its collision; with other "
+		     "contributions use lbmi_symmetric_step + lbmi_lb_collide");
+  }
+  HIPCHECK(hipSetDevice(lb->device));
+  {
+    /* u_prev is read: formed first if a lazy collision still owes it */
+    int ifail = lbmi_hydro_touch(lb, u_prev, NULL);
+    if (ifail) return ifail;
+  }
+
+  hy = *hydro;
+  hy.force = NULL;
+
+  fused = (lb->opts.mode == LBMI_MODE_FUSED && lb->pending_prop &&
+	   lb->pending_halo && !lb->layout_swapped && lb->noise_state == NULL &&
+	   lb->grad_npt == 7 && lb->opts.nvel == 19 &&
+	   (lb->kp.scheme == LBMI_RELAXATION_M10 ||
+	    lb->kp.scheme == LBMI_RELAXATION_BGK) &&
+	   lb->kp.nlocal[X] >= 4 && lb->kp.nlocal[Y] >= 4 && lb->kp.nlocal[Z] >= 4 &&
+	   hydro->nsite == 0);
+
+  if (fused) {
+    lbmi_hydro_dev_t h = lbmi_hydro_dev(&hy);
+    int lay = lbmi_blocked_ok(lb) ? (lb->blocked ? 2 : 1) : 0;
+    int ifail;
+    if (lay == 0 && lb->blocked) {
+      ifail = lbmi_unblock(lb);
+      if (ifail) return ifail;
+    }
+    if (lb->nt_store_mode >= 0) {
+      lb->kp.nt_store = lb->nt_store_mode;
+    }
+    else {
+      size_t bytes = 2*sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel;
+      lb->kp.nt_store = (bytes > ((size_t) 256 << 20)) ? 1 : 0;
+    }
+    lb->hydro_stale = 0;              /* superseded: this collision stores */
+    lbmi_known_zero_drop(lb, h.rho);
+    lbmi_known_zero_drop(lb, h.u);
+    lbmi_known_zero_drop(lb, phi_out);
+    ifail = lbmi_time_begin(lb);
+    if (ifail) return ifail;
+    KCHECK(lbmi_k_symm_lb_step(&lb->kp, lb->f, lb->fprime, &h, a, b, kappa,
+			       mobility, lb->adv_order, phi, u_prev, phi_out,
+			       lay, lb->stream));
+    ifail = lbmi_time_end(lb);
+    if (ifail) return ifail;
+    lb->blocked = (lay != 0);
+    lbmi_swapf(lb);
+    /* lb_halo and lb_propagation of this step: pending again, as they were */
+    return 0;
+  }
+
+  /* Anywhere else (first step after a flush, another mode, 27-point
+   * gradients, TRT, D3Q27, fluctuations ...): the separate calls. The force
+   * needs an array: one of the handle's own. */
+  {
+    int ifail;
+    const int lazy = lb->hydro_lazy;
+    if (lb->fe_force == NULL) {
+      HIPCHECK(hipMalloc((void **) &lb->fe_force,
+			 3*sizeof(double)*(size_t) lb->kp.nsite));
+    }
+    KCHECK(lbmi_k_symm_fe_step(&lb->kp, lb->grad_npt, lb->adv_order, a, b,
+			       kappa, mobility, phi, NULL, NULL, u_prev,
+			       lb->fe_force, phi_out, 0, 1, lb->stream));
+    hy.force = lb->fe_force;
+    hy.nsite = 0;
+    lb->hydro_lazy = 0;               /* the next step reads this u */
+    ifail = lbmi_one_step(lb, &hy);
+    lb->hydro_lazy = lazy;
+    return ifail;
+  }
 }
 
 int lbmi_symmetric_step_grad(lbmi_t * lb, double a, double b, double kappa,

@@ -177,6 +177,18 @@ int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, int npt, int order,
 			double * phi_out, int accumulate, int wrap,
 			void * stream);
 
+/* The whole binary-fluid step (symmetric free energy, 7-point gradients,
+ * D3Q19, M10 or BGK) in one pass on one rank: thermodynamic force and
+ * Cahn-Hilliard update of the site from phi and uprev (u of the previous
+ * collision), pull + collision with that force; rho, u of this collision to
+ * h->rho, h->u (h->u != uprev); h->force is not used. lay as
+ * lbmi_k_propagate_collide. */
+int lbmi_k_symm_lb_step(const lbmi_kparam_t * kp, const double * f,
+			double * fprime, const lbmi_hydro_dev_t * h,
+			double a, double b, double kappa, double mobility,
+			int order, const double * phi, const double * uprev,
+			double * phi_out, int lay, void * stream);
+
 /* k_collide with fe->use_stress_relaxation for the symmetric free energy */
 int lbmi_k_collide_fe(const lbmi_kparam_t * kp, double * f,
 		      const lbmi_hydro_dev_t * h, double a, double b,

@@ -902,11 +902,12 @@ void pc_pull(const lbmi_kparam_t & kp, const double * __restrict__ f,
  * step has no hydro traffic (no force field to read, rho and u not wanted
  * now): a variant of its own, so that it is also a kernel of its own name in
  * a profile */
-template <int NVEL, int SCHEME, bool WB, bool NTS, bool HIO, bool XB, bool NZ = false>
+template <int NVEL, int SCHEME, bool WB, bool NTS, bool HIO, bool XB, bool NZ = false, bool FEXT = false>
 __device__ __forceinline__
 void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
 		      const lbmi_hydro_dev_t & h, int i,
-		      PulledSite<NVEL> & ps, const lbmi_xbuf_t & xb) {
+		      PulledSite<NVEL> & ps, const lbmi_xbuf_t & xb,
+		      double fx = 0.0, double fy = 0.0, double fz = 0.0) {
 
   const size_t ns = (size_t) kp.nsite;
   bool active = ps.s.interior;
@@ -917,7 +918,14 @@ void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
 
   if (active) {
     double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
-    if constexpr (HIO) {
+    if constexpr (FEXT) {
+      /* the force of the site handed over in registers (k_symm_lb_step: the
+       * thermodynamic force, which the reference adds into hydro->force) */
+      frc[0] += fx;
+      frc[1] += fy;
+      frc[2] += fz;
+    }
+    else if constexpr (HIO) {
       if (h.force) {
 	frc[0] += h.force[i];
 	frc[1] += h.force[hstride(kp, h) + i];
@@ -2139,6 +2147,203 @@ void k_symm_fe_step_tiled(lbmi_kparam_t kp, Symm q, double mobility, int order,
     em = ec;
     ec = ep;
   }
+}
+
+/* ---- k_symm_lb_step: the whole binary-fluid step of BASELINE config 4 in ONE pass ----
+ *
+ * ludwig.c:537-860 with free_energy symmetric (finite difference), per site:
+ *   hydro_f_zero, phi_force_calculation   F = -d_b P_ab(phi_t)      (phi_force.c:74-136)
+ *   phi_cahn_hilliard                     phi_t+1 from phi_t, u_t-1 (phi_cahn_hilliard.c:206-284)
+ *   lb_collide (+ lb_halo, lb_propagation of the step before, as k_propagate_collide)
+ * The separate passes move, beside the 304 B of the distributions, the force
+ * twice (24 B written, 24 B read) and u twice (24 B written by the collision,
+ * 24 B read by the advection), phi twice: 424 B per site and step, and the
+ * free-energy pass is bound by the latency of its dependent loads, not by
+ * HBM (profiles/r02_fe_pass_counters.txt). Here the thermodynamic force never
+ * leaves the registers: the thread that collides a site has just evaluated
+ * it from the 25 values of phi around the site (|dx| + |dy| + |dz| <= 2, from
+ * L2: neighbouring lanes share all but one of them), and the same values give
+ * the six Cahn-Hilliard fluxes. Their latency hides behind the 19 pulls of the
+ * distributions, which are in flight meanwhile. 304 + 32 (rho, u) + 24 (u of
+ * the previous step) + 16 (phi in, out) = 376 B per site.
+ *
+ * The advection reads u_t-1 of the six neighbours while the collisions of this
+ * launch write u_t: two arrays, u_prev (read) and h.u (written), swapped by the
+ * caller like phi and phi_out. Single rank: every access across a periodic
+ * face goes to the image inside the domain (no halo of f, phi or u needed).
+ * Arithmetic: that of k_symm_fe_step_tiled<false, 7, true> and of the
+ * collision, expression for expression. */
+
+__host__ __device__ constexpr int iabs_c(int a) { return (a < 0) ? -a : a; }
+
+/* position of (dx, dy, dz) among the 25 points, and its inverse */
+__host__ __device__ constexpr int p25(int dx, int dy, int dz) {
+  int n = 0;
+  for (int a = -2; a <= 2; a++) {
+    for (int b = -2; b <= 2; b++) {
+      for (int c = -2; c <= 2; c++) {
+	if (iabs_c(a) + iabs_c(b) + iabs_c(c) > 2) continue;
+	if (a == dx && b == dy && c == dz) return n;
+	n += 1;
+      }
+    }
+  }
+  return -1;
+}
+
+__host__ __device__ constexpr int q25(int m, int comp) {
+  int n = 0;
+  for (int a = -2; a <= 2; a++) {
+    for (int b = -2; b <= 2; b++) {
+      for (int c = -2; c <= 2; c++) {
+	if (iabs_c(a) + iabs_c(b) + iabs_c(c) > 2) continue;
+	if (n == m) return (comp == 0) ? a : ((comp == 1) ? b : c);
+	n += 1;
+      }
+    }
+  }
+  return 0;
+}
+
+static_assert(p25(2, 0, 0) == 24 && p25(0, 0, 0) == 12 && q25(24, 0) == 2, "25 points");
+
+/* fe_eval at the site (OX, OY, OZ) away, from the 25 values in registers
+ * (7-point gradients: grad7 + fe_eval, same expressions) */
+template <int OX, int OY, int OZ>
+__device__ __forceinline__
+FeSite fe_eval_reg(const Symm & q, const double (&ph)[25]) {
+  constexpr int ic = p25(OX, OY, OZ);
+  constexpr int ixp = p25(OX + 1, OY, OZ), ixm = p25(OX - 1, OY, OZ);
+  constexpr int iyp = p25(OX, OY + 1, OZ), iym = p25(OX, OY - 1, OZ);
+  constexpr int izp = p25(OX, OY, OZ + 1), izm = p25(OX, OY, OZ - 1);
+  static_assert(ic >= 0 && ixp >= 0 && ixm >= 0 && iyp >= 0 && iym >= 0 &&
+		izp >= 0 && izm >= 0, "site not inside the 25 points");
+  FeSite e;
+  const double xp = ph[ixp], xm = ph[ixm];
+  const double yp = ph[iyp], ym = ph[iym];
+  const double zp = ph[izp], zm = ph[izm];
+  e.g[0] = 0.5*(xp - xm);
+  e.g[1] = 0.5*(yp - ym);
+  e.g[2] = 0.5*(zp - zm);
+  const double d2 = xp + xm + yp + ym + zp + zm - 6.0*ph[ic];
+  const double p = ph[ic];
+  e.p0 = 0.5*q.a*p*p + 0.75*q.b*p*p*p*p - q.kappa*p*d2
+    - 0.5*q.kappa*(e.g[0]*e.g[0] + e.g[1]*e.g[1] + e.g[2]*e.g[2]);
+  e.mu = q.a*p + q.b*p*p*p - q.kappa*d2;
+  return e;
+}
+
+template <int NVEL, int SCHEME, int LAY>
+__global__ __launch_bounds__(BLOCK, LBMI_WAVES)
+void k_symm_lb_step(lbmi_kparam_t kp, const double * __restrict__ f,
+		    double * __restrict__ fp, lbmi_hydro_dev_t h, Symm q,
+		    double mobility, int order,
+		    const double * __restrict__ phi,
+		    const double * __restrict__ uprev,
+		    double * __restrict__ phi_out, int i0, int i1,
+		    unsigned nblk) {
+
+  static_assert(SPT == 1, "one site per thread");
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+
+  constexpr int ORD = LAY & 3;
+  constexpr int ALIGNV = (ORD == 0) ? LBMI_ALIGN : LBW;
+  const int i = (i0/ALIGNV)*ALIGNV + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+
+  const lbmi_xbuf_t none = {nullptr, nullptr, nullptr, nullptr};
+  const size_t ns = (size_t) kp.nsite;
+  const Site s = decode(kp, i);
+
+  /* the 25 values of phi and the nine of u first, then the pulls: the
+   * free-energy arithmetic runs while the distributions are on their way */
+  double ph[25];
+  double uc[3][3];
+  if (s.interior) {
+    /* offsets (in sites) of the neighbours at distance -2 .. +2 in each
+     * direction, across a periodic face: the image inside the domain */
+    int ox[5], oy[5], oz[5];
+    auto offsets = [&](int c, int n, int str, int (&o)[5]) {
+      /* c: 0 .. n - 1, the coordinate inside the local domain (n >= 4) */
+      static_for<0, 5>([&](auto K) {
+	constexpr int k = K - 2;
+	int t = k;
+	if (c + k < 0) t += n;
+	else if (c + k >= n) t -= n;
+	o[K] = t*str;
+      });
+    };
+    offsets(s.x - kp.nhalo, kp.nlocal[0], kp.strx, ox);
+    offsets(s.y - kp.nhalo, kp.nlocal[1], kp.stry, oy);
+    offsets(s.z - kp.nhalo, kp.nlocal[2], 1, oz);
+    static_for<0, 25>([&](auto N) {
+      constexpr int m = N;
+      constexpr int a = q25(m, 0), b = q25(m, 1), c = q25(m, 2);
+      ph[m] = phi[i + ox[a + 2] + oy[b + 2] + oz[c + 2]];
+    });
+    /* uc[id][0..2]: u_id at the site, at its + and at its - neighbour in id */
+    const int up[3] = {ox[3], oy[3], oz[3]};
+    const int um[3] = {ox[1], oy[1], oz[1]};
+    static_for<0, 3>([&](auto D) {
+      constexpr int id = D;
+      uc[id][0] = uprev[ns*id + i];
+      uc[id][1] = uprev[ns*id + (size_t) (i + up[id])];
+      uc[id][2] = uprev[ns*id + (size_t) (i + um[id])];
+    });
+  }
+
+  PulledSite<NVEL> ps;
+  pc_pull<NVEL, true, ORD == 2, false>(kp, f, 7, i, ps, none);
+
+  double frc[3] = {0.0, 0.0, 0.0};
+  if (s.interior) {
+    const FeSite ec = fe_eval_reg<0, 0, 0>(q, ph);
+    constexpr int icentre = p25(0, 0, 0);
+    const double phi0 = ph[icentre];
+    double fhi[3], flo[3];
+    static_for<0, 3>([&](auto D) {
+      constexpr int id = D;
+      constexpr int ex = (id == 0), ey = (id == 1), ez = (id == 2);
+      const FeSite hi = fe_eval_reg<ex, ey, ez>(q, ph);
+      const FeSite lo = fe_eval_reg<-ex, -ey, -ez>(q, ph);
+      /* F_a = -d_b P_ab, column id (pth_force_fluid_kernel's association) */
+      static_for<0, 3>([&](auto A) {
+	constexpr int ia = A;
+	const double c0 = ((ia == id) ? ec.p0 : 0.0) + q.kappa*ec.g[ia]*ec.g[id];
+	const double cp = ((ia == id) ? hi.p0 : 0.0) + q.kappa*hi.g[ia]*hi.g[id];
+	const double cm = ((ia == id) ? lo.p0 : 0.0) + q.kappa*lo.g[ia]*lo.g[id];
+	frc[ia] -= 0.5*(cp + c0);
+	frc[ia] += 0.5*(cm + c0);
+      });
+      constexpr int im2 = p25(-2*ex, -2*ey, -2*ez), ip2 = p25(2*ex, 2*ey, 2*ez);
+      constexpr int im1 = p25(-ex, -ey, -ez), ip1 = p25(ex, ey, ez);
+      const double ud0 = uc[id][0];
+      double pm2 = 0.0, pp2 = 0.0;
+      if (order > 2) {
+	pm2 = ph[im2];
+	pp2 = ph[ip2];
+      }
+      const double pm1 = ph[im1], pp1 = ph[ip1];
+      {
+	const double uf = 0.5*(ud0 + uc[id][1]);
+	double fl = adv_flux(order, false, uf, pm1, phi0, pp1, pp2);
+	fl -= mobility*(hi.mu - ec.mu);
+	fhi[id] = fl;
+      }
+      {
+	const double uf = 0.5*(ud0 + uc[id][2]);
+	double fl = adv_flux(order, id == 0, uf, pm2, pm1, phi0, pp1);
+	fl -= mobility*(ec.mu - lo.mu);
+	flo[id] = fl;
+      }
+    });
+    phi_out[i] = phi0 - (+ fhi[0] - flo[0] + fhi[1] - flo[1]
+			 + fhi[2] - flo[2]);
+  }
+
+  pc_collide_store<NVEL, SCHEME, ORD != 0, (LAY & 4) != 0, true, false, false, true>(
+      kp, fp, h, i, ps, none, frc[0], frc[1], frc[2]);
 }
 
 /* ---- two distributions: the symmetric_lb step (row f4) ------------------------
@@ -3414,6 +3619,62 @@ static void launch_fe_step(const lbmi_kparam_t * kp, int npt, int order,
 		       *kp, q, mobility, order, phi, grad, delsq, u, force,
 		       phi_out, r.i0, r.i1, r.nblk);
   }
+}
+
+/* k_symm_lb_step over the interior x planes; lay as lbmi_k_propagate_collide
+ * (0 SoA -> SoA, 1 SoA -> blocked, 2 blocked -> blocked; kp->nt_store bit 0:
+ * nontemporal stores of the blocked state) */
+
+template <int NVEL, int LAY>
+static int launch_symm_lb(const lbmi_kparam_t & kp, const double * f,
+			  double * fp, const lbmi_hydro_dev_t & h,
+			  const Symm & q, double mobility, int order,
+			  const double * phi, const double * uprev,
+			  double * phi_out, hipStream_t st) {
+  constexpr int ALIGNV = ((LAY & 3) == 0) ? LBMI_ALIGN : LBW;
+  const int i0 = kp.nhalo*kp.strx;
+  const int i1 = (kp.nhalo + kp.nlocal[0])*kp.strx;
+  const int i0a = (i0/ALIGNV)*ALIGNV;
+  const unsigned nblk = (unsigned) ((i1 - i0a + BLOCK - 1)/BLOCK);
+  dim3 grid(grid_for(nblk, (unsigned) kp.xcd_group)), block(BLOCK);
+  /* the occupancy cap of the fused kernel (launch_pc_hio) */
+  unsigned lds = (kp.lds_cap <= 65536 && nblk > 4096u) ? (unsigned) kp.lds_cap : 0u;
+  switch (kp.scheme) {
+  case LBMI_M10:
+    hipLaunchKernelGGL((k_symm_lb_step<NVEL, LBMI_M10, LAY>), grid, block, lds,
+		       st, kp, f, fp, h, q, mobility, order, phi, uprev,
+		       phi_out, i0, i1, nblk);
+    break;
+  case LBMI_BGK:
+    hipLaunchKernelGGL((k_symm_lb_step<NVEL, LBMI_BGK, LAY>), grid, block, lds,
+		       st, kp, f, fp, h, q, mobility, order, phi, uprev,
+		       phi_out, i0, i1, nblk);
+    break;
+  default:
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_symm_lb_step(const lbmi_kparam_t * kp, const double * f,
+				   double * fprime, const lbmi_hydro_dev_t * h,
+				   double a, double b, double kappa,
+				   double mobility, int order,
+				   const double * phi, const double * uprev,
+				   double * phi_out, int lay, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  const Symm q = {a, b, kappa};
+  if (kp->nvel != 19) return (int) hipErrorInvalidValue;
+  if (lay == 0) return launch_symm_lb<19, 0>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+#if LBMI_BLOCK*LBMI_SPT == 256
+  if (kp->nt_store & 1) {
+    if (lay == 1) return launch_symm_lb<19, 5>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+    if (lay == 2) return launch_symm_lb<19, 6>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+  }
+  if (lay == 1) return launch_symm_lb<19, 1>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+  if (lay == 2) return launch_symm_lb<19, 2>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+#endif
+  return (int) hipErrorInvalidValue;
 }
 
 extern "C" int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, int npt,

@@ -400,6 +400,17 @@ class LB:
             self._h, a, b, kappa, mobility, _ptr(phi), _ptr(u), _ptr(force),
             _ptr(phi_out), 1 if accumulate else 0))
 
+    def symmetric_lb_step(self, hydro, u_prev, a, b, kappa, mobility, phi, phi_out):
+        """lbmi_symmetric_lb_step: one whole step of the binary fluid
+        (force, Cahn-Hilliard, lb_collide, lb_halo, lb_propagation); in the
+        steady state of FUSED one kernel. u_prev: u of the previous
+        collision; hydro.u (another tensor) receives the new one."""
+        self._zeros_still_hold()
+        h = hydro.ptrs()
+        _l.check(self._lib.lbmi_symmetric_lb_step(
+            self._h, ctypes.byref(h), _ptr(u_prev), a, b, kappa, mobility,
+            _ptr(phi), _ptr(phi_out)))
+
     def symmetric_step_grad(self, a, b, kappa, mobility, phi, grad, delsq, u,
                             force, phi_out, accumulate=True):
         """symmetric_step with the gradients read from the arrays of

@@ -390,6 +390,66 @@ def test_lb_run_as_graph_equals_steps(nvel, scheme, own_stream):
         assert np.array_equal(a, b)
 
 
+def test_a_captured_run_does_not_outlive_what_its_launches_carried():
+    """lbmi_lb_collide joins state of the handle to the hydro object at the
+    moment of the call -- whether the force array is known to hold zeros,
+    whether rho and u are stored, the generator and temperature of the
+    fluctuations -- and a captured lbmi_lb_run (tune "graph") holds the
+    launches as they were captured. Each change between two runs must
+    re-capture: a force field zeroed through the library and then written
+    (reported dirty), the lazy switch flipped both ways, fluctuations switched
+    on, another temperature. Bit for bit against the same calls without the
+    graph."""
+    import ludwig_amd
+    import torch
+    n = (24, 12, 20)
+    p = lbo.make_param(19, n, 1, "m10", 0.1, 0.2)
+    f0 = lbo.init_synthetic(p)
+    nall = lbo.nall(p)
+    frc = 1e-6 * np.random.default_rng(5).standard_normal((3,) + nall)
+    nsite = int(np.prod(nall))
+    state0 = np.random.default_rng(6).integers(1, 2**31 - 1, size=(4, nsite)).astype(np.uint32)
+    out = []
+    for graph in (0, 1):
+        lb = ludwig_amd.LB(19, n, 1, mode=ludwig_amd.FUSED)
+        lb.relaxation_set("m10", 0.1, 0.2)
+        lb.tune("graph", graph)
+        hy = ludwig_amd.Hydro(lb.nall, lb.device, force=np.zeros_like(frc))
+        state = torch.from_numpy(state0.view(np.int32).copy()).to(lb.device)
+        torch.cuda.synchronize()
+        lb.lb_memcpy_h2d(f0)
+        rec = []
+        lb.hydro_field_set(hy.force, (0.0, 0.0, 0.0))   # known zero: not read
+        lb.run(hy, 8)
+        hy.force.copy_(torch.from_numpy(frc))           # written (the mirror reports it)
+        torch.cuda.synchronize()
+        lb.run(hy, 8)                                   # the captured launches skipped it
+        rec.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+        lb.tune("hydro_lazy", 1)
+        lb.run(hy, 8)
+        lb.tune("hydro_lazy", 0)                        # stored again from here
+        hy.u.zero_()
+        torch.cuda.synchronize()
+        lb.run(hy, 8)
+        lb.synchronize()
+        rec.append(interior(hy.u.cpu().numpy(), 1).copy())
+        lb.noise_set(state, 1e-5)                       # fluctuations on
+        lb.run(hy, 8)
+        lb.noise_set(state, 4e-5)                       # another temperature
+        lb.run(hy, 8)
+        lb.noise_set(None, 0.0)
+        lb.run(hy, 8)
+        rec.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+        rec.append(state.cpu().numpy().copy())
+        lb.free()
+        out.append(rec)
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    # and the changes did change something (the test would pass trivially)
+    assert np.abs(out[0][1]).max() > 0.0
+    assert not np.array_equal(out[0][3], state0.view(np.int32))
+
+
 @pytest.mark.parametrize("nlocal,nhalo", [((9, 7, 12), 1), ((16, 14, 14), 2), ((1, 5, 3), 1)])
 def test_field_stats_match_numpy(nlocal, nhalo):
     """lbmi_field_stats (cahn_stats_reduce, cahn_hilliard_stats.c:123-215):

@@ -222,6 +222,125 @@ def test_binary_fluid_steps_vs_oracle(npt, order):
     lb.free()
 
 
+@pytest.mark.parametrize("scheme", ["m10", "bgk"])
+@pytest.mark.parametrize("order", [1, 2, 3, 4])
+def test_one_kernel_binary_fluid_step_vs_oracle(order, scheme):
+    """lbmi_symmetric_lb_step: the whole step of BASELINE config 4 as ONE
+    kernel (force and Cahn-Hilliard update of a site evaluated by the thread
+    that collides it, u of the previous step from a second array) against
+    the oracle running the reference's order of calls (ludwig.c:537-860):
+    phi, the distributions, rho and u after every step, advection orders 1-4.
+    The first step after the copy-in runs the separate calls (nothing is
+    pending yet), the others the fused kernel: lbmi_lb_state says which."""
+    import ludwig_amd
+    import torch
+    nlocal, h, nsteps = (12, 10, 8), 2, 5
+    a, b, kappa, mob = -0.00625, 0.00625, 0.004, 1.25
+    p = lbo.make_param(19, nlocal, h, scheme, 0.1, 0.3, 1.0, (1e-6, -2e-6, 5e-7))
+    rng = np.random.default_rng(9)
+    phi0 = np.zeros(lbo.nall(p))
+    interior(phi0, h)[...] = 0.1 * rng.standard_normal(nlocal)
+    f0 = lbo.init_synthetic(p)
+
+    lb = ludwig_amd.LB(19, nlocal, h, mode=ludwig_amd.FUSED)
+    lb.relaxation_set(scheme, 0.1, 0.3)
+    lb.body_force_set((1e-6, -2e-6, 5e-7))
+    lb.fe_scheme_set(7, order)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device)
+    ua = hy.u
+    ub = torch.zeros_like(ua)
+    pa = _dev(lb, phi0)
+    pb = torch.zeros_like(pa)
+    lb.lb_memcpy_h2d(f0)
+
+    phi = phi0.copy()
+    f = f0.copy()
+    fp = np.zeros_like(f)
+    u = np.zeros((3,) + phi.shape)
+    rho = np.zeros(phi.shape)
+    for n in range(nsteps):
+        # oracle: the reference's sequence
+        force = np.zeros((3,) + phi.shape)
+        lbo.field_halo(p, phi, 2)
+        grad, delsq = lbo.grad(p, phi, 7)
+        lbo.symm_force(p, a, b, kappa, phi, grad, delsq, force)
+        lbo.field_halo(p, u, 1)
+        lbo.cahn_hilliard(p, a, b, kappa, mob, phi, delsq, u, order=order)
+        u[...] = 0.0
+        f, fp = lbo.step(p, f, fp, force, None, rho, u)
+        # device: one call; u_prev = what the last call stored
+        pending = lb.state()[1]
+        hy.u = ub if n % 2 == 0 else ua
+        lb.symmetric_lb_step(hy, ua if n % 2 == 0 else ub, a, b, kappa, mob, pa, pb)
+        pa, pb = pb, pa
+        assert pending == (1 if n > 0 else 0)
+        lb.synchronize()
+        torch.cuda.synchronize()
+        assert relmax(interior(_host(lb, pa), h), interior(phi, h)) < 1e-12, n
+        assert relmax(interior(hy.u.cpu().numpy(), h), interior(u, h)) < 1e-12, n
+        assert relmax(interior(hy.rho.cpu().numpy(), h), interior(rho, h)) < 1e-12, n
+    assert relmax(interior(lb.lb_memcpy_d2h(), h), interior(f, h)) < 1e-12
+    lb.free()
+
+
+@pytest.mark.parametrize("mode", ["eager", "fused_halo", "fused_soa", "inplace"])
+def test_binary_fluid_step_off_the_fused_route_is_the_same(mode):
+    """lbmi_symmetric_lb_step where the one-kernel form does not apply (other
+    execution modes; 27-point gradients; the SoA order of the deferred state is
+    a variant of the fused kernel): the separate calls behind the same entry
+    point, against the fused route of a FUSED handle."""
+    import ludwig_amd
+    import torch
+    nlocal, h, nsteps = (8, 12, 9), 2, 4
+    a, b, kappa, mob = -0.00625, 0.00625, 0.004, 1.25
+    p = lbo.make_param(19, nlocal, h, "m10", 0.1, 0.3)
+    rng = np.random.default_rng(10)
+    phi0 = np.zeros(lbo.nall(p))
+    interior(phi0, h)[...] = 0.1 * rng.standard_normal(nlocal)
+    f0 = lbo.init_synthetic(p)
+    modes = {"eager": ludwig_amd.EAGER, "fused_halo": ludwig_amd.FUSED_HALO,
+             "fused_soa": ludwig_amd.FUSED_SOA, "inplace": ludwig_amd.INPLACE}
+    out = []
+    for m in (ludwig_amd.FUSED, modes[mode]):
+        lb = ludwig_amd.LB(19, nlocal, h, mode=m)
+        lb.relaxation_set("m10", 0.1, 0.3)
+        lb.fe_scheme_set(7, 2)
+        hy = ludwig_amd.Hydro(lb.nall, lb.device)
+        ua, ub = hy.u, torch.zeros_like(hy.u)
+        pa, pb = _dev(lb, phi0), torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+        lb.lb_memcpy_h2d(f0)
+        for n in range(nsteps):
+            hy.u = ub if n % 2 == 0 else ua
+            lb.symmetric_lb_step(hy, ua if n % 2 == 0 else ub, a, b, kappa, mob, pa, pb)
+            pa, pb = pb, pa
+        lb.synchronize()
+        torch.cuda.synchronize()
+        out.append((interior(_host(lb, pa), h).copy(), interior(hy.u.cpu().numpy(), h).copy(),
+                    interior(lb.lb_memcpy_d2h(), h).copy()))
+        lb.free()
+    for x, y in zip(out[0], out[1]):
+        assert relmax(x, y) < 1e-13
+
+
+def test_binary_fluid_step_arguments():
+    import ludwig_amd
+    import torch
+    lb = ludwig_amd.LB(19, (8, 8, 8), 2, mode=ludwig_amd.FUSED)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device, force=np.ones((3,) + lb.nall))
+    pa = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    pb = torch.zeros_like(pa)
+    ub = torch.zeros_like(hy.u)
+    with pytest.raises(ludwig_amd.LbmiError):          # u aliases u_prev
+        lb.symmetric_lb_step(hy, hy.u, -1.0, 1.0, 1.0, 0.1, pa, pb)
+    with pytest.raises(ludwig_amd.LbmiError):          # phi_out aliases phi
+        lb.symmetric_lb_step(hy, ub, -1.0, 1.0, 1.0, 0.1, pa, pa)
+    with pytest.raises(ludwig_amd.LbmiError):          # a force field with contents
+        lb.symmetric_lb_step(hy, ub, -1.0, 1.0, 1.0, 0.1, pa, pb)
+    lb.hydro_field_set(hy.force, (0.0, 0.0, 0.0))      # known zero: accepted
+    lb.symmetric_lb_step(hy, ub, -1.0, 1.0, 1.0, 0.1, pa, pb)
+    lb.free()
+
+
 @pytest.mark.parametrize("name", golden_fe_names())
 def test_symmetric_step_equals_separate_kernels(name):
     import ludwig_amd

@@ -173,7 +173,9 @@ def test_force_known_to_be_zero_is_not_read(mode):
     lb.synchronize()
     torch.cuda.synchronize()
     assert float(hy.force.abs().max()) == 0.0
-    hy.force.copy_(torch.from_numpy(force))                    # a foreign writer
+    # a foreign writer the Python mirror cannot see either (.data does not
+    # share the tensor's version counter: what another library's kernel is)
+    hy.force.data.copy_(torch.from_numpy(force))
     torch.cuda.synchronize()
     lb.hydro_field_set(hy.force, (0.0, 0.0, 0.0))              # zeros over "zeros": no launch
     lb.synchronize()
@@ -193,6 +195,68 @@ def test_force_known_to_be_zero_is_not_read(mode):
     lb.synchronize()
     torch.cuda.synchronize()
     assert float(hy.force.abs().max()) == 0.0
+    lb.free()
+
+
+def test_the_python_mirror_reports_writes_of_torch_to_a_zeroed_array():
+    """The library keeps "known to hold zeros" by device address and relies on
+    every other writer to report (include/lbmi.h). torch does not: the mirror
+    checks the version counter of every tensor it has zeroed before each
+    collision, and that the tensor at that address is still the same one --
+    an in-place write by torch, or a new tensor that the caching allocator
+    put where a dead one was, is reported for it."""
+    import ludwig_amd
+    import torch
+    nall = tuple(n + 2 for n in NLOCAL)
+    force = _force_field(nall)
+    p, f_force, _, _ = _oracle_run(19, 2, force, None)
+    f0 = lbo.init_synthetic(p)
+
+    lb = ludwig_amd.LB(19, NLOCAL, 1, mode=1)
+    lb.relaxation_set("m10", 0.1, 0.3)
+    lb.body_force_set(FBODY)
+    hy = ludwig_amd.Hydro(nall, lb.device, force=np.zeros_like(force))
+    lb.hydro_field_set(hy.force, (0.0, 0.0, 0.0))
+    hy.force.copy_(torch.from_numpy(force))          # torch writes, says nothing
+    torch.cuda.synchronize()
+    lb.lb_memcpy_h2d(f0)
+    for _ in range(2):
+        lb.step(hy)
+    assert relmax(interior(lb.lb_memcpy_d2h(), 1), interior(f_force, 1)) < 1e-12
+
+    # a zeroed tensor dies, a new one lands on its address
+    lb.hydro_field_set(hy.force, (0.0, 0.0, 0.0))
+    lb.synchronize()
+    ptr = hy.force.data_ptr()
+    hy.force = None
+    torch.cuda.synchronize()
+    t = torch.from_numpy(np.ascontiguousarray(force)).to(lb.device)
+    if t.data_ptr() == ptr:                          # (the allocator usually does)
+        hy.force = t
+        lb.lb_memcpy_h2d(f0)
+        for _ in range(2):
+            lb.run(hy, 1)
+        assert relmax(interior(lb.lb_memcpy_d2h(), 1), interior(f_force, 1)) < 1e-12
+    lb.free()
+
+
+def test_lb_dirty_after_the_caller_rewrote_f():
+    """lbmi_lb_dirty: refused while anything is deferred, and what a lazy
+    collision still owed is dropped with the state it would have been formed
+    from."""
+    import ludwig_amd
+    nall = tuple(n + 2 for n in NLOCAL)
+    p, _, _, _ = _oracle_run(19, 1, None, None)
+    f0 = lbo.init_synthetic(p)
+    lb = ludwig_amd.LB(19, NLOCAL, 1, mode=1)
+    lb.relaxation_set("m10", 0.1, 0.3)
+    hy = ludwig_amd.Hydro(nall, lb.device)
+    lb.lb_memcpy_h2d(f0)
+    lb.step(hy)
+    with pytest.raises(Exception):
+        lb.lb_dirty()                                # propagation pending
+    lb.lb_flush()
+    lb.lb_dirty()
     lb.free()
 
 
