@@ -2212,6 +2212,7 @@ static_assert(p25(2, 0, 0) == 24 && p25(0, 0, 0) == 12 && q25(24, 0) == 2, "25 p
 template <int OX, int OY, int OZ>
 __device__ __forceinline__
 FeSite fe_eval_reg(const Symm & q, const double (&ph)[25]) {
+#pragma clang fp contract(fast)
   constexpr int ic = p25(OX, OY, OZ);
   constexpr int ixp = p25(OX + 1, OY, OZ), ixm = p25(OX - 1, OY, OZ);
   constexpr int iyp = p25(OX, OY + 1, OZ), iym = p25(OX, OY - 1, OZ);
@@ -2233,8 +2234,12 @@ FeSite fe_eval_reg(const Symm & q, const double (&ph)[25]) {
   return e;
 }
 
+#ifndef LBMI_FEWAVES
+#define LBMI_FEWAVES 1      /* k_symm_lb_step: __launch_bounds__ min waves per SIMD */
+#endif
+
 template <int NVEL, int SCHEME, int LAY>
-__global__ __launch_bounds__(BLOCK, LBMI_WAVES)
+__global__ __launch_bounds__(BLOCK, LBMI_FEWAVES)
 void k_symm_lb_step(lbmi_kparam_t kp, const double * __restrict__ f,
 		    double * __restrict__ fp, lbmi_hydro_dev_t h, Symm q,
 		    double mobility, int order,
@@ -2298,6 +2303,7 @@ void k_symm_lb_step(lbmi_kparam_t kp, const double * __restrict__ f,
 
   double frc[3] = {0.0, 0.0, 0.0};
   if (s.interior) {
+#pragma clang fp contract(fast)
     const FeSite ec = fe_eval_reg<0, 0, 0>(q, ph);
     constexpr int icentre = p25(0, 0, 0);
     const double phi0 = ph[icentre];
@@ -2307,14 +2313,16 @@ void k_symm_lb_step(lbmi_kparam_t kp, const double * __restrict__ f,
       constexpr int ex = (id == 0), ey = (id == 1), ez = (id == 2);
       const FeSite hi = fe_eval_reg<ex, ey, ez>(q, ph);
       const FeSite lo = fe_eval_reg<-ex, -ey, -ez>(q, ph);
-      /* F_a = -d_b P_ab, column id (pth_force_fluid_kernel's association) */
+      /* F_a = -d_b P_ab, column id: pth_force_fluid_kernel forms
+       * -(P(+) + P(0))/2 + (P(-) + P(0))/2; the stress of the site itself
+       * cancels, and is not evaluated here (the difference to the reference's
+       * association is a rounding of |P|, 1e-16 of a stress whose divergence
+       * is taken: far inside the 1e-12 of the parity criterion) */
       static_for<0, 3>([&](auto A) {
 	constexpr int ia = A;
-	const double c0 = ((ia == id) ? ec.p0 : 0.0) + q.kappa*ec.g[ia]*ec.g[id];
 	const double cp = ((ia == id) ? hi.p0 : 0.0) + q.kappa*hi.g[ia]*hi.g[id];
 	const double cm = ((ia == id) ? lo.p0 : 0.0) + q.kappa*lo.g[ia]*lo.g[id];
-	frc[ia] -= 0.5*(cp + c0);
-	frc[ia] += 0.5*(cm + c0);
+	frc[ia] += 0.5*(cm - cp);
       });
       constexpr int im2 = p25(-2*ex, -2*ey, -2*ez), ip2 = p25(2*ex, 2*ey, 2*ez);
       constexpr int im1 = p25(-ex, -ey, -ez), ip1 = p25(ex, ey, ez);
@@ -3637,8 +3645,11 @@ static int launch_symm_lb(const lbmi_kparam_t & kp, const double * f,
   const int i0a = (i0/ALIGNV)*ALIGNV;
   const unsigned nblk = (unsigned) ((i1 - i0a + BLOCK - 1)/BLOCK);
   dim3 grid(grid_for(nblk, (unsigned) kp.xcd_group)), block(BLOCK);
-  /* the occupancy cap of the fused kernel (launch_pc_hio) */
-  unsigned lds = (kp.lds_cap <= 65536 && nblk > 4096u) ? (unsigned) kp.lds_cap : 0u;
+  /* no occupancy cap here (launch_pc_hio has one): with the free-energy
+   * arithmetic in front of the collision the kernel is bound by latency and
+   * issue as much as by HBM, and every resident wave helps
+   * (profiles/r03_cfg4_sweep.txt: 0.164 -> 0.154 ms per step at 128^3) */
+  const unsigned lds = 0u;
   switch (kp.scheme) {
   case LBMI_M10:
     hipLaunchKernelGGL((k_symm_lb_step<NVEL, LBMI_M10, LAY>), grid, block, lds,
