@@ -517,7 +517,7 @@ def test_ludwig_with_lazy_hydro(name, mode):
 
 # --- the reference's regression suite: runs the binding must hand back ----------
 
-SWEEP = os.path.join(HERE, "golden", "regression_d3q19_short")
+SWEEP = os.path.join(HERE, "golden", "regression_d3q19_short")   # the nine cases tests read
 
 
 def _sweep_tool():

@@ -5,9 +5,12 @@ reference's executable built for gfx950 WITH the binding, and -- to tell what
 the binding changed from what the reference's HIP target changes by itself --
 through the same executable without it.
 
-  collect   (development container; needs /root/reference) copy the inputs and
-            their logs into tests/golden/regression_d3q19_short/ -- data the
-            reference's tests hold, no source
+  collect   (development container; needs /root/reference) stage the inputs and
+            their logs of the whole suite under tools/_sweep_data/ -- data the
+            reference's tests hold, no source; git-ignored, it travels to the
+            GPU box with the gpurun snapshot like the built binaries. (The nine
+            cases a committed TEST reads are kept under
+            tests/golden/regression_d3q19_short/.)
   run       (GPU box) run every input, compare each log with the expected one
             line by line: same words, numbers within --tol (the reference's
             tests/awk-fp-diff.sh uses 1e-12 on the printed values), after
@@ -33,7 +36,10 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-DATA = os.path.join(ROOT, "tests", "golden", "regression_d3q19_short")
+# the cases committed tests read; the whole suite when `collect` has staged it
+KEPT = os.path.join(ROOT, "tests", "golden", "regression_d3q19_short")
+STAGED = os.path.join(HERE, "_sweep_data")
+DATA = STAGED if os.path.isdir(STAGED) else KEPT
 REFDIR = "/root/reference/tests/regression/d3q19-short"
 EXE = os.path.join(ROOT, "oracle", "_ref", "ludwig_hip_d3q19")
 
@@ -114,6 +120,8 @@ def names():
 
 
 def collect():
+    global DATA
+    DATA = STAGED
     os.makedirs(DATA, exist_ok=True)
     n = 0
     # d3q19-short: every serial input; d3q19-io: the one-rank runs of the
@@ -130,7 +138,10 @@ def run_one(name, exe, env, workdir, limit):
     dst = os.path.join(workdir, "input")
     if os.path.exists(dst):
         os.remove(dst)                     # (a restart chain shares its directory)
-    shutil.copyfile(os.path.join(DATA, name + ".inp"), dst)
+    src = os.path.join(DATA, name + ".inp")
+    if not os.path.exists(src):
+        src = os.path.join(KEPT, name + ".inp")     # a case the tests keep
+    shutil.copyfile(src, dst)
     t0 = time.time()
     try:
         r = subprocess.run([exe], cwd=workdir, env=env, capture_output=True,
