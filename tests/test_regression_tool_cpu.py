@@ -83,5 +83,5 @@ def test_words_and_structure_count(rs):
 
 
 def test_two_different_runs_differ(rs):
-    bad, worst, _ = rs.compare(_log(rs, "serial-dist-1dp"), _log(rs, "serial-dist-3du"), 1e-12)
+    bad, worst, _ = rs.compare(_log(rs, "serial-dist-1dp"), _log(rs, "serial-wall-st1"), 1e-12)
     assert bad > 3 and worst > 1e-6
