@@ -110,6 +110,13 @@ def parse():
     ap.add_argument("--fe-halos", type=int, default=0,
                     help="1: keep the field halo swaps of phi and u (the "
                     "reference's structure) on one GPU as well")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "peer"],
+                    help="N > 1: rccl = one process per GPU, ncclSend/ncclRecv "
+                    "(the driver's launch); peer = ONE process, one host thread "
+                    "per GPU, the planes as peer-to-peer copies over xGMI "
+                    "(lbmi_ring_t; no RCCL bootstrap; ranks beyond the number "
+                    "of devices share them: a rehearsal). `python bench.py "
+                    "--gpus N --transport peer` from a plain shell")
     ap.add_argument("--selfring", type=int, default=0,
                     help="1 GPU only: route the X halo through a 1-rank RCCL "
                     "ring (exercises the N>1 step path: pack, send/recv, "
@@ -158,7 +165,22 @@ def self_launch(args):
            "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    # the ranks are fresh child processes (never a re-exec of this one); a
+    # rank that hangs must not hang the caller: the whole group is ended and
+    # the exit code says so
+    limit = float(os.environ.get("LBMI_BENCH_TIMEOUT", "1500"))
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True,
+                         start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(p.pid, signal.SIGKILL)       # exactly the group started here
+        p.wait()
+        sys.stderr.write("bench.py: the %d ranks did not finish within %.0f s\n"
+                         % (args.gpus, limit))
+        raise SystemExit(124)
+    r = subprocess.CompletedProcess(cmd, p.returncode, out)
     lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
     if r.returncode != 0 or not lines:
         sys.stderr.write(r.stdout)
@@ -289,6 +311,144 @@ def dry_run(args, rank, world):
     return out
 
 
+def peer_run(args):
+    """--transport peer: the N-rank slab step in ONE process. Rank k is a host
+    thread with a handle of its own on device k (modulo the devices present),
+    the X planes travel as peer-to-peer copies between the devices (the peer
+    ring of include/lbmi.h) instead of ncclSend / ncclRecv. Same step, same
+    schedule, same three streams per rank as the RCCL path; the JSON line has
+    the contract's fields, `transport: peer`, and per rank the phases of its
+    step. A rank that fails or does not finish in time ends the run with a
+    non-zero exit."""
+    import threading
+
+    import numpy as np
+    import torch
+
+    import ludwig_amd
+    from ludwig_amd import synthetic
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no CPU path exists")
+    world = args.gpus
+    ndev = torch.cuda.device_count()
+    ntotal = tuple(args.size)
+    if args.scaling == "weak":
+        ntotal = (args.size[0] * world, args.size[1], args.size[2])
+    zeta = 0.3 if args.scheme == "m10" else 0.1
+    lazy = (args.hydro == "lazy")
+    ring = ludwig_amd.Ring(world)
+    gate = threading.Barrier(world)
+    res = [None] * world
+    err = []
+    m = ludwig_amd.lb.model(args.nvel)
+
+    def rank_main(rank):
+        try:
+            dev = rank % ndev
+            torch.cuda.set_device(dev)
+            dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, nhalo=args.nhalo)
+            lb = ludwig_amd.LB(args.nvel, dec.nlocal, args.nhalo, mode=ludwig_amd.FUSED,
+                               halo_scheme=ludwig_amd.HALO_REDUCED, device=dev,
+                               cartsz=world, cartrank=rank, own_stream=True)
+            lb.relaxation_set(args.scheme, 0.1, zeta)
+            for kv in filter(None, args.tune.split(",")):
+                k, v = kv.split("=")
+                lb.tune(k, int(v))
+            lb.comm_init_ring(ring)
+            synthetic.fill_device(lb, m["cv"], m["wv"], ntotal,
+                                  xrange=(dec.noffset[0], dec.noffset[0] + dec.nlocal[0]))
+            hydro = None
+            if args.hydro != "0":
+                hydro = ludwig_amd.Hydro(lb.nall, lb.device)
+                hydro.force = torch.empty((3,) + lb.nall, dtype=torch.float64,
+                                          device=lb.device)
+                torch.cuda.synchronize(dev)
+                lb.hydro_field_set(hydro.force, (0.0, 0.0, 0.0))
+                if lazy:
+                    lb.tune("hydro_lazy", 1)
+                else:
+                    lb.hydro_field_dirty(hydro.force)
+            lb.synchronize()
+            gate.wait()
+            lb.run(hydro, PRELOAD_STEPS)
+            lb.synchronize()
+            mom0 = lb.moments()[[1, 5, 6, 7]]
+            lb.run(hydro, 2 + args.warmup)
+            lb.synchronize()
+            lb.timing(max(1, args.steps // 6))
+            gate.wait()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            lb.run(hydro, args.steps)
+            if lazy:
+                lb.hydro_sync()
+            lb.synchronize()
+            torch.cuda.synchronize(dev)
+            gate.wait()
+            dt = time.perf_counter() - t0
+            kms, nlaunch = lb.timing_read()
+            detail, ndetail = lb.timing_read_detail()
+            lb.timing(False)
+            mom1 = lb.moments()[[1, 5, 6, 7]]
+            res[rank] = {"dt": dt, "mom0": mom0, "mom1": mom1, "nlocal": list(dec.nlocal),
+                         "phases": {"rank": rank, "device": dev, "ring": world,
+                                    "transport": "peer",
+                                    "interior_ms": round(detail[0], 5),
+                                    "exchange_ms": round(detail[1], 5),
+                                    "boundary_ms": round(detail[2], 5),
+                                    "steps_sampled": ndetail,
+                                    "step_ms": round(kms / max(nlaunch, 1), 5)}}
+            gate.wait()                  # nobody frees while a peer still reads
+            lb.free()
+        except Exception as e:           # noqa: BLE001
+            err.append((rank, repr(e)))
+            ring.abort()
+            gate.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,), daemon=True)
+               for r in range(world)]
+    for t in threads:
+        t.start()
+    limit = time.time() + 900
+    for t in threads:
+        t.join(timeout=max(1.0, limit - time.time()))
+    if err or any(t.is_alive() for t in threads) or any(r is None for r in res):
+        sys.stderr.write("bench.py --transport peer: %r, %d rank(s) unfinished\n"
+                         % (err, sum(t.is_alive() for t in threads)))
+        sys.stderr.flush()
+        os._exit(1)                      # (daemon threads may sit in a wait)
+    ring.free()
+    dt = max(r["dt"] for r in res)
+    sites = ntotal[0] * ntotal[1] * ntotal[2]
+    mom0 = sum(r["mom0"] for r in res)
+    mom1 = sum(r["mom1"] for r in res)
+    return json.dumps({
+        "metric": "MLUPS (million lattice updates/sec) D3Q%d %dx%dx%d"
+                  % (args.nvel, *ntotal),
+        "value": round(1e-6 * sites * args.steps / dt, 1), "unit": "MLUPS",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "untimed_startup_steps": PRELOAD_STEPS + 2,
+        "ms_per_step": round(1e3 * dt / args.steps, 5),
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": "D3Q%d %s single-fluid %dx%dx%d periodic, "
+                        "lb_collide+lb_halo+lb_propagation per step"
+                        % (args.nvel, args.scheme.upper(), *ntotal),
+            "mode": "fused", "decomposition": "x-slab %d_1_1" % world,
+            "transport": "peer: one process, one host thread per rank, "
+                         "hipMemcpyPeerAsync between %d device(s)" % min(ndev, world),
+            "halo": "reduced X planes, peer-to-peer copies",
+        },
+        "roofline": None, "cpu_baseline": None, "rccl_ranks": 0,
+        "devices": min(ndev, world),
+        "slab_step": [r["phases"] for r in res],
+        "check": {"mass_drift_rel": float(abs(mom1[0] - mom0[0]) / mom0[0]),
+                  "momentum_drift_abs": float(np.max(np.abs(mom1[1:] - mom0[1:])))},
+    })
+
+
 def kernel_source_sha1():
     import hashlib
     h = hashlib.sha1()
@@ -303,6 +463,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.transport == "peer" and args.gpus > 1 and world == 1:
+        # one process drives all ranks: nothing to launch
+        return peer_run(args)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             return self_launch(args)
@@ -659,9 +822,19 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
+                # (the hydro traffic is part of the workload's name: rounds 1
+                # and 2 reported different steps under one name -- r01 stored
+                # rho, u and read the force every step, r02 did not)
                 "workload": "D3Q%d %s single-fluid %dx%dx%d periodic, "
-                            "lb_collide+lb_halo+lb_propagation per step"
-                            % (args.nvel, args.scheme.upper(), *ntotal),
+                            "lb_collide+lb_halo+lb_propagation per step, %s"
+                            % (args.nvel, args.scheme.upper(), *ntotal,
+                               {"lazy": "hydro arrays as the binding runs them "
+                                "unconfigured: zero force field not read, "
+                                "rho,u on demand (hydro_every_step: the "
+                                "reference-equivalent step)",
+                                "1": "force read and rho,u stored every step "
+                                "(the reference-equivalent step)",
+                                "0": "no hydro arrays"}[args.hydro]),
                 "mode": args.mode,
                 "order": order,
                                 "hydro_io": {"lazy": "arrays present; force zeroed through the "

@@ -59,7 +59,7 @@ extern "C" {
 #define LBMI_VERSION_MINOR 1
 
 typedef struct lbmi_s lbmi_t;           /* opaque handle ~ lb_t + halo_swap_t */
-typedef struct lbmi_ring_s lbmi_ring_t; /* a ring of handles inside one process */
+typedef struct lbmi_ring_s lbmi_ring_t; /* the peer transport: a ring of handles inside one process */
 
 typedef enum lbmi_error_e {
   LBMI_SUCCESS         =  0,
@@ -134,9 +134,18 @@ typedef struct lbmi_options_s {
   int device;               /* HIP device ordinal, or -1: current device     */
   int mode;                 /* lbmi_mode_t                                   */
   int halo_scheme;          /* lbmi_halo_t                                   */
-  int cartsz;               /* number of slabs along X (1 = single GPU)      */
+  int cartsz;               /* number of slabs (1 = single GPU)              */
   int cartrank;             /* this rank's slab, 0 <= cartrank < cartsz      */
-  int reserved[7];          /* must be zero                                  */
+  int cartdim;              /* the decomposed direction: 0 = X (the default:
+			       boundary planes are contiguous, and the fused
+			       step overlaps their exchange with the interior
+			       launch), 1 = Y, 2 = Z (grid 1_N_1 / 1_1_N,
+			       coords_rt.c:46-47: planes are gathered and
+			       scattered, halo_swap.c:1074-1274; FUSED runs as
+			       FUSED_HALO: the exchange where lb_halo is
+			       called, the propagation folded into the next
+			       collision)                                    */
+  int reserved[6];          /* must be zero                                  */
 } lbmi_options_t;
 
 /* Borrowed per-call fields of lb_collide(): hydro_t and map_t device arrays
@@ -693,7 +702,7 @@ int lbmi_timing_read_detail(lbmi_t * lb, double ms[3], int * nsample);
  *            (default). */
 int lbmi_tune(lbmi_t * lb, const char * key, int value);
 
-/* ---- multi-GPU: 1-d slab decomposition along X over RCCL ---------------- */
+/* ---- multi-GPU: 1-d slab decomposition (lbmi_options_t::cartdim) over RCCL -- */
 
 #define LBMI_UNIQUE_ID_BYTES 128
 /* ncclGetUniqueId: HOST buffer of LBMI_UNIQUE_ID_BYTES, call on rank 0 and
@@ -703,7 +712,7 @@ int lbmi_comm_unique_id(void * id);
 int lbmi_comm_init(lbmi_t * lb, const void * id);
 int lbmi_comm_free(lbmi_t * lb);
 /* What the handle exchanges over: the number of ranks of its ring, its own
- * rank there, and the transport (0 none, 1 RCCL, 2 in-process ring) */
+ * rank there, and the transport (0 none, 1 RCCL, 2 the peer ring of one process) */
 int lbmi_comm_info(lbmi_t * lb, int * nranks, int * rank, int * transport);
 
 /* The point-to-point operations of ONE X exchange of a rank, in the order
@@ -733,14 +742,21 @@ typedef struct lbmi_xop_s {
 int lbmi_x_schedule(const lbmi_options_t * opts, int scheme, int packed,
 		    lbmi_xop_t * ops, int maxops, int * nops);
 
-/* A ring of cartsz handles inside ONE process, all on one device, each
- * driven by a thread of its own: the slab path -- kernels, schedule, streams,
- * overlap -- with device-to-device copies in place of RCCL, for tests and
- * rehearsals on a single GPU (RCCL refuses two ranks on one device).
+/* The peer transport: a ring of cartsz handles inside ONE process, each
+ * driven by a host thread of its own and each on a device of its own -- one
+ * process steering the GPUs of a node, the planes travelling as peer-to-peer
+ * copies over xGMI (hipMemcpyPeerAsync; the receiver pulls) -- or several of
+ * them on the same device. The slab path is the one that runs over RCCL:
+ * kernels, schedule (lbmi_x_schedule), streams, overlap; only the execution
+ * of the schedule differs (posts into per-pair FIFOs, event waits, copies).
+ * It needs no RCCL bootstrap and no out-of-band exchange of an id
+ * (bench.py --transport peer), and on ONE GPU it is the rehearsal of the
+ * N-rank step that RCCL does not allow there ("Duplicate GPU detected").
  * lbmi_ring_create once, lbmi_comm_init_ring on every handle in place of
- * lbmi_comm_init, lbmi_comm_free / lbmi_free on every handle, lbmi_ring_free.
- * An exchange waits for the neighbours' posts: with more than one rank the
- * handles must step concurrently (one thread each). */
+ * lbmi_comm_init (it enables peer access to the neighbours' devices),
+ * lbmi_comm_free / lbmi_free on every handle, lbmi_ring_free. An exchange
+ * waits for the neighbours' posts: with more than one rank the handles must
+ * step concurrently (one thread each), each on its own stream. */
 int lbmi_ring_create(int nranks, lbmi_ring_t ** ring);
 int lbmi_comm_init_ring(lbmi_t * lb, lbmi_ring_t * ring);
 int lbmi_ring_free(lbmi_ring_t * ring);

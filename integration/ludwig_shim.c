@@ -273,22 +273,39 @@ static void shim_report_policy(void) {
     }									\
   } while (0)
 
-/* Can liblbmi take this lb_t? SoA build, device halo scheme, decomposition
- * along X only. Anything else uses the originals. */
+/* Can liblbmi take this lb_t? SoA build, device halo scheme, a decomposition
+ * along ONE axis (slabs: grid N_1_1, 1_N_1 or 1_1_N, coords_rt.c:46-47).
+ * Anything else uses the originals. */
+
+static int shim_slab_dim(lb_t * lb, int * dim) {
+  int cartsz[3];
+  int ndec = 0;
+  cs_cartsz(lb->cs, cartsz);
+  *dim = X;
+  for (int d = 0; d < 3; d++) {
+    if (cartsz[d] > 1) {
+      ndec += 1;
+      *dim = d;
+    }
+  }
+  return (ndec <= 1);
+}
 
 static int shim_supported(lb_t * lb) {
-  int cartsz[3];
+  int dim = X;
   if (DATA_MODEL != DATA_MODEL_SOA) return 0;
   if (lb->ndist != 1 && lb->ndist != 2) return 0;
   if (lb->model.nvel != 19 && lb->model.nvel != 27) return 0;
   if (lb->haloscheme != LB_HALO_TARGET) return 0;
-  cs_cartsz(lb->cs, cartsz);
-  if (cartsz[Y] != 1 || cartsz[Z] != 1) {
+  if (!shim_slab_dim(lb, &dim)) {
     static int told = 0;
+    int cartsz[3];
+    cs_cartsz(lb->cs, cartsz);
     if (!told) {
-      pe_info(lb->pe, "liblbmi: decomposition %d_%d_%d: only slabs along X "
-	      "(grid N_1_1) are covered; this run uses the reference's own "
-	      "lattice Boltzmann kernels\n", cartsz[X], cartsz[Y], cartsz[Z]);
+      pe_info(lb->pe, "liblbmi: decomposition %d_%d_%d: slabs along one axis "
+	      "(grid N_1_1, 1_N_1, 1_1_N) are covered; this run uses the "
+	      "reference's own lattice Boltzmann kernels\n", cartsz[X],
+	      cartsz[Y], cartsz[Z]);
     }
     told = 1;
     return 0;
@@ -385,6 +402,7 @@ static lbmi_t * shim_handle(lb_t * lb) {
   {
     lbmi_options_t opts;
     int cartsz[3], coords[3];
+    int slabdim = X;
     double * f = NULL;
     double * fprime = NULL;
     /* LBMI_MODE unset (the default): the run starts in LBMI_MODE_FUSED -- halo
@@ -411,8 +429,10 @@ static lbmi_t * shim_handle(lb_t * lb) {
     cs_nhalo(lb->cs, &opts.nhalo);
     cs_cartsz(lb->cs, cartsz);
     cs_cart_coords(lb->cs, coords);
-    opts.cartsz = cartsz[X];
-    opts.cartrank = coords[X];
+    (void) shim_slab_dim(lb, &slabdim);          /* shim_supported: at most one */
+    opts.cartdim = slabdim;
+    opts.cartsz = cartsz[slabdim];
+    opts.cartrank = coords[slabdim];
     opts.device = -1;                            /* ludwig.c:467-492 chose it */
     opts.halo_scheme = LBMI_HALO_FULL;           /* halo_swap_packed semantics */
     opts.mode = LBMI_MODE_FUSED;                 /* ndist 1 or 2 */
@@ -442,7 +462,7 @@ static lbmi_t * shim_handle(lb_t * lb) {
     last_f = f;
     last_fprime = fprime;
 
-    if (cartsz[X] > 1) {
+    if (cartsz[slabdim] > 1) {
       /* ncclUniqueId from rank 0 of the Cartesian communicator */
       char id[LBMI_UNIQUE_ID_BYTES];
       MPI_Comm comm;
@@ -1020,7 +1040,10 @@ int lb_memcpy(lb_t * lb, tdpMemcpyKind flag) {
  *****************************************************************************/
 
 static int shim_io_supported(lb_t * lb, const io_metadata_t * meta) {
+  int dim = X;
   if (!shim_supported(lb)) return 0;
+  /* (a slab along Y or Z is not one byte range of the file) */
+  if (!shim_slab_dim(lb, &dim) || dim != X) return 0;
   if (meta->options.mode != IO_MODE_MPIIO) return 0;
   if (meta->options.iorformat != IO_RECORD_BINARY) return 0;
   if (meta->options.iogrid[X] != 1 || meta->options.iogrid[Y] != 1 ||

@@ -89,6 +89,8 @@ struct lbmi_s {
   int have_comm;
   double * sendlo, * sendhi, * recvlo, * recvhi;   /* staging, any halo swap */
   size_t xbuf_doubles;
+  int xdim;                          /* the decomposed direction: X (0) unless
+					opts.cartdim says Y (1) or Z (2) */
   int x_packed;                      /* 1: pack/unpack through buffers */
   /* FUSED step: buffers of its own (a field halo between two steps must not
    * disturb what the boundary launch left for the next exchange) */
@@ -285,6 +287,9 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "cartsz/cartrank = %d/%d",
 		     opts->cartsz, opts->cartrank);
   }
+  if (opts->cartdim < 0 || opts->cartdim > 2) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "cartdim = %d (0 X, 1 Y, 2 Z)", opts->cartdim);
+  }
   if (opts->mode != LBMI_MODE_EAGER && opts->mode != LBMI_MODE_FUSED &&
       opts->mode != LBMI_MODE_INPLACE && opts->mode != LBMI_MODE_FUSED_HALO) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "mode = %d", opts->mode);
@@ -318,6 +323,16 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "calloc failed");
 
   lb->opts = *opts;
+  lb->xdim = opts->cartdim;
+  if (opts->cartsz > 1 && opts->cartdim != X &&
+      (opts->mode == LBMI_MODE_FUSED || opts->mode == LBMI_MODE_INPLACE)) {
+    /* Slabs along Y or Z: the boundary planes are not contiguous runs of x
+     * planes, so the split of the fused step into an interior launch and a
+     * boundary launch against the exchange buffers does not apply: the halo
+     * swap runs where lb_halo is called (the planes over the ring), and the
+     * propagation alone is folded into the next collision */
+    lb->opts.mode = LBMI_MODE_FUSED_HALO;
+  }
   if (opts->device >= 0) {
     if (opts->device >= ndevice) {
       free(lb);
@@ -858,8 +873,9 @@ int lbmi_propagate(lbmi_t * lb, const double * f, double * fprime) {
 /* Which directions can be wrapped by index arithmetic on this rank */
 
 static int lbmi_wrapmask(const lbmi_t * lb) {
-  int mask = 2 | 4;                        /* Y and Z are never decomposed */
-  if (lb->opts.cartsz == 1 && !lb->have_comm) mask |= 1;
+  int mask = 1 | 2 | 4;
+  /* the decomposed direction has its halo planes filled by the neighbours */
+  if (lb->opts.cartsz > 1 || lb->have_comm) mask &= ~(1 << lb->xdim);
   return mask;
 }
 
@@ -956,11 +972,11 @@ static int lbmi_x_ops(int cartsz, int cartrank, const lbmi_halo_sel_t * sel,
 }
 
 static void lbmi_sel_make(const int8_t cv[][3], int nvel, int reduced,
-			  lbmi_halo_sel_t * sx) {
+			  int dim, lbmi_halo_sel_t * sx) {
   memset(sx, 0, sizeof(*sx));
   for (int p = 0; p < nvel; p++) {
-    if (!reduced || cv[p][X] == +1) sx->lo[sx->nlo++] = (int8_t) p;
-    if (!reduced || cv[p][X] == -1) sx->hi[sx->nhi++] = (int8_t) p;
+    if (!reduced || cv[p][dim] == +1) sx->lo[sx->nlo++] = (int8_t) p;
+    if (!reduced || cv[p][dim] == -1) sx->hi[sx->nhi++] = (int8_t) p;
   }
 }
 
@@ -980,18 +996,24 @@ int lbmi_x_schedule(const lbmi_options_t * opts, int scheme, int packed,
     return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
   }
   if (opts->cartsz < 1 || opts->cartrank < 0 || opts->cartrank >= opts->cartsz ||
-      opts->nhalo < 1 || opts->nlocal[X] < 1 || opts->nlocal[Y] < 1 || opts->nlocal[Z] < 1) {
+      opts->nhalo < 1 || opts->nlocal[X] < 1 || opts->nlocal[Y] < 1 || opts->nlocal[Z] < 1 ||
+      opts->cartdim < 0 || opts->cartdim > 2) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_x_schedule: bad options");
+  }
+  if (!packed && opts->cartdim != X) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_x_schedule: the planes of Y and Z "
+		     "slabs are not contiguous: packed messages only");
   }
   ma = (double *) malloc(sizeof(double)*LBMI_NVEL_MAX*LBMI_NVEL_MAX);
   if (ma == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "malloc");
   lbmi_k_model(opts->nvel, &cv[0][0], wv, na, ma);
   free(ma);
-  lbmi_sel_make(cv, opts->nvel, scheme == LBMI_HALO_REDUCED, &sx);
-  psz = (long long) (opts->nlocal[Y] + 2*opts->nhalo)*(opts->nlocal[Z] + 2*opts->nhalo);
-  ns = psz*(opts->nlocal[X] + 2*opts->nhalo);
+  lbmi_sel_make(cv, opts->nvel, scheme == LBMI_HALO_REDUCED, opts->cartdim, &sx);
+  ns = 1;
+  for (int d = 0; d < 3; d++) ns *= (long long) (opts->nlocal[d] + 2*opts->nhalo);
+  psz = ns/(opts->nlocal[opts->cartdim] + 2*opts->nhalo);    /* sites of a plane */
   n = lbmi_x_ops(opts->cartsz, opts->cartrank, &sx, psz, ns, opts->nhalo,
-		 opts->nlocal[X], packed, 0, tmp);
+		 opts->nlocal[opts->cartdim], packed, 0, tmp);
   if (n > maxops) return lbmi_fail(LBMI_ERR_ARGUMENT, "%d operations, room for %d", n, maxops);
   memcpy(ops, tmp, sizeof(lbmi_xop_t)*(size_t) n);
   *nops = n;
@@ -1000,22 +1022,34 @@ int lbmi_x_schedule(const lbmi_options_t * opts, int scheme, int packed,
 
 /*****************************************************************************
  *
- *  In-process ring: N handles on ONE device in ONE process, one thread per
- *  handle, stand in for N ranks. A send posts (pointer, count, "data ready"
- *  event) into the FIFO of its directed pair; the matching receive -- the
- *  next one issued towards that peer, RCCL's rule -- waits for the post,
- *  makes its stream wait for the event and copies device to device; the end
- *  of the group makes the sender's stream wait until its buffers have been
- *  read. Everything else of a slab step (kernels, schedule, overlap, streams)
- *  is the code that runs over RCCL.
+ *  The peer ring: the second transport of the X exchange. N handles of ONE
+ *  process, one host thread per handle, each on a device of its own (one
+ *  process driving the GPUs of a node over xGMI peer copies,
+ *  hipMemcpyPeerAsync) -- or several of them, or all, on the same device (a
+ *  rehearsal of the slab path on one GPU, where RCCL refuses two ranks). It
+ *  replaces halo_swap.c:762-881 like the RCCL path does and needs no RCCL
+ *  bootstrap (no unique id, no out-of-band exchange): bench.py --transport
+ *  peer, a comparator for what the RCCL kernels cost beside the interior
+ *  launch.
+ *
+ *  A send posts (pointer, device, count, "data ready" event) into the FIFO of
+ *  its directed pair; the matching receive -- the next one issued towards
+ *  that peer, RCCL's rule -- waits for the post, makes its stream wait for
+ *  the event and copies device to device (the receiver pulls); the end of the
+ *  group makes the sender's stream wait until its buffers have been read.
+ *  Events are recorded on streams of the device they were created on: `ready`
+ *  belongs to the sender's device, `done` to the receiver's. Everything else
+ *  of a slab step (kernels, schedule, overlap, streams) is the code that runs
+ *  over RCCL.
  *
  *****************************************************************************/
 
-enum {RING_SLOTS = 128};
+enum {RING_SLOTS = 128, LBMI_RING_MAX = 64};
 enum {RING_FREE = 0, RING_POSTED = 1, RING_CONSUMED = 2};
 
 typedef struct ring_msg_s {
   const double * ptr;
+  int device;                        /* where ptr lives (the sender's) */
   size_t count;
   hipEvent_t ready;                  /* recorded by the sender: data complete */
   hipEvent_t done;                   /* recorded by the receiver: data read */
@@ -1033,6 +1067,7 @@ struct lbmi_ring_s {
   int nranks;
   int nattached;
   int failed;
+  int device[LBMI_RING_MAX];         /* of each attached rank, -1: not yet */
   pthread_mutex_t mu;
   pthread_cond_t cv;
   ring_fifo_t * fifo;                /* [src*nranks + dst] */
@@ -1040,13 +1075,16 @@ struct lbmi_ring_s {
 
 int lbmi_ring_create(int nranks, lbmi_ring_t ** ring) {
   lbmi_ring_t * r = NULL;
-  if (ring == NULL || nranks < 1) return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_ring_create");
+  if (ring == NULL || nranks < 1 || nranks > LBMI_RING_MAX) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_ring_create: 1 .. %d ranks", LBMI_RING_MAX);
+  }
   *ring = NULL;
   r = (lbmi_ring_t *) calloc(1, sizeof(lbmi_ring_t));
   if (r == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "calloc");
   r->nranks = nranks;
   r->fifo = (ring_fifo_t *) calloc((size_t) nranks*nranks, sizeof(ring_fifo_t));
   if (r->fifo == NULL) { free(r); return lbmi_fail(LBMI_ERR_ARGUMENT, "calloc"); }
+  for (int n = 0; n < LBMI_RING_MAX; n++) r->device[n] = -1;
   pthread_mutex_init(&r->mu, NULL);
   pthread_cond_init(&r->cv, NULL);
   *ring = r;
@@ -1090,8 +1128,9 @@ static int ring_fail(lbmi_ring_t * r, int code, const char * what) {
   return lbmi_fail(code, "in-process ring: %s", what);
 }
 
-static int ring_sendrecv(lbmi_ring_t * r, int me, const lbmi_xop_t * ops,
-			 int nops, double * const base[5], hipStream_t st) {
+static int ring_sendrecv(lbmi_ring_t * r, int me, int mydev,
+			 const lbmi_xop_t * ops, int nops,
+			 double * const base[5], hipStream_t st) {
   unsigned first_mine[LBMI_XOPS_MAX];   /* per op: index of my send in its fifo */
 
   pthread_mutex_lock(&r->mu);
@@ -1103,12 +1142,13 @@ static int ring_sendrecv(lbmi_ring_t * r, int me, const lbmi_xop_t * ops,
     q = &r->fifo[me*r->nranks + ops[n].peer];
     if (q->posted - q->released >= RING_SLOTS) return ring_fail(r, LBMI_ERR_STATE, "too many sends in flight");
     m = &q->slot[q->posted % RING_SLOTS];
+    /* (this thread's current device is the sender's: the event is its) */
     if (m->ready == NULL &&
-	(hipEventCreateWithFlags(&m->ready, hipEventDisableTiming) != hipSuccess ||
-	 hipEventCreateWithFlags(&m->done, hipEventDisableTiming) != hipSuccess)) {
+	hipEventCreateWithFlags(&m->ready, hipEventDisableTiming) != hipSuccess) {
       return ring_fail(r, LBMI_ERR_HIP, "hipEventCreate");
     }
     m->ptr = base[ops[n].buffer] + ops[n].offset;
+    m->device = mydev;
     m->count = (size_t) ops[n].count;
     if (hipEventRecord(m->ready, st) != hipSuccess) return ring_fail(r, LBMI_ERR_HIP, "hipEventRecord");
     m->state = RING_POSTED;
@@ -1127,9 +1167,18 @@ static int ring_sendrecv(lbmi_ring_t * r, int me, const lbmi_xop_t * ops,
     if (r->failed) { pthread_mutex_unlock(&r->mu); return lbmi_fail(LBMI_ERR_STATE, "in-process ring: another rank failed"); }
     m = &q->slot[q->taken % RING_SLOTS];
     if (m->count != (size_t) ops[n].count) return ring_fail(r, LBMI_ERR_STATE, "a receive met a send of another length");
+    /* the receiver pulls, on its own stream: from its own device, or over
+     * xGMI from the sender's (peer access enabled at lbmi_comm_init_ring) */
+    if (m->done == NULL &&
+	hipEventCreateWithFlags(&m->done, hipEventDisableTiming) != hipSuccess) {
+      return ring_fail(r, LBMI_ERR_HIP, "hipEventCreate");
+    }
     if (hipStreamWaitEvent(st, m->ready, 0) != hipSuccess ||
-	hipMemcpyAsync(base[ops[n].buffer] + ops[n].offset, m->ptr,
-		       sizeof(double)*m->count, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+	((m->device == mydev)
+	 ? hipMemcpyAsync(base[ops[n].buffer] + ops[n].offset, m->ptr,
+			  sizeof(double)*m->count, hipMemcpyDeviceToDevice, st)
+	 : hipMemcpyPeerAsync(base[ops[n].buffer] + ops[n].offset, mydev, m->ptr,
+			      m->device, sizeof(double)*m->count, st)) != hipSuccess ||
 	hipEventRecord(m->done, st) != hipSuccess) {
       return ring_fail(r, LBMI_ERR_HIP, "device-to-device copy");
     }
@@ -1161,7 +1210,8 @@ static int ring_sendrecv(lbmi_ring_t * r, int me, const lbmi_xop_t * ops,
 static int lbmi_x_sendrecv(lbmi_t * lb, const lbmi_xop_t * ops, int nops,
 			   double * const base[5], hipStream_t st) {
   if (lb->ring) {
-    return ring_sendrecv(lb->ring, lb->opts.cartrank, ops, nops, base, st);
+    return ring_sendrecv(lb->ring, lb->opts.cartrank, lb->device, ops, nops,
+			 base, st);
   }
   NCCLCHECK(ncclGroupStart());
   for (int n = 0; n < nops; n++) {
@@ -1188,29 +1238,33 @@ static int lbmi_x_exchange_buf(lbmi_t * lb, const lbmi_halo_sel_t * sel,
 			       int unpack, hipStream_t st) {
   lbmi_xop_t ops[LBMI_XOPS_MAX];
   double * base[5] = {buf[0], buf[1], buf[2], buf[3], data};
-  const int packed = (lb->x_packed || blocked || !unpack || packed_already);
+  const int dim = lb->xdim;
+  const long long psz = lb->kp.nsite/lb->kp.nall[dim];     /* sites of a plane */
+  /* (only the planes of X slabs are contiguous runs of the array) */
+  const int packed = (lb->x_packed || blocked || !unpack || packed_already ||
+		      dim != X);
   int nops, ifail;
 
   if (!lb->have_comm) {
     return lbmi_fail(LBMI_ERR_STATE, "cartsz = %d but lbmi_comm_init() has "
 		     "not been called", lb->opts.cartsz);
   }
-  if (packed && ((size_t) lb->kp.strx*(size_t) sel->nlo > lb->xbuf_doubles ||
-		 (size_t) lb->kp.strx*(size_t) sel->nhi > lb->xbuf_doubles)) {
+  if (packed && ((size_t) psz*(size_t) sel->nlo > lb->xbuf_doubles ||
+		 (size_t) psz*(size_t) sel->nhi > lb->xbuf_doubles)) {
     return lbmi_fail(LBMI_ERR_STATE, "halo buffers too small");
   }
-  nops = lbmi_x_ops(lb->opts.cartsz, lb->opts.cartrank, sel, lb->kp.strx,
-		    lb->kp.nsite, lb->kp.nhalo, lb->kp.nlocal[X], packed, layer,
+  nops = lbmi_x_ops(lb->opts.cartsz, lb->opts.cartrank, sel, psz,
+		    lb->kp.nsite, lb->kp.nhalo, lb->kp.nlocal[dim], packed, layer,
 		    ops);
   if (packed && !packed_already) {
-    KCHECK(lbmi_k_halo_pack_x(&lb->kp, sel, data, buf[0], buf[1], blocked,
-			      layer, st));
+    KCHECK(lbmi_k_halo_pack(&lb->kp, dim, sel, data, buf[0], buf[1], blocked,
+			    layer, st));
   }
   ifail = lbmi_x_sendrecv(lb, ops, nops, base, st);
   if (ifail) return ifail;
   if (packed && unpack) {
-    KCHECK(lbmi_k_halo_unpack_x(&lb->kp, sel, data, buf[2], buf[3], blocked,
-				layer, st));
+    KCHECK(lbmi_k_halo_unpack(&lb->kp, dim, sel, data, buf[2], buf[3], blocked,
+			      layer, st));
   }
   return 0;
 }
@@ -1224,16 +1278,18 @@ static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
 
 static int lbmi_halo_generic(lbmi_t * lb, const lbmi_halo_sel_t sel[3],
 			     double * data, hipStream_t st) {
-  int ifail;
-  if (lb->opts.cartsz > 1 || lb->have_comm) {
-    ifail = lbmi_x_exchange(lb, &sel[X], data, 0, 0, st);
-    if (ifail) return ifail;
+  /* X, Y, Z in this order whichever of them goes over the ring: each pass
+   * covers the full extent of the others, so edges and corners complete
+   * (halo_swap.c:709-1063 does the same with its Cartesian neighbours) */
+  for (int d = 0; d < 3; d++) {
+    if (d == lb->xdim && (lb->opts.cartsz > 1 || lb->have_comm)) {
+      int ifail = lbmi_x_exchange(lb, &sel[d], data, 0, 0, st);
+      if (ifail) return ifail;
+    }
+    else {
+      KCHECK(lbmi_k_halo_copy(&lb->kp, d, &sel[d], data, 1, st));
+    }
   }
-  else {
-    KCHECK(lbmi_k_halo_copy(&lb->kp, X, &sel[X], data, 1, st));
-  }
-  KCHECK(lbmi_k_halo_copy(&lb->kp, Y, &sel[Y], data, 1, st));
-  KCHECK(lbmi_k_halo_copy(&lb->kp, Z, &sel[Z], data, 1, st));
   return 0;
 }
 
@@ -1261,6 +1317,10 @@ int lbmi_halo_x_count(lbmi_t * lb, int scheme, size_t * nsendlo,
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   sel = lbmi_sel(lb, scheme);
   if (sel == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
+  if (lb->xdim != X) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "lbmi_halo_x_*: slabs along X only "
+		     "(cartdim = %d: lbmi_halo / lbmi_lb_halo do the exchange)", lb->xdim);
+  }
   /* sendlo feeds the neighbour's HIGH halo (components hi), sendhi its LOW */
   if (nsendlo) *nsendlo = (size_t) lb->kp.strx*(size_t) sel[X].nhi;
   if (nsendhi) *nsendhi = (size_t) lb->kp.strx*(size_t) sel[X].nlo;
@@ -1858,11 +1918,17 @@ int lbmi_wall_map(lbmi_t * lb, const int isboundary[3], char * status) {
 	int wall = 0;
 	/* X slabs: the global coordinate 0 lies below the first rank, the
 	 * global ntotal + 1 above the last (noffset in wall.c:1236-1240) */
-	if (isboundary[X] && ic == h - 1 && lb->opts.cartrank == 0) wall = 1;
-	if (isboundary[X] && ic == h + lb->kp.nlocal[X] &&
-	    lb->opts.cartrank == lb->opts.cartsz - 1) wall = 1;
-	if (isboundary[Y] && (jc == h - 1 || jc == h + lb->kp.nlocal[Y])) wall = 1;
-	if (isboundary[Z] && (kc == h - 1 || kc == h + lb->kp.nlocal[Z])) wall = 1;
+	{
+	  const int c[3] = {ic, jc, kc};
+	  for (int d = 0; d < 3; d++) {
+	    /* in the decomposed direction only the first rank has the low
+	     * wall, only the last one the high wall */
+	    const int first = (d != lb->xdim || lb->opts.cartrank == 0);
+	    const int last = (d != lb->xdim || lb->opts.cartrank == lb->opts.cartsz - 1);
+	    if (isboundary[d] && c[d] == h - 1 && first) wall = 1;
+	    if (isboundary[d] && c[d] == h + lb->kp.nlocal[d] && last) wall = 1;
+	  }
+	}
 	if (wall) {
 	  host[(size_t) ic*lb->kp.strx + (size_t) jc*lb->kp.stry + kc] = LBMI_MAP_BOUNDARY;
 	}
@@ -2696,6 +2762,10 @@ int lbmi_lb_mode_set(lbmi_t * lb, int mode) {
   if (lb->opts.ndist == 2 && mode == LBMI_MODE_INPLACE) {
     return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = 2 needs LBMI_MODE_EAGER, LBMI_MODE_FUSED_HALO or LBMI_MODE_FUSED");
   }
+  if ((mode == LBMI_MODE_FUSED || mode == LBMI_MODE_INPLACE) && lb->xdim != X &&
+      (lb->opts.cartsz > 1 || lb->have_comm)) {
+    mode = LBMI_MODE_FUSED_HALO;     /* slabs along Y or Z: see lbmi_create */
+  }
   if (mode == lb->opts.mode) return 0;
   if (lb->f != NULL) {
     int ifail = lbmi_lb_flush(lb);
@@ -3017,19 +3087,19 @@ int lbmi_field_halo_n(lbmi_t * lb, int nel, int nswap, double * data) {
     sel.lo[sel.nlo++] = (int8_t) n;
     sel.hi[sel.nhi++] = (int8_t) n;
   }
-  if (lb->opts.cartsz > 1 || lb->have_comm) {
-    /* slabs: the X planes of every layer over RCCL (device to device, where
-     * the reference stages them through the host, halo_swap.c:762-881) */
-    for (int layer = 0; layer < nswap; layer++) {
-      int ifail = lbmi_x_exchange(lb, &sel, data, 0, layer, lb->stream);
-      if (ifail) return ifail;
+  for (int d = 0; d < 3; d++) {
+    if (d == lb->xdim && (lb->opts.cartsz > 1 || lb->have_comm)) {
+      /* slabs: the planes of every layer over the ring (device to device,
+       * where the reference stages them through the host, halo_swap.c:762-881) */
+      for (int layer = 0; layer < nswap; layer++) {
+	int ifail = lbmi_x_exchange(lb, &sel, data, 0, layer, lb->stream);
+	if (ifail) return ifail;
+      }
+    }
+    else {
+      KCHECK(lbmi_k_halo_copy(&lb->kp, d, &sel, data, nswap, lb->stream));
     }
   }
-  else {
-    KCHECK(lbmi_k_halo_copy(&lb->kp, X, &sel, data, nswap, lb->stream));
-  }
-  KCHECK(lbmi_k_halo_copy(&lb->kp, Y, &sel, data, nswap, lb->stream));
-  KCHECK(lbmi_k_halo_copy(&lb->kp, Z, &sel, data, nswap, lb->stream));
   return 0;
 }
 
@@ -3506,6 +3576,11 @@ static int lbmi_io_args(lbmi_t * lb, const char * dir, int ntotal_x,
 			int offset_x) {
   if (lb == NULL || dir == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
+  if (lb->xdim != X && lb->opts.cartsz > 1) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "distribution files: a slab along Y or "
+		     "Z is not a contiguous byte range of the file (X slabs, or "
+		     "the reference's lb_io_write)");
+  }
   if (offset_x < 0 || offset_x + lb->kp.nlocal[X] > ntotal_x) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "planes %d..%d outside 0..%d", offset_x,
 		     offset_x + lb->kp.nlocal[X] - 1, ntotal_x - 1);
@@ -3607,9 +3682,11 @@ int lbmi_comm_unique_id(void * id) {
 
 static int lbmi_comm_buffers(lbmi_t * lb) {
   size_t bytes;
-  int nred = lb->sel_reduced[X].nlo > lb->sel_reduced[X].nhi
-    ? lb->sel_reduced[X].nlo : lb->sel_reduced[X].nhi;
-  lb->xbuf_doubles = (size_t) lb->kp.strx*LBMI_NVEL_MAX;
+  const int dim = lb->xdim;
+  const size_t psz = (size_t) (lb->kp.nsite/lb->kp.nall[dim]);
+  int nred = lb->sel_reduced[dim].nlo > lb->sel_reduced[dim].nhi
+    ? lb->sel_reduced[dim].nlo : lb->sel_reduced[dim].nhi;
+  lb->xbuf_doubles = psz*LBMI_NVEL_MAX;
   bytes = sizeof(double)*lb->xbuf_doubles;
   if (hipMalloc((void **) &lb->sendlo, bytes) != hipSuccess ||
       hipMalloc((void **) &lb->sendhi, bytes) != hipSuccess ||
@@ -3617,7 +3694,7 @@ static int lbmi_comm_buffers(lbmi_t * lb) {
       hipMalloc((void **) &lb->recvhi, bytes) != hipSuccess) {
     return lbmi_fail(LBMI_ERR_HIP, "hipMalloc (halo staging buffers) failed");
   }
-  bytes = sizeof(double)*(size_t) lb->kp.strx*(size_t) nred;
+  bytes = sizeof(double)*psz*(size_t) nred;
   for (int k = 0; k < 4; k++) {
     if (hipMalloc((void **) &lb->fx[k], bytes) != hipSuccess ||
 	hipMemset(lb->fx[k], 0, bytes) != hipSuccess) {
@@ -3643,6 +3720,7 @@ int lbmi_comm_init(lbmi_t * lb, const void * id) {
   lb->have_comm = 1;
 
   ifail = lbmi_comm_buffers(lb);
+  if (ifail == 0) ifail = lbmi_lb_mode_set(lb, lb->opts.mode);   /* Y/Z slabs: no FUSED */
   if (ifail) lbmi_comm_free(lb);
   return ifail;
 }
@@ -3667,11 +3745,52 @@ int lbmi_comm_init_ring(lbmi_t * lb, lbmi_ring_t * ring) {
   }
   HIPCHECK(hipSetDevice(lb->device));
   pthread_mutex_lock(&ring->mu);
+  if (ring->device[lb->opts.cartrank] >= 0) {
+    pthread_mutex_unlock(&ring->mu);
+    return lbmi_fail(LBMI_ERR_STATE, "rank %d of the ring is taken", lb->opts.cartrank);
+  }
+  ring->device[lb->opts.cartrank] = lb->device;
   ring->nattached += 1;
   pthread_mutex_unlock(&ring->mu);
+  /* the receiver pulls from its neighbours' devices: this device must be
+   * able to reach both (whichever of them are other devices; a neighbour
+   * that attaches later enables its own direction, and the copies name both
+   * devices, so an order of attachment is not required) */
+  for (int dn = -1; dn <= 1; dn += 2) {
+    int peer = (lb->opts.cartrank + dn + ring->nranks) % ring->nranks;
+    int pdev;
+    pthread_mutex_lock(&ring->mu);
+    pdev = ring->device[peer];
+    pthread_mutex_unlock(&ring->mu);
+    if (pdev >= 0 && pdev != lb->device) {
+      int can = 0;
+      hipError_t e;
+      HIPCHECK(hipDeviceCanAccessPeer(&can, lb->device, pdev));
+      if (!can) {
+	pthread_mutex_lock(&ring->mu);
+	ring->device[lb->opts.cartrank] = -1;
+	ring->nattached -= 1;
+	pthread_mutex_unlock(&ring->mu);
+	return lbmi_fail(LBMI_ERR_UNSUPPORTED, "device %d cannot access device "
+			 "%d as a peer", lb->device, pdev);
+      }
+      e = hipDeviceEnablePeerAccess(pdev, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+	(void) hipGetLastError();
+	pthread_mutex_lock(&ring->mu);
+	ring->device[lb->opts.cartrank] = -1;
+	ring->nattached -= 1;
+	pthread_mutex_unlock(&ring->mu);
+	return lbmi_fail(LBMI_ERR_HIP, "hipDeviceEnablePeerAccess(%d): %s", pdev,
+			 hipGetErrorString(e));
+      }
+      (void) hipGetLastError();        /* (already enabled is not an error) */
+    }
+  }
   lb->ring = ring;
   lb->have_comm = 1;
   ifail = lbmi_comm_buffers(lb);
+  if (ifail == 0) ifail = lbmi_lb_mode_set(lb, lb->opts.mode);   /* Y/Z slabs: no FUSED */
   if (ifail) lbmi_comm_free(lb);
   return ifail;
 }
@@ -3717,6 +3836,7 @@ int lbmi_comm_free(lbmi_t * lb) {
     if (lb->ring) {
       pthread_mutex_lock(&lb->ring->mu);
       lb->ring->nattached -= 1;
+      lb->ring->device[lb->opts.cartrank] = -1;
       pthread_mutex_unlock(&lb->ring->mu);
       lb->ring = NULL;
     }

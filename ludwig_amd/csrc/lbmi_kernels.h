@@ -136,6 +136,18 @@ int lbmi_k_halo_copy(const lbmi_kparam_t * kp, int dir,
  * unpack the reverse way. Buffer layout: [component k][plane site].
  * blocked != 0: data is a distribution array in the blocked order.
  * layer: 0 for a width-1 swap; l for the (l+1)-th plane of a wider one. */
+/* The same for slabs along direction dir (0 X, 1 Y, 2 Z): the planes of Y and
+ * Z slabs are gathered (rows of nall[Z] values, or single values nall[Z]
+ * apart); buffer layout [component k][plane site], plane sites in the order
+ * of the two remaining coordinates, the faster one fastest. */
+int lbmi_k_halo_pack(const lbmi_kparam_t * kp, int dir,
+		     const lbmi_halo_sel_t * sel, const double * data,
+		     double * buf_lo, double * buf_hi, int blocked, int layer,
+		     void * stream);
+int lbmi_k_halo_unpack(const lbmi_kparam_t * kp, int dir,
+		       const lbmi_halo_sel_t * sel, double * data,
+		       const double * buf_lo, const double * buf_hi, int blocked,
+		       int layer, void * stream);
 int lbmi_k_halo_pack_x(const lbmi_kparam_t * kp, const lbmi_halo_sel_t * sel,
 		       const double * data, double * buf_lo, double * buf_hi,
 		       int blocked, int layer, void * stream);

@@ -1399,8 +1399,12 @@ size_t xaddr(const lbmi_kparam_t & kp, int blocked, int p, size_t i) {
   return (size_t) kp.nsite*p + i;
 }
 
+/* dir: the decomposed direction (0: X, the planes are contiguous runs; 1, 2:
+ * slabs along Y or Z, plane_site gathers rows of nall[Z] values or single
+ * values nall[Z] apart -- halo_swap.c:1074-1274 packs the same sets) */
+
 __global__ __launch_bounds__(BLOCK)
-void k_halo_pack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
+void k_halo_pack_x(lbmi_kparam_t kp, int dir, lbmi_halo_sel_t sel,
 		   const double * __restrict__ data,
 		   double * __restrict__ buf_lo, double * __restrict__ buf_hi,
 		   int blocked, int layer) {
@@ -1408,17 +1412,17 @@ void k_halo_pack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
   /* layer l of a swap of several layers: the (l+1)-th interior plane from
    * either end */
   int j = blockIdx.x*BLOCK + threadIdx.x;
-  int psz = kp.strx;
+  int psz = plane_size(kp, dir);
   if (j >= psz) return;
   int k = blockIdx.y;
   const int nh = kp.nhalo;
   if (k < sel.nhi) {
-    size_t i = (size_t) (nh + layer)*kp.strx + j;
+    size_t i = plane_site(kp, dir, j, nh + layer);
     buf_lo[(size_t) k*psz + j] = data[xaddr(kp, blocked, sel.hi[k], i)];
   }
   else {
     int kk = k - sel.nhi;
-    size_t i = (size_t) (nh + kp.nlocal[0] - 1 - layer)*kp.strx + j;
+    size_t i = plane_site(kp, dir, j, nh + kp.nlocal[dir] - 1 - layer);
     buf_hi[(size_t) kk*psz + j] = data[xaddr(kp, blocked, sel.lo[kk], i)];
   }
 }
@@ -1428,14 +1432,14 @@ void k_halo_pack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
  * UPPER neighbour (its first interior plane, components sel.hi). */
 
 __global__ __launch_bounds__(BLOCK)
-void k_halo_unpack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
+void k_halo_unpack_x(lbmi_kparam_t kp, int dir, lbmi_halo_sel_t sel,
 		     double * __restrict__ data,
 		     const double * __restrict__ buf_lo,
 		     const double * __restrict__ buf_hi, int blocked,
 		     int layer) {
 
   int j = blockIdx.x*BLOCK + threadIdx.x;
-  int psz = kp.strx;
+  int psz = plane_size(kp, dir);
   if (j >= psz) return;
   int k = blockIdx.y;
   const int nh = kp.nhalo;
@@ -1443,12 +1447,12 @@ void k_halo_unpack_x(lbmi_kparam_t kp, lbmi_halo_sel_t sel,
    * high halo plane, y/z halo rows nobody pulls from) do not exist */
   const size_t nfull = blocked ? ((size_t) kp.nsite/LBW)*LBW : (size_t) kp.nsite;
   if (k < sel.nlo) {
-    size_t i = (size_t) (nh - 1 - layer)*kp.strx + j;
+    size_t i = plane_site(kp, dir, j, nh - 1 - layer);
     if (i < nfull) data[xaddr(kp, blocked, sel.lo[k], i)] = buf_lo[(size_t) k*psz + j];
   }
   else {
     int kk = k - sel.nlo;
-    size_t i = (size_t) (nh + kp.nlocal[0] + layer)*kp.strx + j;
+    size_t i = plane_site(kp, dir, j, nh + kp.nlocal[dir] + layer);
     if (i < nfull) data[xaddr(kp, blocked, sel.hi[kk], i)] = buf_hi[(size_t) kk*psz + j];
   }
 }
@@ -3437,18 +3441,47 @@ extern "C" int lbmi_k_halo_copy(const lbmi_kparam_t * kp, int dir,
   return (int) hipGetLastError();
 }
 
+static int host_plane_size(const lbmi_kparam_t * kp, int dir) {
+  return (dir == 0) ? kp->nall[1]*kp->nall[2]
+    : ((dir == 1) ? kp->nall[0]*kp->nall[2] : kp->nall[0]*kp->nall[1]);
+}
+
+extern "C" int lbmi_k_halo_pack(const lbmi_kparam_t * kp, int dir,
+				const lbmi_halo_sel_t * sel,
+				const double * data, double * buf_lo,
+				double * buf_hi, int blocked, int layer,
+				void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  int ncomp = sel->nlo + sel->nhi;
+  if (ncomp == 0) return 0;
+  if (dir < 0 || dir > 2) return (int) hipErrorInvalidValue;
+  dim3 grid((host_plane_size(kp, dir) + BLOCK - 1)/BLOCK, ncomp), block(BLOCK);
+  hipLaunchKernelGGL(k_halo_pack_x, grid, block, 0, st, *kp, dir, *sel, data,
+		     buf_lo, buf_hi, blocked, layer);
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_halo_unpack(const lbmi_kparam_t * kp, int dir,
+				  const lbmi_halo_sel_t * sel,
+				  double * data, const double * buf_lo,
+				  const double * buf_hi, int blocked,
+				  int layer, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  int ncomp = sel->nlo + sel->nhi;
+  if (ncomp == 0) return 0;
+  if (dir < 0 || dir > 2) return (int) hipErrorInvalidValue;
+  dim3 grid((host_plane_size(kp, dir) + BLOCK - 1)/BLOCK, ncomp), block(BLOCK);
+  hipLaunchKernelGGL(k_halo_unpack_x, grid, block, 0, st, *kp, dir, *sel, data,
+		     buf_lo, buf_hi, blocked, layer);
+  return (int) hipGetLastError();
+}
+
 extern "C" int lbmi_k_halo_pack_x(const lbmi_kparam_t * kp,
 				  const lbmi_halo_sel_t * sel,
 				  const double * data, double * buf_lo,
 				  double * buf_hi, int blocked, int layer,
 				  void * stream) {
-  hipStream_t st = (hipStream_t) stream;
-  int ncomp = sel->nlo + sel->nhi;
-  if (ncomp == 0) return 0;
-  dim3 grid((kp->strx + BLOCK - 1)/BLOCK, ncomp), block(BLOCK);
-  hipLaunchKernelGGL(k_halo_pack_x, grid, block, 0, st, *kp, *sel, data,
-		     buf_lo, buf_hi, blocked, layer);
-  return (int) hipGetLastError();
+  return lbmi_k_halo_pack(kp, 0, sel, data, buf_lo, buf_hi, blocked, layer, stream);
 }
 
 extern "C" int lbmi_k_halo_unpack_x(const lbmi_kparam_t * kp,
@@ -3456,13 +3489,7 @@ extern "C" int lbmi_k_halo_unpack_x(const lbmi_kparam_t * kp,
 				    double * data, const double * buf_lo,
 				    const double * buf_hi, int blocked,
 				    int layer, void * stream) {
-  hipStream_t st = (hipStream_t) stream;
-  int ncomp = sel->nlo + sel->nhi;
-  if (ncomp == 0) return 0;
-  dim3 grid((kp->strx + BLOCK - 1)/BLOCK, ncomp), block(BLOCK);
-  hipLaunchKernelGGL(k_halo_unpack_x, grid, block, 0, st, *kp, *sel, data,
-		     buf_lo, buf_hi, blocked, layer);
-  return (int) hipGetLastError();
+  return lbmi_k_halo_unpack(kp, 0, sel, data, buf_lo, buf_hi, blocked, layer, stream);
 }
 
 template <int NCOMP, int RBT>

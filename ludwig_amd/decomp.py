@@ -1,25 +1,33 @@
-"""1-d slab decomposition along X: the reference's Cartesian decomposition
-(coords.c:146-215, `grid N_1_1`) restricted to one axis. X is the slowest
-index of the reference's memory order, so a slab's boundary planes are
-contiguous per population.
+"""1-d slab decomposition: the reference's Cartesian decomposition
+(coords.c:146-215, `grid N_1_1`, `1_N_1` or `1_1_N`, coords_rt.c:46-47)
+restricted to one axis. X (the default) is the slowest index of the
+reference's memory order, so a slab's boundary planes are contiguous per
+population; slabs along Y or Z have planes that are gathered and scattered.
 """
 
 
 class SlabDecomposition:
 
-    def __init__(self, ntotal, cartsz, cartrank, nhalo=1):
+    def __init__(self, ntotal, cartsz, cartrank, nhalo=1, dim=0):
         if cartsz < 1 or not (0 <= cartrank < cartsz):
             raise ValueError("cartsz/cartrank")
-        if ntotal[0] % cartsz != 0:
+        if dim not in (0, 1, 2):
+            raise ValueError("dim")
+        if ntotal[dim] % cartsz != 0:
             # the reference requires an exact division (coords.c:327-338)
-            raise ValueError("ntotal[X] = %d not divisible by %d ranks"
-                             % (ntotal[0], cartsz))
+            raise ValueError("ntotal[%d] = %d not divisible by %d ranks"
+                             % (dim, ntotal[dim], cartsz))
         self.ntotal = tuple(ntotal)
         self.cartsz = cartsz
         self.cartrank = cartrank
         self.nhalo = nhalo
-        self.nlocal = (ntotal[0] // cartsz, ntotal[1], ntotal[2])
-        self.noffset = (self.nlocal[0] * cartrank, 0, 0)
+        self.dim = dim
+        nlocal = list(ntotal)
+        nlocal[dim] = ntotal[dim] // cartsz
+        self.nlocal = tuple(nlocal)
+        noffset = [0, 0, 0]
+        noffset[dim] = nlocal[dim] * cartrank
+        self.noffset = tuple(noffset)
 
     @property
     def nall(self):
@@ -39,11 +47,12 @@ class SlabDecomposition:
         """Message length of one X face with ncomp components
         (hsz[X]*nfel, halo_swap.c:763)."""
         nall = self.nall
-        return nall[1] * nall[2] * ncomp
+        return nall[0] * nall[1] * nall[2] // nall[self.dim] * ncomp
 
     def local_slice(self):
-        """Slice of the global interior x-range owned by this rank."""
-        return slice(self.noffset[0], self.noffset[0] + self.nlocal[0])
+        """Slice of the global interior range (along dim) owned by this rank."""
+        d = self.dim
+        return slice(self.noffset[d], self.noffset[d] + self.nlocal[d])
 
     @staticmethod
     def reduced_populations(cv, axis=0):

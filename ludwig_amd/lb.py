@@ -93,7 +93,7 @@ class LB:
 
     def __init__(self, nvel=19, nlocal=(64, 64, 64), nhalo=1, mode=EAGER,
                  halo_scheme=HALO_FULL, device=0, cartsz=1, cartrank=0,
-                 own_stream=False, ndist=1):
+                 own_stream=False, ndist=1, cartdim=0):
         """own_stream=False (default): the library works on torch's current
         stream of `device`, so its kernels are ordered with torch operations
         on the same tensors. own_stream=True keeps the handle's private
@@ -115,6 +115,7 @@ class LB:
         opts.halo_scheme = halo_scheme
         opts.cartsz = cartsz
         opts.cartrank = cartrank
+        opts.cartdim = cartdim
         _l.check(self._lib.lbmi_create(ctypes.byref(opts), ctypes.byref(self._h)))
         self.nvel = nvel
         self.ndist = ndist
@@ -681,7 +682,7 @@ class Ring:
 
 
 def x_schedule(nvel, nlocal, nhalo, cartsz, cartrank, scheme=HALO_REDUCED,
-               packed=True):
+               packed=True, cartdim=0):
     """lbmi_x_schedule: the point-to-point operations of one X exchange of a
     rank, in issue order, as dicts (kind 'send'|'recv', peer, buffer 'sendlo'|
     'sendhi'|'recvlo'|'recvhi'|'data', offset, count). Pure host: no GPU."""
@@ -693,6 +694,7 @@ def x_schedule(nvel, nlocal, nhalo, cartsz, cartrank, scheme=HALO_REDUCED,
     opts.nhalo = nhalo
     opts.cartsz = cartsz
     opts.cartrank = cartrank
+    opts.cartdim = cartdim
     ops = (_l.XOp * 128)()
     n = ctypes.c_int(0)
     _l.check(lib.lbmi_x_schedule(ctypes.byref(opts), int(scheme), int(bool(packed)),

@@ -25,7 +25,8 @@ class Options(ctypes.Structure):
         ("halo_scheme", ctypes.c_int),
         ("cartsz", ctypes.c_int),
         ("cartrank", ctypes.c_int),
-        ("reserved", ctypes.c_int * 7),
+        ("cartdim", ctypes.c_int),
+        ("reserved", ctypes.c_int * 6),
     ]
 
 

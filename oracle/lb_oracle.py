@@ -174,6 +174,15 @@ def halo_yz(p, data):
     assert rc == 0
 
 
+def halo_dirs(p, data, mask):
+    """The local passes of the directions in mask (1 X, 2 Y, 4 Z), in the
+    order X, Y, Z: what a rank of a slab decomposition does itself around the
+    exchange of the decomposed direction."""
+    nel = data.shape[0]
+    rc = lib().lbo_halo_dirs(ctypes.byref(p), nel, _ptr(data), int(mask))
+    assert rc == 0
+
+
 def field_halo(p, data, nswap):
     """field_halo (field.c) = halo_swap_packed with nswap = the field's halo
     width; data shape (nel, nall...) or (nall...)."""

@@ -33,7 +33,7 @@ def _oracle(nvel, ntotal, nsteps, scheme="m10", force=None):
 
 
 def _run_ring(world, nvel, ntotal, nsteps, mode, tune=(), scheme="m10",
-              force=None, lazy=False, observe=None):
+              force=None, lazy=False, observe=None, dim=0):
     """Each rank in a thread of its own. Returns per rank the interior f, rho,
     u, the local moments, what `observe(lb, hy, rank, step)` returned, and the
     ring size the handle reported."""
@@ -46,9 +46,9 @@ def _run_ring(world, nvel, ntotal, nsteps, mode, tune=(), scheme="m10",
 
     def rank_main(rank):
         try:
-            dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, 1)
+            dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, 1, dim=dim)
             lb = ludwig_amd.LB(nvel, dec.nlocal, 1, mode=mode, cartsz=world,
-                               cartrank=rank, own_stream=True,
+                               cartrank=rank, own_stream=True, cartdim=dim,
                                halo_scheme=ludwig_amd.HALO_REDUCED)
             lb.relaxation_set(scheme, 0.1, 0.3 if scheme == "m10" else 0.1)
             lb.body_force_set(FBODY)
@@ -61,8 +61,9 @@ def _run_ring(world, nvel, ntotal, nsteps, mode, tune=(), scheme="m10",
             f0 = lbo.init_synthetic(p, ntotal, dec.noffset)
             fl = None
             if force is not None:
-                fl = np.ascontiguousarray(
-                    force[:, dec.noffset[0]:dec.noffset[0] + dec.nlocal[0] + 2])
+                sl = [slice(None)] * 4
+                sl[1 + dim] = slice(dec.noffset[dim], dec.noffset[dim] + dec.nlocal[dim] + 2)
+                fl = np.ascontiguousarray(force[tuple(sl)])
             hy = ludwig_amd.Hydro(lb.nall, lb.device, force=fl)
             lb.lb_memcpy_h2d(f0)
             seen = []
@@ -99,8 +100,8 @@ def _run_ring(world, nvel, ntotal, nsteps, mode, tune=(), scheme="m10",
     return out
 
 
-def _join(out, k):
-    return np.concatenate([o[k] for o in out], axis=-3)
+def _join(out, k, dim=0):
+    return np.concatenate([o[k] for o in out], axis=-3 + dim)
 
 
 @pytest.mark.parametrize("tune", [
@@ -348,3 +349,53 @@ def test_long_run_on_the_ring():
     for k in range(6):
         total = sum(o[1][k] for o in out)
         assert abs(total - mref[1]) / mref[1] < 1e-12        # mass is conserved throughout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_peer_transport_line(world):
+    """`python bench.py --gpus N --transport peer`: the N-rank slab step in one
+    process over the peer ring (one device here: the ranks share it; N devices
+    on an N-GPU node, the planes then travel as hipMemcpyPeerAsync). The
+    contract's JSON line, conserved mass, a step time per rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world),
+                        "--transport", "peer", "--size", "48", "32", "32", "--steps", "12",
+                        "--warmup", "2", "--cpu-baseline", "0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert d["n_gpus"] == world and d["unit"] == "MLUPS" and d["value"] > 0
+    assert d["config"]["transport"].startswith("peer")
+    assert len(d["slab_step"]) == world
+    assert all(p["transport"] == "peer" and p["step_ms"] > 0 for p in d["slab_step"])
+    assert d["check"]["mass_drift_rel"] < 1e-12
+
+
+@pytest.mark.parametrize("mode", ["eager", "fused_halo", "fused"])
+@pytest.mark.parametrize("world,nvel,dim", [(2, 19, 2), (3, 19, 2), (2, 27, 2), (3, 19, 1), (2, 27, 1)])
+def test_slabs_along_y_or_z_equal_single_domain(world, nvel, dim, mode):
+    """grid 1_1_N (BASELINE config 3 as written: z slabs) and 1_N_1: the
+    planes of the decomposed direction are gathered into the message buffers
+    and scattered into the halo (k_halo_pack_x / k_halo_unpack_x with a
+    direction), the two other passes stay local, in the order X, Y, Z. FUSED
+    on such slabs runs as FUSED_HALO (the exchange where lb_halo is called,
+    only the propagation deferred). With a force field, rho and u checked."""
+    import ludwig_amd
+    modes = {"eager": ludwig_amd.EAGER, "fused_halo": ludwig_amd.FUSED_HALO,
+             "fused": ludwig_amd.FUSED}
+    ntotal = [10, 6, 14]
+    ntotal[dim] = 12
+    ntotal = tuple(ntotal)
+    nsteps = 4
+    rng = np.random.default_rng(11)
+    force = 1e-6 * rng.standard_normal((3,) + tuple(n + 2 for n in ntotal))
+    out = _run_ring(world, nvel, ntotal, nsteps, modes[mode], force=force, dim=dim)
+    p, f, rho, u = _oracle(nvel, ntotal, nsteps, force=force)
+    assert relmax(_join(out, 0, dim), interior(f, 1)) < 1e-12
+    assert relmax(_join(out, 1, dim), interior(rho, 1)) < 1e-12
+    assert relmax(_join(out, 2, dim), interior(u, 1)) < 1e-12
+    assert all(o[5][0] == world and o[5][2] == 2 for o in out)

@@ -47,17 +47,27 @@ def _selection(cv, reduced):
 
 
 def _exchange_x(dec, f, nh, cv, reduced, packed, tamper=None):
-    """One X exchange of f (nvel, nall) by the product's schedule."""
+    """One exchange of f (nvel, nall) along the decomposed direction by the
+    product's schedule (X slabs, or dec.dim = 1, 2: slabs along Y, Z)."""
     nvel = f.shape[0]
+    dim = dec.dim
     scheme = ludwig_amd.HALO_REDUCED if reduced else ludwig_amd.HALO_FULL
     ops = ludwig_amd.x_schedule(nvel, dec.nlocal, nh, dec.cartsz, dec.cartrank,
-                                scheme=scheme, packed=packed)
+                                scheme=scheme, packed=packed, cartdim=dim)
     if tamper is not None:
         ops = tamper(ops)
-    lo, hi = _selection(cv, reduced)          # fill a LOW halo / a HIGH halo
-    first, last = nh, nh + dec.nlocal[0] - 1
+    if reduced:
+        lo, hi = ludwig_amd.SlabDecomposition.reduced_populations(cv, axis=dim)
+    else:
+        lo, hi = _selection(cv, False)        # fill a LOW halo / a HIGH halo
+    first, last = nh, nh + dec.nlocal[dim] - 1
     psz = dec.plane_doubles(1)
-    flat = f.reshape(-1)
+    whole = f
+    # the decomposed direction in front: f[k, plane] is plane `plane` of
+    # component k, its sites in the order of the two remaining coordinates
+    # (a view: what is stored through it lands in the array)
+    f = np.moveaxis(whole, 1 + dim, 1)
+    flat = whole.reshape(-1)
     assert flat.base is not None or flat is f  # a view: receives land in f
     buf = {"data": flat}
     if packed:
@@ -84,14 +94,14 @@ def _exchange_x(dec, f, nh, cv, reduced, packed, tamper=None):
         f[hi, last + 1] = buf["recvhi"].reshape(len(hi), *f.shape[2:])
 
 
-def _worker(rank, world, port, nvel, ntotal, nsteps, reduced, packed, tamper, q):
+def _worker(rank, world, port, nvel, ntotal, nsteps, reduced, packed, tamper, q, dim=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["GLOO_SOCKET_IFNAME"] = "lo"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         nh = 1
-        dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, nh)
+        dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, nh, dim=dim)
         cv = lbo.model(nvel)["cv"]
         p = lbo.make_param(nvel, dec.nlocal, nh, "m10", 0.1, 0.3, 1.0, FBODY)
         f = lbo.init_synthetic(p, ntotal, dec.noffset)
@@ -99,8 +109,13 @@ def _worker(rank, world, port, nvel, ntotal, nsteps, reduced, packed, tamper, q)
         tf = _TAMPER[tamper] if (tamper and rank == 0) else None
         for _ in range(nsteps):
             lbo.collide(p, f)
-            _exchange_x(dec, f, nh, cv, reduced, packed, tf)   # X first ...
-            lbo.halo_yz(p, f)            # ... then Y, Z over the full extent
+            # X, Y, Z in this order, each over the full extent of the others
+            # (halo_swap.c:709-1063); the decomposed one goes over the ring
+            for d in range(3):
+                if d == dim:
+                    _exchange_x(dec, f, nh, cv, reduced, packed, tf)
+                else:
+                    lbo.halo_dirs(p, f, 1 << d)
             lbo.propagate(p, f, fp)
             f, fp = fp, f
         mo = torch.from_numpy(lbo.moments(p, f)[[0, 1, 5, 6, 7]].copy())
@@ -121,13 +136,13 @@ def _swap_sends(ops):
 _TAMPER = {"swap_sends": _swap_sends}
 
 
-def _run(world, nvel, ntotal, nsteps, reduced, packed, tamper=None):
+def _run(world, nvel, ntotal, nsteps, reduced, packed, tamper=None, dim=0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker,
                          args=(r, world, port, nvel, ntotal, nsteps, reduced,
-                               packed, tamper, q))
+                               packed, tamper, q, dim))
              for r in range(world)]
     for pr in procs:
         pr.start()
@@ -171,6 +186,35 @@ def test_slabs_equal_single_domain(world, nvel, reduced, packed):
         assert np.array_equal(res[0][1], res[r][1])
 
 
+@pytest.mark.parametrize("world,nvel,reduced,dim", [
+    (2, 19, True, 2),           # grid 1_1_2: BASELINE config 3 as it is written (z slabs)
+    (3, 19, False, 2),          # every population
+    (2, 27, True, 2),
+    (3, 19, True, 1),           # grid 1_3_1
+    (2, 27, False, 1),
+])
+def test_slabs_along_y_or_z_equal_single_domain(world, nvel, reduced, dim):
+    """Slabs along Y or Z (coords_rt.c:46-47, `grid 1_N_1`, `1_1_N`): the
+    product's schedule with lbmi_options_t::cartdim -- packed messages of
+    gathered planes (halo_swap.c:1074-1274), the local passes of the other two
+    directions around the exchange in the order X, Y, Z -- reproduces the
+    single domain bit for bit."""
+    ntotal = [5, 6, 7]
+    ntotal[dim] = {2: 8, 3: 9}[world]
+    ntotal, nsteps = tuple(ntotal), 4
+    res = _run(world, nvel, ntotal, nsteps, reduced, True, dim=dim)
+    p, f = _single_domain(nvel, ntotal, nsteps)
+    got = np.concatenate([res[r][0] for r in range(world)], axis=1 + dim)
+    assert np.array_equal(got, interior(f, 1))
+    for r in range(1, world):
+        assert np.array_equal(res[0][1], res[r][1])
+
+
+def test_zero_copy_messages_are_for_x_slabs_only():
+    with pytest.raises(ludwig_amd.LbmiError):
+        ludwig_amd.x_schedule(19, (4, 5, 6), 1, 2, 0, packed=False, cartdim=2)
+
+
 def test_a_wrong_order_is_noticed():
     """Two ranks, one of them issuing its two sends in the other order: the
     planes land in the wrong halos and the result is not the single domain's.
@@ -187,10 +231,11 @@ def test_schedule_pairs_up_for_any_ring_size():
     receive on the peer that it meets under in-order matching, with the same
     length, and the buffers are the ones the layout says (sendhi -> the next
     rank's recvlo, sendlo -> the previous rank's recvhi)."""
-    for nvel in (19, 27):
+    for nvel, cartdim in ((19, 0), (27, 0), (19, 1), (19, 2), (27, 2)):
         for world in range(1, 9):
-            for packed in (True, False):
-                sched = [ludwig_amd.x_schedule(nvel, (4, 5, 6), 1, world, r, packed=packed)
+            for packed in ((True, False) if cartdim == 0 else (True,)):
+                sched = [ludwig_amd.x_schedule(nvel, (4, 5, 6), 1, world, r, packed=packed,
+                                               cartdim=cartdim)
                          for r in range(world)]
                 for r in range(world):
                     for peer in set(op["peer"] for op in sched[r]):
