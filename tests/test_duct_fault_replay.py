@@ -1,7 +1,7 @@
 """The round-1 "Memory access fault by GPU" of the duct case (serial-rect-ct1
 through the binding), replayed as address arithmetic on the CPU.
 
-Cause: the bound lb_collide of round 1 never called
+Cause (CHANGELOG.md, "The round-1 GPU memory fault"): the bound lb_collide of round 1 never called
 lb_collide_param_commit (reference collision.c:157, model.c:342-349), the only
 upload of lb->param to the device copy behind lb->target->param. The
 reference's wall_setu_kernel (wall.c:930-950), run every step by

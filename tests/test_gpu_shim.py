@@ -332,7 +332,7 @@ def test_ludwig_duct_flow_between_walls(mode):
     at the first wall_set_wall_distributions and continues in halo mode.
     (Round 1 skipped this case after one GPU memory fault; the cause --
     lb->target->param never uploaded, so wall_setu_kernel wrote in front of
-    f -- is in DESIGN.md section 8 and tests/test_duct_fault_replay.py.)"""
+    f -- is in CHANGELOG.md and tests/test_duct_fault_replay.py.)"""
     ref = _json.load(open(os.path.join(HERE, "golden", "regression_app_extra.json")))["rect_ct1"]
     log = _ludwig("rect_ct1.inp", mode)
     assert ("execution mode fused -> halo" in log) == (mode in ("fused", None))
