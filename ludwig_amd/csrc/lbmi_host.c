@@ -97,6 +97,9 @@ struct lbmi_s {
   double * fx[4];                    /* sendlo, sendhi, recvlo, recvhi */
   int x_direct;                      /* boundary launch works on fx directly */
   int xsend_valid;                   /* fx send buffers hold the planes of f */
+  int halo_fold;                     /* FUSED_HALO, one rank: the step's kernel computes
+					the halo shell of its result (lbmi_tune) */
+  int halo_fresh;                    /* ... and it did: f has its halo already */
 
   /* free-energy sector: gradient stencil (7 | 27), advection order (1..4) */
   int grad_npt;
@@ -392,6 +395,7 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   lb->kp.lds_cap = 65536;
   lb->x_packed = 1;
   lb->x_direct = 1;
+  lb->halo_fold = 1;
   lb->x_concurrent = 1;
   lb->use_blocked = 1;               /* profiles/r01_blocked_order.txt */
   lb->kp.fe_tiled = 1;
@@ -824,7 +828,11 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
   }
   if (strcmp(key, "x_direct") == 0) {
     lb->x_direct = (value != 0);
-    lb->xsend_valid = 0;
+    lb->xsend_valid = 0; lb->halo_fresh = 0;
+    return 0;
+  }
+  if (strcmp(key, "halo_fold") == 0) {
+    lb->halo_fold = (value != 0);
     return 0;
   }
   if (strcmp(key, "x_concurrent") == 0) {
@@ -1424,7 +1432,7 @@ int lbmi_lb_bind(lbmi_t * lb, double * f, double * fprime) {
    * with the old pair need not hold for what lives at them now */
   memset(lb->known_zero, 0, sizeof(lb->known_zero));
   lbmi_run_graph_release(lb);
-  lb->xsend_valid = 0;
+  lb->xsend_valid = 0; lb->halo_fresh = 0;
   lb->pending_halo = 0;
   lb->pending_prop = 0;
   lb->layout_swapped = 0;
@@ -1480,7 +1488,7 @@ static void lbmi_swapf(lbmi_t * lb) {        /* lb_model_swapf */
   /* another array is current: what the last boundary launch of a slab left
    * in the send buffers belongs to the old one (lbmi_fused_step sets the
    * flag again after its own swap) */
-  lb->xsend_valid = 0;
+  lb->xsend_valid = 0; lb->halo_fresh = 0;
 }
 
 /* INPLACE is honoured on a single rank without a communicator; with slabs
@@ -1537,6 +1545,7 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
   const int xhi = nh + lb->kp.nlocal[X] - 1;
   const int wrapmask = lbmi_wrapmask(lb);
   int xsend = 0;
+  int fresh = 0;
   int ifail;
 
   ifail = lbmi_time_begin(lb);
@@ -1545,8 +1554,17 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
   if (lb->opts.mode == LBMI_MODE_FUSED_HALO) {
     /* the halo swap has been done (and anything may have bounced back into
      * it): pull from the array as it is, halo sites included */
-    KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, 0, 0,
-				    xlo, xhi, 0, -1, NULL, lb->stream));
+    if (lb->halo_fold && lb->opts.cartsz == 1 && !lb->have_comm && h->noise == NULL) {
+      /* ... and compute the halo shell of the result on the way (every shell
+       * site = the collision of its periodic image): the lb_halo that follows
+       * has nothing left to do unless somebody writes to f first */
+      KCHECK(lbmi_k_propagate_collide_halo(&lb->kp, lb->f, lb->fprime, h, lb->stream));
+      fresh = 1;
+    }
+    else {
+      KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, 0, 0,
+				      xlo, xhi, 0, -1, NULL, lb->stream));
+    }
   }
   else if (lb->opts.cartsz == 1 && !lb->have_comm) {
     /* lay: 0 SoA -> SoA; 1 SoA -> blocked; 2 blocked -> blocked */
@@ -1670,6 +1688,7 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
 
   lbmi_swapf(lb);
   lb->xsend_valid = xsend;
+  lb->halo_fresh = fresh;
 
   return 0;
 }
@@ -1841,7 +1860,7 @@ static int lbmi_lb_collide_dev(lbmi_t * lb, const lbmi_hydro_dev_t * hp) {
     int ifail = lbmi_unblock(lb);
     if (ifail) return ifail;
   }
-  lb->xsend_valid = 0;               /* f changes in place */
+  lb->xsend_valid = 0; lb->halo_fresh = 0;               /* f changes in place */
   KCHECK(lbmi_k_collide(&lb->kp, lb->f, &h, lb->stream));
 
   return 0;
@@ -2169,6 +2188,7 @@ int lbmi_wall_bbl_arrays(lbmi_t * lb, int nlink, const int * linki,
   if (nlink < 0 || !linki || !linkj || !linkp || !linku || !ubot || !utop || !fnet) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_wall_bbl_arrays: bad argument");
   }
+  lb->halo_fresh = 0;                /* f is written: a halo swap after this one is real */
   HIPCHECK(hipSetDevice(lb->device));
   if (lb->wall_part == NULL || lb->wall_part_nblk < lbmi_k_wall_nblk(nlink)) {
     if (lb->wall_part) HIPCHECK(hipFree(lb->wall_part));
@@ -2420,6 +2440,7 @@ int lbmi_wall_bbl_slip_arrays(lbmi_t * lb, int nlink, const int * linki,
       !stab || !fnet) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_wall_bbl_slip_arrays: bad argument");
   }
+  lb->halo_fresh = 0;                /* f is written: a halo swap after this one is real */
   HIPCHECK(hipSetDevice(lb->device));
   if (lb->wall_part == NULL || lb->wall_part_nblk < lbmi_k_wall_nblk(nlink)) {
     if (lb->wall_part) HIPCHECK(hipFree(lb->wall_part));
@@ -2510,7 +2531,7 @@ int lbmi_lb_collide_fe(lbmi_t * lb, const lbmi_hydro_t * hydro,
   }
   ifail = lbmi_lb_flush(lb);
   if (ifail) return ifail;
-  lb->xsend_valid = 0;
+  lb->xsend_valid = 0; lb->halo_fresh = 0;
   KCHECK(lbmi_k_collide_fe(&lb->kp, lb->f, &h, fe->a, fe->b, fe->kappa,
 			   fe->phi, fe->grad, fe->delsq, lb->stream));
   return 0;
@@ -2598,7 +2619,12 @@ int lbmi_lb_halo(lbmi_t * lb) {
     if (lb->pending_prop) {
       return lbmi_fail(LBMI_ERR_STATE, "lb_halo while a propagation is pending");
     }
-    if (lb->opts.mode == LBMI_MODE_FUSED_HALO ||
+    if (lb->opts.mode == LBMI_MODE_FUSED_HALO && lb->halo_fresh) {
+      /* the kernel of the collision has computed the shell already and
+       * nothing has written to f since (anything that does clears the flag) */
+      lb->halo_done = 1;
+    }
+    else if (lb->opts.mode == LBMI_MODE_FUSED_HALO ||
 	(lb->opts.ndist == 2 && (lb->opts.cartsz > 1 || lb->have_comm))) {
       /* eager: f gets its halo now; only the propagation will be deferred
        * (two distributions on slabs: FUSED is FUSED_HALO; on one GPU the
@@ -2926,7 +2952,7 @@ int lbmi_lb_memcpy_h2d(lbmi_t * lb, const double * f_host) {
   lb->halo_seen = 0;
   lb->halo_done = 0;
   lb->blocked = 0;
-  lb->xsend_valid = 0;
+  lb->xsend_valid = 0; lb->halo_fresh = 0;
   HIPCHECK(hipMemcpyAsync(lb->f, f_host, sz, hipMemcpyHostToDevice, lb->stream));
   HIPCHECK(hipStreamSynchronize(lb->stream));
   return 0;
@@ -2947,7 +2973,7 @@ int lbmi_lb_dirty(lbmi_t * lb) {
     return lbmi_fail(LBMI_ERR_STATE, "lbmi_lb_dirty: a deferred state cannot "
 		     "have been rewritten by the caller (lbmi_lb_flush first)");
   }
-  lb->xsend_valid = 0;
+  lb->xsend_valid = 0; lb->halo_fresh = 0;
   lb->hydro_stale = 0;
   return 0;
 }
@@ -3433,7 +3459,7 @@ int lbmi_lb_records_unpack(lbmi_t * lb, const double * records) {
   lb->halo_seen = 0;
   lb->halo_done = 0;
   lb->blocked = 0;
-  lb->xsend_valid = 0;
+  lb->xsend_valid = 0; lb->halo_fresh = 0;
   if (lb->layout_swapped) {
     lb->layout_swapped = 0;
   }
@@ -3701,7 +3727,7 @@ static int lbmi_comm_buffers(lbmi_t * lb) {
       return lbmi_fail(LBMI_ERR_HIP, "hipMalloc (exchange buffers of the fused step) failed");
     }
   }
-  lb->xsend_valid = 0;
+  lb->xsend_valid = 0; lb->halo_fresh = 0;
   return 0;
 }
 
@@ -3832,7 +3858,7 @@ int lbmi_comm_free(lbmi_t * lb) {
       if (lb->fx[k]) hipFree(lb->fx[k]);
       lb->fx[k] = NULL;
     }
-    lb->xsend_valid = 0;
+    lb->xsend_valid = 0; lb->halo_fresh = 0;
     if (lb->ring) {
       pthread_mutex_lock(&lb->ring->mu);
       lb->ring->nattached -= 1;

@@ -104,6 +104,13 @@ int lbmi_k_propagate_collide(const lbmi_kparam_t * kp, const double * f,
 			     double * fprime, const lbmi_hydro_dev_t * h,
 			     int wrapmask, int lay, int xlo, int xhi, int xlo2,
 			     int xhi2, const lbmi_xbuf_t * xb, void * stream);
+/* The FUSED_HALO step of one rank, SoA -> SoA, pulling from f with its halo
+ * as it is, AND the width-1 halo shell of fprime computed on the way (every
+ * shell site = the collision of its periodic image): what three
+ * lbmi_k_halo_copy launches on fprime would deliver. No fluctuations. */
+int lbmi_k_propagate_collide_halo(const lbmi_kparam_t * kp, const double * f,
+				  double * fprime, const lbmi_hydro_dev_t * h,
+				  void * stream);
 int lbmi_k_blocked_sites(const lbmi_kparam_t * kp);
 /* rho, u of the collision that left the post-collision state f (SoA, or the
  * blocked order): u = (sum f'_p c_p - F/2)/rho at interior fluid sites */

@@ -907,9 +907,15 @@ __device__ __forceinline__
 void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
 		      const lbmi_hydro_dev_t & h, int i,
 		      PulledSite<NVEL> & ps, const lbmi_xbuf_t & xb,
-		      double fx = 0.0, double fy = 0.0, double fz = 0.0) {
+		      double fx = 0.0, double fy = 0.0, double fz = 0.0,
+		      int istore = -1, bool image = false) {
 
+  /* i: the site whose collision this is (its force, status, viscosity);
+   * istore >= 0: where the populations go instead -- a halo site whose
+   * periodic image i is (k_propagate_collide_halo); rho and u of an image are
+   * not stored again */
   const size_t ns = (size_t) kp.nsite;
+  const int is = (istore >= 0) ? istore : i;
   bool active = ps.s.interior;
   if (h.status) active = active && (h.status[i] == 0);
 #if LBMI_ABL_NOCOLLIDE
@@ -938,6 +944,9 @@ void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
     if constexpr (!HIO) {
       /* nothing to store */
     }
+    else if (image) {
+      /* the collision of the site itself stores them */
+    }
     else if (kp.nt_store & 2) {
       /* rho and u are written once and not read again by this kernel */
       if (h.rho) __builtin_nontemporal_store(rho, &h.rho[i]);
@@ -959,10 +968,10 @@ void pc_collide_store(const lbmi_kparam_t & kp, double * __restrict__ fp,
 
   static_for<0, NVEL>([&](auto P) {
     if constexpr (NTS) {
-      __builtin_nontemporal_store(ps.fl[P], &fp[faddr<NVEL, WB>(ns, P, i)]);
+      __builtin_nontemporal_store(ps.fl[P], &fp[faddr<NVEL, WB>(ns, P, is)]);
     }
     else {
-      stf(&fp[faddr<NVEL, WB>(ns, P, i)], ps.fl[P]);
+      stf(&fp[faddr<NVEL, WB>(ns, P, is)], ps.fl[P]);
     }
   });
 
@@ -1039,6 +1048,63 @@ void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
       pc_collide_store<NVEL, SCHEME, ORD != 0, (LAY & 4) != 0, HIO, XB, NZ>(kp, fp, h, i[k], ps[k], xb);
     }
   });
+}
+
+/* k_propagate_collide_halo: the step of LBMI_MODE_FUSED_HALO on one rank with
+ * the halo swap of its OWN result folded in. f is the reference's
+ * post-collision state with its halo (whatever bounced back into it included);
+ * the kernel pulls from it as it is, SoA -> SoA. The width-1 shell around the
+ * interior of fprime -- which k_propagate_collide fills with zeros and three
+ * k_halo_copy launches then overwrite with the periodic images (19 or 27
+ * planes read and written again, per direction, in sequence) -- is computed
+ * here: a shell lane runs the collision of its periodic image (same inputs,
+ * same instructions, so the same bits as the copy would have delivered) and
+ * stores it at its own place. 2.3 % more collisions on lanes that were
+ * storing zeros, two x planes more, no halo launch, no second pass over the
+ * boundary planes. What lb_halo means afterwards: nothing left to do, as long
+ * as nobody has written to f in between (lbmi_host.c: halo_fresh). */
+
+template <int NVEL, int SCHEME, bool HIO>
+__global__ __launch_bounds__(BLOCK, LBMI_WAVES)
+void k_propagate_collide_halo(lbmi_kparam_t kp, const double * __restrict__ f,
+			      double * __restrict__ fp, lbmi_hydro_dev_t h,
+			      int i0, int i1, unsigned nblk) {
+
+  static_assert(SPT == 1, "one site per thread");
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  const int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+
+  const lbmi_xbuf_t none = {nullptr, nullptr, nullptr, nullptr};
+  const Site s = decode(kp, i);
+  const int nh = kp.nhalo;
+  /* inside the interior or the width-1 shell around it? (an outer halo layer
+   * of a wider allocation keeps the zero fill) */
+  const bool near = (s.x >= nh - 1 && s.x <= nh + kp.nlocal[0] &&
+		     s.y >= nh - 1 && s.y <= nh + kp.nlocal[1] &&
+		     s.z >= nh - 1 && s.z <= nh + kp.nlocal[2]);
+  const bool inside = s.interior && s.x >= nh && s.x < nh + kp.nlocal[0];
+  int isrc = i;
+  if (near && !inside) {
+    /* the periodic image: every coordinate back into the local domain */
+    int dx = 0, dy = 0, dz = 0;
+    if (s.x < nh) dx = kp.nlocal[0]; else if (s.x >= nh + kp.nlocal[0]) dx = -kp.nlocal[0];
+    if (s.y < nh) dy = kp.nlocal[1]; else if (s.y >= nh + kp.nlocal[1]) dy = -kp.nlocal[1];
+    if (s.z < nh) dz = kp.nlocal[2]; else if (s.z >= nh + kp.nlocal[2]) dz = -kp.nlocal[2];
+    isrc = i + dx*kp.strx + dy*kp.stry + dz;
+  }
+  PulledSite<NVEL> ps;
+  if (near) {
+    pc_pull<NVEL, false, false, false>(kp, f, 0, isrc, ps, none);
+  }
+  else {
+    ps.s = s;
+    ps.s.interior = false;
+    static_for<0, NVEL>([&](auto P) { ps.fl[P] = 0.0; });
+  }
+  pc_collide_store<NVEL, SCHEME, false, false, HIO, false>(kp, fp, h, isrc, ps, none,
+							    0.0, 0.0, 0.0, i, isrc != i);
 }
 
 /* k_relayout: the whole array from one order to the other (every whole
@@ -3314,6 +3380,56 @@ extern "C" int lbmi_k_propagate_collide(const lbmi_kparam_t * kp,
   }
   if (kp->nvel == 27) {
     return launch_pc_any<27>(*kp, f, fprime, *h, wrapmask, lay, i0, i1, j0, j1, st, xb);
+  }
+  return (int) hipErrorInvalidValue;
+}
+
+template <int NVEL, bool HIO>
+static int launch_pc_halo(const lbmi_kparam_t & kp, const double * f, double * fp,
+			  const lbmi_hydro_dev_t & h, hipStream_t st) {
+  /* the x planes of the interior and the halo plane on either side */
+  const int i0 = (kp.nhalo - 1)*kp.strx;
+  const int i1 = (kp.nhalo + kp.nlocal[0] + 1)*kp.strx;
+  const int i0a = (i0/LBMI_ALIGN)*LBMI_ALIGN;
+  const unsigned nblk = (unsigned) ((i1 - i0a + BLOCK - 1)/BLOCK);
+  dim3 grid(grid_for(nblk, (unsigned) kp.xcd_group)), block(BLOCK);
+  unsigned lds = (kp.lds_cap <= 65536 && nblk > 4096u) ? (unsigned) kp.lds_cap : 0u;
+  switch (kp.scheme) {
+  case LBMI_M10:
+    hipLaunchKernelGGL((k_propagate_collide_halo<NVEL, LBMI_M10, HIO>), grid, block,
+		       lds, st, kp, f, fp, h, i0, i1, nblk);
+    break;
+  case LBMI_BGK:
+    hipLaunchKernelGGL((k_propagate_collide_halo<NVEL, LBMI_BGK, HIO>), grid, block,
+		       lds, st, kp, f, fp, h, i0, i1, nblk);
+    break;
+  case LBMI_TRT:
+    if constexpr (NVEL == 19) {
+      hipLaunchKernelGGL((k_propagate_collide_halo<NVEL, LBMI_TRT, HIO>), grid, block,
+			 lds, st, kp, f, fp, h, i0, i1, nblk);
+      break;
+    }
+    return (int) hipErrorInvalidValue;
+  default:
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_propagate_collide_halo(const lbmi_kparam_t * kp,
+					     const double * f, double * fprime,
+					     const lbmi_hydro_dev_t * h,
+					     void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  const bool hio = (h->force != nullptr || h->rho != nullptr || h->u != nullptr);
+  if (h->noise != nullptr) return (int) hipErrorInvalidValue;
+  if (kp->nvel == 19) {
+    return hio ? launch_pc_halo<19, true>(*kp, f, fprime, *h, st)
+      : launch_pc_halo<19, false>(*kp, f, fprime, *h, st);
+  }
+  if (kp->nvel == 27) {
+    return hio ? launch_pc_halo<27, true>(*kp, f, fprime, *h, st)
+      : launch_pc_halo<27, false>(*kp, f, fprime, *h, st);
   }
   return (int) hipErrorInvalidValue;
 }

@@ -500,3 +500,64 @@ def test_mode_set_at_every_call_point():
             out = lb.lb_memcpy_d2h()
             assert relmax(interior(out, 1), interior(f, 1)) < 1e-12, (point, first, then)
             lb.free()
+
+
+@pytest.mark.parametrize("nvel,nlocal,nhalo,scheme", [
+    (19, (10, 7, 12), 1, "m10"), (19, (6, 8, 5), 2, "trt"), (27, (7, 6, 9), 1, "bgk"),
+    (19, (9, 8, 1), 1, "m10"),          # a quasi-two-dimensional box
+])
+def test_halo_computed_by_the_collision_kernel_is_the_swapped_halo(nvel, nlocal, nhalo, scheme):
+    """LBMI_MODE_FUSED_HALO on one rank: the kernel of lb_collide computes the
+    width-1 halo shell of its own result (each shell site = the collision of
+    its periodic image, k_propagate_collide_halo), and the lb_halo that
+    follows has nothing left to do. What is observable between lb_halo and
+    lb_propagation -- the array other Ludwig kernels act on -- must be what
+    three halo copies deliver: compared BIT FOR BIT, interior and shell, with
+    the same handle run with lbmi_tune halo_fold 0, with a force field and
+    solid sites, step after step; then with a writer between lb_collide and
+    lb_halo that owns up (lbmi_lb_dirty), where the halo swap must be real."""
+    import ludwig_amd
+    import torch
+    from oracle import lb_oracle as lbo
+    zeta = 0.3 if scheme == "m10" else 0.1
+    p = lbo.make_param(nvel, nlocal, nhalo, scheme, 0.1, zeta, 1.0, (1e-6, 2e-6, -1e-6))
+    f0 = lbo.init_synthetic(p)
+    nall = lbo.nall(p)
+    rng = np.random.default_rng(21)
+    force = 1e-6 * rng.standard_normal((3,) + nall)
+    status = np.zeros(nall, dtype=np.int8)
+    if min(nlocal) > 4:
+        status[nhalo + 2:nhalo + 4, nhalo + 1:nhalo + 3, nhalo + 2:nhalo + 5] = 1
+    h = nhalo - 1
+    shell = (slice(None),) + ((slice(h, -h) if h else slice(None)),) * 3
+    seen = {}
+    for fold in (0, 1):
+        lb = ludwig_amd.LB(nvel, nlocal, nhalo, mode=ludwig_amd.FUSED_HALO)
+        lb.relaxation_set(scheme, 0.1, zeta)
+        lb.body_force_set((1e-6, 2e-6, -1e-6))
+        lb.tune("halo_fold", fold)
+        hy = ludwig_amd.Hydro(lb.nall, lb.device, force=force, status=status)
+        lb.lb_memcpy_h2d(f0)
+        rec = []
+        for n in range(5):
+            lb.lb_collide(hy)
+            if n == 3:
+                # somebody rewrites an interior plane between collide and halo
+                # (the Lees-Edwards reprojection does, through lb_memcpy) and
+                # says so: this halo swap has to be done
+                lb.synchronize()
+                lb.f[:, nhalo, :, :] *= 1.0 + 1e-3
+                torch.cuda.synchronize()
+                lb.lb_dirty()
+            lb.lb_halo()
+            lb.synchronize()
+            torch.cuda.synchronize()
+            rec.append(lb.f.cpu().numpy()[shell].copy())
+            lb.lb_propagation()
+        rec.append(interior(lb.lb_memcpy_d2h(), nhalo).copy())
+        lb.synchronize()
+        rec.append(interior(hy.u.cpu().numpy(), nhalo).copy())
+        lb.free()
+        seen[fold] = rec
+    for a, b in zip(seen[0], seen[1]):
+        assert np.array_equal(a, b)
