@@ -17,7 +17,12 @@
  *      phi_lb_to_field() phi_lb_coupler.h  (replaces phi_lb_coupler.c:39-64)
  *      hydro_u_zero(), hydro_f_zero()  hydro.h:64-65 (hydro.c:279-330)
  *      hydro_memcpy()    hydro.h:56        (the original, after rho and u that a
- *                        lazy collision still owes have been formed: LBMI_HYDRO)
+ *                        collision has left on demand have been formed; a copy to
+ *                        the device is reported to the library as a foreign write)
+ *      lb_bc_inflow_rhou_create(), lb_bc_outflow_rhou_create()
+ *                        lb_bc_inflow_rhou.h:39, lb_bc_outflow_rhou.h:36: the
+ *                        originals, counted (a run with open boundaries keeps the
+ *                        reference's state between lb_halo and lb_propagation)
  *      field_halo()      field.h:96        (field.c; FIELD_HALO_TARGET only)
   *      field_grad_compute() field_grad.h:49 (3d_7pt_fluid / 3d_27pt_fluid d2)
  *      wall_set_wall_distributions() wall.h:100, bounce_back_on_links()
@@ -63,9 +68,15 @@
  *  -Dcahn_hilliard_stats=cahn_hilliard_stats_ref -Dcahn_hilliard_stats_time0=
  *  cahn_hilliard_stats_time0_ref) so that their originals remain
  *  available as fall-backs (colloids, Lees-Edwards, host halo
- *  schemes, noise), and this file is compiled
+ *  schemes, noise; lb_bc_inflow_rhou.c with -Dlb_bc_inflow_rhou_create=
+ *  lb_bc_inflow_rhou_create_ref, lb_bc_outflow_rhou.c likewise), and this file
+ *  is compiled
  *  with the same -D_D3Q19_|-D_D3Q27_ -DADDR_SOA as the rest of libludwig.a
  *  and linked with -llbmi. See INTEGRATION.md.
+ *
+ *  No environment variable is needed: a run starts in LBMI_MODE_FUSED with
+ *  hydro->rho, u on demand and the binding demotes it per consumer it detects
+ *  (shim_handle, lb_collide, shim_needs_canonical_f below).
  *
  *  This file is compile-checked against the reference headers by
  *  __graft_entry__.build() when /root/reference is present (gcc
