@@ -2335,6 +2335,7 @@ void k_symm_lb_step(lbmi_kparam_t kp, const double * __restrict__ f,
    * free-energy arithmetic runs while the distributions are on their way */
   double ph[25];
   double uc[3][3];
+  int up[3] = {0, 0, 0}, um[3] = {0, 0, 0};
   if (s.interior) {
     /* offsets (in sites) of the neighbours at distance -2 .. +2 in each
      * direction, across a periodic face: the image inside the domain */
@@ -2357,9 +2358,17 @@ void k_symm_lb_step(lbmi_kparam_t kp, const double * __restrict__ f,
       constexpr int a = q25(m, 0), b = q25(m, 1), c = q25(m, 2);
       ph[m] = phi[i + ox[a + 2] + oy[b + 2] + oz[c + 2]];
     });
-    /* uc[id][0..2]: u_id at the site, at its + and at its - neighbour in id */
-    const int up[3] = {ox[3], oy[3], oz[3]};
-    const int um[3] = {ox[1], oy[1], oz[1]};
+    up[0] = ox[3]; up[1] = oy[3]; up[2] = oz[3];
+    um[0] = ox[1]; um[1] = oy[1]; um[2] = oz[1];
+  }
+
+  PulledSite<NVEL> ps;
+  pc_pull<NVEL, true, ORD == 2, false>(kp, f, 7, i, ps, none);
+
+  if (s.interior) {
+    /* uc[id][0..2]: u_id at the site, at its + and at its - neighbour in id:
+     * requested last (the fluxes are the last thing evaluated, and nine
+     * values fewer are alive while the stresses are) */
     static_for<0, 3>([&](auto D) {
       constexpr int id = D;
       uc[id][0] = uprev[ns*id + i];
@@ -2367,9 +2376,6 @@ void k_symm_lb_step(lbmi_kparam_t kp, const double * __restrict__ f,
       uc[id][2] = uprev[ns*id + (size_t) (i + um[id])];
     });
   }
-
-  PulledSite<NVEL> ps;
-  pc_pull<NVEL, true, ORD == 2, false>(kp, f, 7, i, ps, none);
 
   double frc[3] = {0.0, 0.0, 0.0};
   if (s.interior) {
