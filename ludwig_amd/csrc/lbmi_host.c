@@ -1512,7 +1512,10 @@ static int lbmi_deferred(const lbmi_t * lb) {
 static int lbmi_blocked_ok(const lbmi_t * lb) {
   int nfull = lbmi_k_blocked_sites(&lb->kp);
   if (!lb->use_blocked || lb->opts.mode != LBMI_MODE_FUSED) return 0;
-  if (lb->opts.ndist != 1) return 0;
+  /* two distributions ([site/256][n*nvel + p][site%256]): one rank, no
+   * fluctuations (their collision has no variant in this order) */
+  if (lb->opts.ndist != 1 &&
+      (lb->opts.cartsz > 1 || lb->have_comm || lb->noise_state != NULL)) return 0;
   if (lb->opts.cartsz == 1 && !lb->have_comm) {
     /* every pull is wrapped by index: nothing beyond the interior planes */
     int last = (lb->kp.nhalo + lb->kp.nlocal[X])*lb->kp.strx;
@@ -1529,7 +1532,7 @@ static int lbmi_blocked_ok(const lbmi_t * lb) {
 
 static int lbmi_unblock(lbmi_t * lb) {
   if (!lb->blocked) return 0;
-  KCHECK(lbmi_k_relayout(&lb->kp, lb->f, lb->fprime, 0, lb->stream));
+  KCHECK(lbmi_k_relayout_n(&lb->kp, lb->opts.ndist, lb->f, lb->fprime, 0, lb->stream));
   lbmi_swapf(lb);
   lb->blocked = 0;
   return 0;
@@ -2546,7 +2549,7 @@ int lbmi_lb_phi_to_field(lbmi_t * lb, double * phi) {
    * straight from the post-collision array (which has its halo) */
   KCHECK(lbmi_k_phi_from_g(&lb->kp, lb->f, phi, lb->pending_prop,
 			   (lb->pending_prop && !lb->halo_done) ? 7 : 0,
-			   lb->stream));
+			   lb->blocked, lb->stream));
   return 0;
 }
 
@@ -2584,19 +2587,39 @@ int lbmi_lb_collide_binary(lbmi_t * lb, const lbmi_hydro_t * hydro,
     /* propagation(t) of both distributions inside collision(t+1): from the
      * halo where lb_halo has filled it (FUSED_HALO), by index wrap where that
      * is pending as well (FUSED on one GPU) */
+    /* FUSED on one GPU (the halo swap pending as well: every pull wraps by
+     * index): the deferred state in the blocked order, as for one
+     * distribution. lay: 0 SoA -> SoA, 1 SoA -> blocked, 2 blocked -> blocked */
+    int lay = (!lb->halo_done && lbmi_blocked_ok(lb)) ? (lb->blocked ? 2 : 1) : 0;
+    if (lay == 0 && lb->blocked) {
+      int ifail = lbmi_unblock(lb);
+      if (ifail) return ifail;
+    }
+    if (lb->nt_store_mode >= 0) {
+      lb->kp.nt_store = lb->nt_store_mode;
+    }
+    else {
+      size_t bytes = 4*sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel;
+      lb->kp.nt_store = (bytes > ((size_t) 256 << 20)) ? 1 : 0;
+    }
     KCHECK(lbmi_k_collide_binary(&lb->kp, lb->f, lb->fprime, &h, fe->a, fe->b,
 				 fe->kappa, 2.0/(1.0 + 2.0*fe->mobility),
 				 fe->phi, fe->grad, fe->delsq,
-				 lb->halo_done ? 0 : 7, lb->stream));
+				 lb->halo_done ? 0 : 7, lay, lb->stream));
     lb->pending_prop = 0;
     lb->pending_halo = 0;
     lb->halo_done = 0;
     lbmi_swapf(lb);
+    lb->blocked = (lay != 0);
     return 0;
+  }
+  if (lb->blocked) {
+    int ifail = lbmi_unblock(lb);
+    if (ifail) return ifail;
   }
   KCHECK(lbmi_k_collide_binary(&lb->kp, lb->f, lb->f, &h, fe->a, fe->b,
 			       fe->kappa, 2.0/(1.0 + 2.0*fe->mobility), fe->phi,
-			       fe->grad, fe->delsq, 0, lb->stream));
+			       fe->grad, fe->delsq, 0, 0, lb->stream));
   return 0;
 }
 

@@ -219,14 +219,22 @@ int lbmi_k_collide_fe(const lbmi_kparam_t * kp, double * f,
  * populations come from i - c_p (the array has its halo, wrapmask 0) or, in
  * the directions of wrapmask, from the periodic image inside the domain (the
  * halo swap is pending as well); results go to f2 */
+/* blocked != 0 (pull only): f2 is a deferred state in the blocked order of
+ * two distributions, [site/256][n*nvel + p][site%256]; lay of
+ * lbmi_k_collide_binary as in lbmi_k_propagate_collide (0 SoA -> SoA, 1 SoA ->
+ * blocked, 2 blocked -> blocked; nontemporal stores with kp->nt_store & 1) */
 int lbmi_k_phi_from_g(const lbmi_kparam_t * kp, const double * f2,
-		      double * phi, int pull, int wrapmask, void * stream);
+		      double * phi, int pull, int wrapmask, int blocked,
+		      void * stream);
 int lbmi_k_collide_binary(const lbmi_kparam_t * kp, const double * src,
 			  double * f2,
 			  const lbmi_hydro_dev_t * h, double a, double b,
 			  double kappa, double rtau2, const double * phi,
 			  const double * grad, const double * delsq,
-			  int wrapmask, void * stream);
+			  int wrapmask, int lay, void * stream);
+/* lbmi_k_relayout for a state of ndist distributions (ndist*nvel components) */
+int lbmi_k_relayout_n(const lbmi_kparam_t * kp, int ndist, const double * src,
+		      double * dst, int to_blocked, void * stream);
 
 /* Bounce-back on links (wall_bbl_kernel, wall.c:996-1107). Tables travel by
  * value; part: nblk*3 doubles of per-block momentum, added to fnet[3] (device)

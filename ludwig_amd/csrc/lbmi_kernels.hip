@@ -1111,6 +1111,8 @@ void k_propagate_collide_halo(lbmi_kparam_t kp, const double * __restrict__ f,
  * block of LBW sites, halo included), src != dst. Used when a deferred
  * blocked state has to become observable again (lbmi_lb_flush). */
 
+/* (NVEL here: the number of components per site: nvel, or 2 nvel for the
+ * two distributions of a symmetric_lb state) */
 template <int NVEL, bool TO_BLK>
 __global__ __launch_bounds__(BLOCK)
 void k_relayout(lbmi_kparam_t kp, const double * __restrict__ src,
@@ -2458,7 +2460,9 @@ __device__ __forceinline__ int pull_offset(const lbmi_kparam_t & kp,
   return off;
 }
 
-template <int NVEL, bool PULL>
+/* RB: f2 is in the blocked order of a deferred two-distribution state,
+ * [site/256][n*NVEL + p][site%256] (faddr with 2 NVEL components) */
+template <int NVEL, bool PULL, bool RB = false>
 __global__ __launch_bounds__(BLOCK)
 void k_phi_from_g(lbmi_kparam_t kp, const double * __restrict__ f2,
 		  double * __restrict__ phi, int wrapmask, int i0, int i1,
@@ -2470,7 +2474,6 @@ void k_phi_from_g(lbmi_kparam_t kp, const double * __restrict__ f2,
   Site s = decode(kp, i);
   if (!s.interior) return;
   const size_t ns = (size_t) kp.nsite;
-  const double * __restrict__ g = f2 + ns*NVEL;
   double sum = 0.0;
   /* PULL: the propagation is pending: population p of this site still sits
    * at i - c_p of the post-collision array -- in its halo where that has
@@ -2480,7 +2483,7 @@ void k_phi_from_g(lbmi_kparam_t kp, const double * __restrict__ f2,
   static_for<0, NVEL>([&](auto P) {
     constexpr int p = P;
     const int off = PULL ? pull_offset<NVEL, p>(kp, w) : 0;
-    sum += g[ns*p + (i - off)];
+    sum += f2[faddr<2*NVEL, RB>(ns, NVEL + p, i - off)];
   });
   phi[i] = sum;
 }
@@ -2489,7 +2492,11 @@ void k_phi_from_g(lbmi_kparam_t kp, const double * __restrict__ f2,
  * fused in: populations pulled from src (the post-collision array with its
  * halo), results written to f2 (the other array), as k_propagate_collide
  * does for one distribution. */
-template <int NVEL, int SCHEME, bool PULL, bool NZ = false>
+/* LAY as k_propagate_collide (PULL only): 0 SoA -> SoA, 1 SoA -> blocked,
+ * 2 blocked -> blocked, + 4 nontemporal stores; the blocked order of two
+ * distributions is [site/256][n*NVEL + p][site%256]: a block writes ONE
+ * contiguous 2*NVEL*2 KiB chunk instead of 2*NVEL pieces nsite*8 B apart */
+template <int NVEL, int SCHEME, bool PULL, bool NZ = false, int LAY = 0>
 __global__ __launch_bounds__(BLOCK)
 void k_collide_binary(lbmi_kparam_t kp, const double * src, double * f2,
 		      lbmi_hydro_dev_t h, Symm q, double rtau2,
@@ -2499,16 +2506,17 @@ void k_collide_binary(lbmi_kparam_t kp, const double * src, double * f2,
 		      int i0, int i1, unsigned nblk) {
 
   using M = Model<NVEL>;
+  constexpr bool RB = ((LAY & 3) == 2), WB = ((LAY & 3) != 0), NTS = ((LAY & 4) != 0);
+  constexpr int ALIGNV = ((LAY & 3) == 0) ? LBMI_ALIGN : LBW;
+  static_assert(LAY == 0 || PULL, "the blocked order is a deferred state");
   unsigned lb;
   if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
-  int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  int i = (i0/ALIGNV)*ALIGNV + (int) (lb*BLOCK + threadIdx.x);
   if (i < i0 || i >= i1) return;
   Site s = decode(kp, i);
   if (!s.interior) return;
 
   const size_t ns = (size_t) kp.nsite;
-  double * g = f2 + ns*NVEL;
-  const double * gsrc = src + ns*NVEL;
 
   double fl[NVEL];
   double gl[NVEL];
@@ -2516,8 +2524,8 @@ void k_collide_binary(lbmi_kparam_t kp, const double * src, double * f2,
   static_for<0, NVEL>([&](auto P) {
     constexpr int p = P;
     const int off = PULL ? pull_offset<NVEL, p>(kp, w) : 0;
-    fl[p] = src[ns*p + (i - off)];
-    if constexpr (p > 0) gl[p] = gsrc[ns*p + (i - off)];
+    fl[p] = src[faddr<2*NVEL, RB>(ns, p, i - off)];
+    if constexpr (p > 0) gl[p] = src[faddr<2*NVEL, RB>(ns, NVEL + p, i - off)];
   });
 
   double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
@@ -2550,7 +2558,10 @@ void k_collide_binary(lbmi_kparam_t kp, const double * src, double * f2,
     collide_site_impl<NVEL, SCHEME, true>(fl, frc, rx, sth, rho, u);
   }
 
-  static_for<0, NVEL>([&](auto P) { f2[ns*P + i] = fl[P]; });
+  static_for<0, NVEL>([&](auto P) {
+    if constexpr (NTS) __builtin_nontemporal_store(fl[P], &f2[faddr<2*NVEL, WB>(ns, P, i)]);
+    else f2[faddr<2*NVEL, WB>(ns, P, i)] = fl[P];
+  });
   if (h.u) {
     h.u[i] = u[0];
     h.u[hstride(kp, h) + i] = u[1];
@@ -2601,7 +2612,8 @@ void k_collide_binary(lbmi_kparam_t kp, const double * src, double * f2,
     constexpr double wp = M::w(p);
     double gn = wp*(jdotc*3.0 + sq*4.5);
     if constexpr (p == 0) gn += ph;
-    g[ns*p + i] = gn;
+    if constexpr (NTS) __builtin_nontemporal_store(gn, &f2[faddr<2*NVEL, WB>(ns, NVEL + p, i)]);
+    else f2[faddr<2*NVEL, WB>(ns, NVEL + p, i)] = gn;
   });
 }
 
@@ -3459,6 +3471,29 @@ extern "C" int lbmi_k_blocked_sites(const lbmi_kparam_t * kp) {
   return (int) ((kp->nsite/LBW)*LBW);
 }
 
+extern "C" int lbmi_k_relayout_n(const lbmi_kparam_t * kp, int ndist,
+				 const double * src, double * dst,
+				 int to_blocked, void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  int nfull = lbmi_k_blocked_sites(kp);
+  unsigned nblk = (unsigned) ((nfull + BLOCK - 1)/BLOCK);
+  dim3 grid(grid_for(nblk, (unsigned) kp->xcd_group)), block(BLOCK);
+  if (ndist == 1) return lbmi_k_relayout(kp, src, dst, to_blocked, stream);
+  if (ndist != 2) return (int) hipErrorInvalidValue;
+  if (kp->nvel == 19) {
+    if (to_blocked) hipLaunchKernelGGL((k_relayout<38, true>), grid, block, 0, st, *kp, src, dst, nfull, nblk);
+    else hipLaunchKernelGGL((k_relayout<38, false>), grid, block, 0, st, *kp, src, dst, nfull, nblk);
+  }
+  else if (kp->nvel == 27) {
+    if (to_blocked) hipLaunchKernelGGL((k_relayout<54, true>), grid, block, 0, st, *kp, src, dst, nfull, nblk);
+    else hipLaunchKernelGGL((k_relayout<54, false>), grid, block, 0, st, *kp, src, dst, nfull, nblk);
+  }
+  else {
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
 extern "C" int lbmi_k_relayout(const lbmi_kparam_t * kp, const double * src,
 			       double * dst, int to_blocked, void * stream) {
   hipStream_t st = (hipStream_t) stream;
@@ -3859,27 +3894,71 @@ extern "C" int lbmi_k_symm_fe_step(const lbmi_kparam_t * kp, int npt,
 
 extern "C" int lbmi_k_phi_from_g(const lbmi_kparam_t * kp, const double * f2,
 				 double * phi, int pull, int wrapmask,
-				 void * stream) {
+				 int blocked, void * stream) {
   hipStream_t st = (hipStream_t) stream;
   Range1D r = interior_range(*kp);
   dim3 grid(r.grid), block(BLOCK);
+  if (blocked && !pull) return (int) hipErrorInvalidValue;
   if (kp->nvel == 19 && !pull) {
     hipLaunchKernelGGL((k_phi_from_g<19, false>), grid, block, 0, st, *kp, f2, phi,
 		       wrapmask, r.i0, r.i1, r.nblk);
   }
-  else if (kp->nvel == 19) {
+  else if (kp->nvel == 19 && !blocked) {
     hipLaunchKernelGGL((k_phi_from_g<19, true>), grid, block, 0, st, *kp, f2, phi,
+		       wrapmask, r.i0, r.i1, r.nblk);
+  }
+  else if (kp->nvel == 19) {
+    hipLaunchKernelGGL((k_phi_from_g<19, true, true>), grid, block, 0, st, *kp, f2, phi,
 		       wrapmask, r.i0, r.i1, r.nblk);
   }
   else if (kp->nvel == 27 && !pull) {
     hipLaunchKernelGGL((k_phi_from_g<27, false>), grid, block, 0, st, *kp, f2, phi,
 		       wrapmask, r.i0, r.i1, r.nblk);
   }
-  else if (kp->nvel == 27) {
+  else if (kp->nvel == 27 && !blocked) {
     hipLaunchKernelGGL((k_phi_from_g<27, true>), grid, block, 0, st, *kp, f2, phi,
 		       wrapmask, r.i0, r.i1, r.nblk);
   }
+  else if (kp->nvel == 27) {
+    hipLaunchKernelGGL((k_phi_from_g<27, true, true>), grid, block, 0, st, *kp, f2, phi,
+		       wrapmask, r.i0, r.i1, r.nblk);
+  }
   else {
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
+/* the pull variants in the blocked order (no fluctuations there) */
+template <int NVEL, int LAY>
+static int launch_collide_binary_lay(const lbmi_kparam_t & kp, const double * src,
+				     double * f2, const lbmi_hydro_dev_t & h,
+				     Symm q, double rtau2, const double * phi,
+				     const double * grad, const double * delsq,
+				     int wrapmask, hipStream_t st) {
+  constexpr int ALIGNV = ((LAY & 3) == 0) ? LBMI_ALIGN : LBW;
+  const int i0 = kp.nhalo*kp.strx;
+  const int i1 = (kp.nhalo + kp.nlocal[0])*kp.strx;
+  const int i0a = (i0/ALIGNV)*ALIGNV;
+  const unsigned nblk = (unsigned) ((i1 - i0a + BLOCK - 1)/BLOCK);
+  dim3 grid(grid_for(nblk, (unsigned) kp.xcd_group)), block(BLOCK);
+  switch (kp.scheme) {
+  case LBMI_M10:
+    hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_M10, true, false, LAY>), grid, block, 0, st,
+		       kp, src, f2, h, q, rtau2, phi, grad, delsq, wrapmask, i0, i1, nblk);
+    break;
+  case LBMI_BGK:
+    hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_BGK, true, false, LAY>), grid, block, 0, st,
+		       kp, src, f2, h, q, rtau2, phi, grad, delsq, wrapmask, i0, i1, nblk);
+    break;
+  case LBMI_TRT:
+    if constexpr (NVEL == 19) {
+      hipLaunchKernelGGL((k_collide_binary<NVEL, LBMI_TRT, true, false, LAY>), grid, block, 0, st,
+			 kp, src, f2, h, q, rtau2, phi, grad, delsq, wrapmask, i0, i1, nblk);
+      break;
+    }
+    return (int) hipErrorInvalidValue;
+  default:
     return (int) hipErrorInvalidValue;
   }
   return (int) hipGetLastError();
@@ -3945,10 +4024,30 @@ extern "C" int lbmi_k_collide_binary(const lbmi_kparam_t * kp,
 				     double b, double kappa, double rtau2,
 				     const double * phi, const double * grad,
 				     const double * delsq, int wrapmask,
-				     void * stream) {
+				     int lay, void * stream) {
   hipStream_t st = (hipStream_t) stream;
   Symm q = {a, b, kappa};
   /* src == f2: in place; otherwise pull from src (propagation fused in) */
+  if (lay != 0) {
+#if LBMI_BLOCK*LBMI_SPT == 256
+    /* the deferred state in the blocked order: pull, no fluctuations */
+    if (src == f2 || h->noise != nullptr) return (int) hipErrorInvalidValue;
+    const int l = lay + ((kp->nt_store & 1) ? 4 : 0);
+    if (kp->nvel == 19) {
+      if (l == 1) return launch_collide_binary_lay<19, 1>(*kp, src, f2, *h, q, rtau2, phi, grad, delsq, wrapmask, st);
+      if (l == 2) return launch_collide_binary_lay<19, 2>(*kp, src, f2, *h, q, rtau2, phi, grad, delsq, wrapmask, st);
+      if (l == 5) return launch_collide_binary_lay<19, 5>(*kp, src, f2, *h, q, rtau2, phi, grad, delsq, wrapmask, st);
+      if (l == 6) return launch_collide_binary_lay<19, 6>(*kp, src, f2, *h, q, rtau2, phi, grad, delsq, wrapmask, st);
+    }
+    if (kp->nvel == 27) {
+      if (l == 1) return launch_collide_binary_lay<27, 1>(*kp, src, f2, *h, q, rtau2, phi, grad, delsq, wrapmask, st);
+      if (l == 2) return launch_collide_binary_lay<27, 2>(*kp, src, f2, *h, q, rtau2, phi, grad, delsq, wrapmask, st);
+      if (l == 5) return launch_collide_binary_lay<27, 5>(*kp, src, f2, *h, q, rtau2, phi, grad, delsq, wrapmask, st);
+      if (l == 6) return launch_collide_binary_lay<27, 6>(*kp, src, f2, *h, q, rtau2, phi, grad, delsq, wrapmask, st);
+    }
+#endif
+    return (int) hipErrorInvalidValue;
+  }
   if (src == f2) {
     if (kp->nvel == 19) return launch_collide_binary<19, false>(*kp, f2, f2, *h, q, rtau2, phi, grad, delsq, 0, st);
     if (kp->nvel == 27) return launch_collide_binary<27, false>(*kp, f2, f2, *h, q, rtau2, phi, grad, delsq, 0, st);

@@ -351,3 +351,57 @@ def test_collisions_with_strided_gradient_and_hydro_arrays(which):
     assert relmax(interior(u[:, :nsite].reshape((3,) + lb.nall), 1), interior(g["u"], 1)) < 1e-12
     assert np.all(u[:, nsite:] == marker)
     lb.free()
+
+
+@pytest.mark.parametrize("nvel", [19, 27])
+def test_two_distributions_in_the_blocked_order(nvel):
+    """FUSED on one GPU with two distributions: the deferred state is kept in
+    the blocked order [site/256][n*nvel + p][site%256] (lbmi_lb_state says
+    so), phi_lb_to_field reads it there, a flush converts back. Bit for bit
+    what the same handle gives with lbmi_tune blocked 0, observers included."""
+    import ludwig_amd
+    import torch
+    nlocal = (20, 12, 16)
+    a, b, kappa, mob = -0.00625, 0.00625, 0.004, 1.25
+    p = lbo.make_param(nvel, nlocal, 1, "m10", 0.1, 0.2, 1.0, (1e-6, 0, 0))
+    rng = np.random.default_rng(23)
+    f2 = np.zeros((2 * nvel,) + lbo.nall(p))
+    f2[:nvel] = lbo.init_synthetic(p)
+    w = lbo.model(nvel)["wv"]
+    ph0 = 0.3 * rng.standard_normal(nlocal)
+    for q in range(nvel):
+        interior(f2[nvel + q], 1)[...] = w[q] * ph0 * (1 + 0.01 * rng.standard_normal(nlocal))
+    out = []
+    for blocked in (0, 1):
+        lb = ludwig_amd.LB(nvel, nlocal, 1, ndist=2, mode=ludwig_amd.FUSED)
+        lb.relaxation_set("m10", 0.1, 0.2)
+        lb.tune("blocked", blocked)
+        lb.fe_scheme_set(7, 1)
+        hy = ludwig_amd.Hydro(lb.nall, lb.device)
+        phi = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+        grad = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+        delsq = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+        lb.lb_memcpy_h2d(f2)
+        rec, orders = [], []
+        for n in range(6):
+            lb.phi_to_field(phi)
+            rec.append(interior(_host(lb, phi), 1).copy())
+            lb.field_halo_n(phi, 1)
+            lb.field_grad(phi, grad, delsq)
+            lb.lb_collide_binary(hy, a, b, kappa, mob, phi, grad, delsq)
+            orders.append(lb.state()[2])
+            lb.lb_halo()
+            lb.lb_propagation()
+            if n == 3:
+                rec.append(interior(lb.lb_memcpy_d2h(), 1).copy())      # flush: back to SoA
+                assert tuple(lb.state()) == (0, 0, 0)
+        rec.append(interior(lb.lb_memcpy_d2h(), 1).copy())
+        rec.append(interior(_host(lb, hy.u), 1).copy())
+        lb.free()
+        out.append((rec, orders))
+    # SoA throughout / blocked from the second collision on (the first is in
+    # place), and again after the flush
+    assert out[0][1] == [0] * 6
+    assert out[1][1] == [0, 1, 1, 1, 0, 1]
+    for x, y in zip(out[0][0], out[1][0]):
+        assert np.array_equal(x, y)
