@@ -786,7 +786,7 @@ def main():
             # passes): quote the committed measurement of this command
             # (tools/profile_bench.sh + tools/pmc_summary.py), and only while
             # the kernel source it was taken with is the one that runs now
-            pmc = os.path.join(ROOT, "profiles", "r02_default_pmc_hbm_traffic.json")
+            pmc = os.path.join(ROOT, "profiles", "r03_default_pmc_hbm_traffic.json")
             same = (args.nvel == 19 and tuple(args.size) == (256, 256, 256)
                     and lazy and world == 1 and args.mode == "fused"
                     and args.scheme == "m10" and args.fe == "none"
