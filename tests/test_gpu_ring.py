@@ -33,7 +33,7 @@ def _oracle(nvel, ntotal, nsteps, scheme="m10", force=None):
 
 
 def _run_ring(world, nvel, ntotal, nsteps, mode, tune=(), scheme="m10",
-              force=None, lazy=False, observe=None, dim=0):
+              force=None, lazy=False, observe=None, dim=0, mid=None):
     """Each rank in a thread of its own. Returns per rank the interior f, rho,
     u, the local moments, what `observe(lb, hy, rank, step)` returned, and the
     ring size the handle reported."""
@@ -70,6 +70,8 @@ def _run_ring(world, nvel, ntotal, nsteps, mode, tune=(), scheme="m10",
             start.wait()
             for n in range(nsteps):
                 lb.lb_collide(hy)
+                if mid is not None:
+                    mid(lb, hy, rank, n)             # between lb_collide and lb_halo
                 lb.lb_halo()
                 lb.lb_propagation()
                 if observe is not None:
@@ -399,3 +401,47 @@ def test_slabs_along_y_or_z_equal_single_domain(world, nvel, dim, mode):
     assert relmax(_join(out, 1, dim), interior(rho, 1)) < 1e-12
     assert relmax(_join(out, 2, dim), interior(u, 1)) < 1e-12
     assert all(o[5][0] == world and o[5][2] == 2 for o in out)
+
+
+@pytest.mark.parametrize("blocked", [0, 1], ids=["soa", "blocked"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_f_rewritten_between_collide_and_halo_of_a_fused_slab_step(world, blocked):
+    """A fused slab step sends the planes of its NEXT exchange ahead, right
+    after its boundary launch. If the caller then rewrites f behind the
+    library's back between lb_collide and lb_halo -- the reference's
+    lb_le_apply_boundary_conditions does, through lb_memcpy both ways
+    (model_le.c:72-83) -- those planes are stale although nothing is pending
+    (the flush of the copy out has nothing to do and leaves them valid):
+    lbmi_lb_dirty, which the binding calls after every host -> device copy,
+    makes the next step pack and exchange afresh. Here every rank scales its
+    FIRST interior plane -- a plane the lower neighbour pulls from -- after
+    the collision of the fourth step; the single domain does the same."""
+    import ludwig_amd
+    import torch
+    nvel, ntotal, nsteps = 19, (12, 14, 14), 7
+    nl = ntotal[0] // world
+
+    def mid(lb, hy, rank, n):
+        if n == 3:
+            lb.lb_flush()                    # what lb_memcpy (D2H) does first
+            lb.synchronize()
+            lb.f[:, 1, :, :] *= 1.0 + 1e-3
+            torch.cuda.synchronize()
+            lb.lb_dirty()
+
+    # (SoA: the flush has nothing to do and the send buffers stay "valid";
+    # blocked: the flush converts the order, which invalidates them by itself)
+    out = _run_ring(world, nvel, ntotal, nsteps, ludwig_amd.FUSED, mid=mid,
+                    tune=(("blocked", blocked),))
+    p = lbo.make_param(nvel, ntotal, 1, "m10", 0.1, 0.3, 1.0, FBODY)
+    f = lbo.init_synthetic(p)
+    fp = np.zeros_like(f)
+    for n in range(nsteps):
+        lbo.collide(p, f)
+        if n == 3:
+            for r in range(world):
+                f[:, 1 + r * nl, :, :] *= 1.0 + 1e-3
+        lbo.halo(p, f)
+        lbo.propagate(p, f, fp)
+        f, fp = fp, f
+    assert relmax(_join(out, 0), interior(f, 1)) < 1e-12
