@@ -640,6 +640,13 @@ int lbmi_lb_records_unpack(lbmi_t * lb, const double * records);
  * lbmi_lb_io_read replaces the state (nothing stays pending). */
 int lbmi_lb_io_write(lbmi_t * lb, const char * dir, int timestep,
 		     int ntotal_x, int offset_x);
+/* The record format of lbmi_lb_io_write / lbmi_lb_io_read: 0 (the default)
+ * binary records of ndist*nvel doubles; 1 text records, the input key
+ * distribution_io_format ascii (lb_write_buf_ascii / lb_read_buf_ascii,
+ * model.c:1438-1490): per site nvel lines, line p = the ndist values f(n, p)
+ * as " %22.15e", and metadata that says MPI_CHAR x nvel*(ndist*23 + 1). The
+ * records are still packed on the device; the text is made on the host. */
+int lbmi_io_format_set(lbmi_t * lb, int ascii);
 int lbmi_lb_io_read(lbmi_t * lb, const char * dir, int timestep,
 		    int ntotal_x, int offset_x);
 
@@ -648,6 +655,10 @@ int lbmi_lb_io_read(lbmi_t * lb, const char * dir, int timestep,
  * name of a time step (io_subfile_name, io_subfile.c). */
 int lbmi_io_metadata_write(const char * dir, const char * stub, int nel,
 			   const int ntotal[3]);
+/* the same for records of ndist*nvel values in either format (ascii != 0:
+ * text records) */
+int lbmi_io_metadata_write_fmt(const char * dir, const char * stub, int nvel,
+			       int ndist, const int ntotal[3], int ascii);
 int lbmi_io_filename(const char * dir, const char * stub, int timestep,
 		     char * buf, size_t bufsz);
 

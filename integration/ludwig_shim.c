@@ -1046,7 +1046,9 @@ int lb_memcpy(lb_t * lb, tdpMemcpyKind flag) {
  *  and binary records, an X slab is one contiguous byte range of that file:
  *  the records are packed on the device and written from there, the files
  *  are the same byte for byte. Anything else (old-style i/o, several files,
- *  ASCII records) goes to the original.
+ *  the legacy io_info_t path) goes to the original. Text records
+ *  (distribution_io_format ascii) are the library's as well: packed on the
+ *  device, formatted on the host as lb_write_buf_ascii formats them.
  *
  *****************************************************************************/
 
@@ -1056,7 +1058,8 @@ static int shim_io_supported(lb_t * lb, const io_metadata_t * meta) {
   /* (a slab along Y or Z is not one byte range of the file) */
   if (!shim_slab_dim(lb, &dim) || dim != X) return 0;
   if (meta->options.mode != IO_MODE_MPIIO) return 0;
-  if (meta->options.iorformat != IO_RECORD_BINARY) return 0;
+  if (meta->options.iorformat != IO_RECORD_BINARY &&
+      meta->options.iorformat != IO_RECORD_ASCII) return 0;
   if (meta->options.iogrid[X] != 1 || meta->options.iogrid[Y] != 1 ||
       meta->options.iogrid[Z] != 1) return 0;
   return 1;
@@ -1079,6 +1082,9 @@ int lb_io_write(lb_t * lb, int timestep, io_event_t * event) {
     io_event_record(event, IO_EVENT_WRITE);
     /* the metadata file (rank at offset 0) and this rank's byte range */
     shim_note(S_LB_IO_WRITE, 1);
+    /* binary records, or distribution_io_format ascii (model.c:1438-1462) */
+    SHIM_CHECK(lb, lbmi_io_format_set(shim_handle(lb),
+				      lb->output.options.iorformat == IO_RECORD_ASCII));
     SHIM_CHECK(lb, lbmi_lb_io_write(shim_handle(lb), ".", timestep, ntotal[X],
 				    noffset[X]));
     shim_sync_pointers(lb, shim_.h);                /* a flush may have swapped */
@@ -1108,6 +1114,8 @@ int lb_io_read(lb_t * lb, int timestep, io_event_t * event) {
     cs_ntotal(lb->cs, ntotal);
     cs_nlocal_offset(lb->cs, noffset);
     shim_note(S_LB_IO_READ, 1);
+    SHIM_CHECK(lb, lbmi_io_format_set(shim_handle(lb),
+				      lb->input.options.iorformat == IO_RECORD_ASCII));
     SHIM_CHECK(lb, lbmi_lb_io_read(shim_handle(lb), ".", timestep, ntotal[X],
 				   noffset[X]));
     shim_sync_pointers(lb, shim_.h);

@@ -104,6 +104,7 @@ struct lbmi_s {
   /* free-energy sector: gradient stencil (7 | 27), advection order (1..4) */
   int grad_npt;
   int adv_order;
+  int io_ascii;                      /* distribution files: text records */
   double * fe_force;                 /* lbmi_symmetric_lb_step off the fused
 					route: the thermodynamic force */
 
@@ -3508,12 +3509,29 @@ int lbmi_io_filename(const char * dir, const char * stub, int timestep,
   return 0;
 }
 
+/* Text records (io_options_t::iorformat == IO_RECORD_ASCII, the input key
+ * distribution_io_format ascii): lb_write_buf_ascii (model.c:1438-1462) puts
+ * the record of a site on nvel lines, line p holding the ndist values
+ * f(n, p) as " %22.15e" (23 characters each) and a newline */
+
+enum {LBMI_ASCII_DATUM = 23};
+
+static size_t lbmi_ascii_record(int nvel, int ndist) {
+  return (size_t) nvel*((size_t) ndist*LBMI_ASCII_DATUM + 1);
+}
+
 int lbmi_io_metadata_write(const char * dir, const char * stub, int nel,
 			   const int ntotal[3]) {
+  return lbmi_io_metadata_write_fmt(dir, stub, nel, 1, ntotal, 0);
+}
+
+int lbmi_io_metadata_write_fmt(const char * dir, const char * stub, int nvel,
+			       int ndist, const int ntotal[3], int ascii) {
+  const int nel = nvel*ndist;
   char fn[1024];
   FILE * fp = NULL;
   int n;
-  if (dir == NULL || stub == NULL || ntotal == NULL || nel < 1) {
+  if (dir == NULL || stub == NULL || ntotal == NULL || nvel < 1 || ndist < 1) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_io_metadata_write: bad argument");
   }
   n = snprintf(fn, sizeof(fn), "%s/%s-metadata.%3.3d-%3.3d", dir, stub, 1, 1);
@@ -3536,7 +3554,7 @@ int lbmi_io_metadata_write(const char * dir, const char * stub, int nel,
   fprintf(fp, "\t},\n");
   fprintf(fp, "\t\"io_options\":\t{\n");
   fprintf(fp, "\t\t\"Mode\":\t\"mpiio\",\n");
-  fprintf(fp, "\t\t\"Record format\":\t\"binary\",\n");
+  fprintf(fp, "\t\t\"Record format\":\t\"%s\",\n", ascii ? "ascii" : "binary");
   fprintf(fp, "\t\t\"Metadata version\":\t3,\n");
   fprintf(fp, "\t\t\"Report\":\ttrue,\n");
   fprintf(fp, "\t\t\"Asynchronous\":\tfalse,\n");
@@ -3544,9 +3562,18 @@ int lbmi_io_metadata_write(const char * dir, const char * stub, int nel,
   fprintf(fp, "\t\t\"I/O grid\":\t[1, 1, 1]\n");
   fprintf(fp, "\t},\n");
   fprintf(fp, "\t\"io_element\":\t{\n");
-  fprintf(fp, "\t\t\"MPI_Datatype\":\t\"MPI_DOUBLE\",\n");
-  fprintf(fp, "\t\t\"Size (bytes)\":\t8,\n");
-  fprintf(fp, "\t\t\"Count\":\t%d,\n", nel);
+  if (ascii) {
+    /* lb_data_create: the element of a text record is its characters
+     * (model.c:118-129: MPI_CHAR, nvel*(ndist*23 + 1) of them) */
+    fprintf(fp, "\t\t\"MPI_Datatype\":\t\"MPI_CHAR\",\n");
+    fprintf(fp, "\t\t\"Size (bytes)\":\t1,\n");
+    fprintf(fp, "\t\t\"Count\":\t%d,\n", (int) lbmi_ascii_record(nvel, ndist));
+  }
+  else {
+    fprintf(fp, "\t\t\"MPI_Datatype\":\t\"MPI_DOUBLE\",\n");
+    fprintf(fp, "\t\t\"Size (bytes)\":\t8,\n");
+    fprintf(fp, "\t\t\"Count\":\t%d,\n", nel);
+  }
   fprintf(fp, "\t\t\"Endianness\":\t\"LITTLE_ENDIAN\"\n");
   fprintf(fp, "\t},\n");
   fprintf(fp, "\t\"io_subfile\":\t{\n");
@@ -3567,9 +3594,60 @@ int lbmi_io_metadata_write(const char * dir, const char * stub, int nel,
 
 #define LBMI_IO_CHUNK ((size_t) 32*1024*1024)
 
+/* binary records (ndist*nvel doubles per site, [n][p]) <-> text records */
+
+static void lbmi_ascii_from_records(const double * rec, size_t nsites, int nvel,
+				    int ndist, char * text) {
+  const size_t len = lbmi_ascii_record(nvel, ndist);
+  for (size_t k = 0; k < nsites; k++) {
+    const double * r = rec + k*(size_t) (nvel*ndist);
+    char * t = text + k*len;
+    for (int p = 0; p < nvel; p++) {
+      char * line = t + (size_t) p*((size_t) ndist*LBMI_ASCII_DATUM + 1);
+      for (int n = 0; n < ndist; n++) {
+	char tmp[64];
+	/* (a value that does not fit the width is cut, as snprintf(tmp,
+	 * nbyte + 1, ...) cuts it there) */
+	snprintf(tmp, LBMI_ASCII_DATUM + 1, " %22.15e", r[n*nvel + p]);
+	memcpy(line + n*LBMI_ASCII_DATUM, tmp, LBMI_ASCII_DATUM);
+      }
+      line[ndist*LBMI_ASCII_DATUM] = '\n';
+    }
+  }
+}
+
+static int lbmi_records_from_ascii(const char * text, size_t nsites, int nvel,
+				   int ndist, double * rec) {
+  const size_t len = lbmi_ascii_record(nvel, ndist);
+  for (size_t k = 0; k < nsites; k++) {
+    double * r = rec + k*(size_t) (nvel*ndist);
+    const char * t = text + k*len;
+    for (int p = 0; p < nvel; p++) {
+      const char * line = t + (size_t) p*((size_t) ndist*LBMI_ASCII_DATUM + 1);
+      for (int n = 0; n < ndist; n++) {
+	char tmp[LBMI_ASCII_DATUM + 1];
+	char * end = NULL;
+	memcpy(tmp, line + n*LBMI_ASCII_DATUM, LBMI_ASCII_DATUM);
+	tmp[LBMI_ASCII_DATUM] = '\0';
+	r[n*nvel + p] = strtod(tmp, &end);             /* sscanf "%le" there */
+	if (end == tmp) return -1;
+      }
+    }
+  }
+  return 0;
+}
+
+/* nbytes, offset: of the BINARY record stream; with text records the file
+ * holds lbmi_ascii_record() characters where that stream has nel*8 bytes */
+
 static int lbmi_io_transfer(lbmi_t * lb, const char * fn, int writing,
 			    double * dev, size_t nbytes, off_t offset) {
   void * stage = NULL;
+  char * text = NULL;
+  const int ascii = lb->io_ascii;
+  const size_t recb = sizeof(double)*(size_t) lb->kp.nvel*(size_t) lb->opts.ndist;
+  const size_t rect = lbmi_ascii_record(lb->kp.nvel, lb->opts.ndist);
+  const size_t chunk = (LBMI_IO_CHUNK/recb)*recb;       /* whole records */
   size_t done = 0;
   int fd = -1;
   int ifail = 0;
@@ -3580,10 +3658,26 @@ static int lbmi_io_transfer(lbmi_t * lb, const char * fn, int writing,
     close(fd);
     return lbmi_fail(LBMI_ERR_HIP, "hipHostMalloc of the i/o staging buffer");
   }
+  if (ascii) {
+    text = (char *) malloc((chunk/recb)*rect);
+    if (text == NULL) {
+      hipHostFree(stage);
+      close(fd);
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "malloc of the text buffer");
+    }
+  }
   while (done < nbytes && ifail == 0) {
     size_t n = nbytes - done;
     size_t io = 0;
-    if (n > LBMI_IO_CHUNK) n = LBMI_IO_CHUNK;
+    /* what goes to / comes from the file for this chunk, and where */
+    char * fbuf = (char *) stage;
+    size_t fn_bytes;
+    off_t foff;
+    if (n > chunk) n = chunk;
+    fn_bytes = ascii ? (n/recb)*rect : n;
+    foff = ascii ? (off_t) ((((size_t) offset + done)/recb)*rect)
+      : offset + (off_t) done;
+    if (ascii) fbuf = text;
     if (writing) {
       if (hipMemcpyAsync(stage, (char *) dev + done, n, hipMemcpyDeviceToHost,
 			 lb->stream) != hipSuccess ||
@@ -3591,11 +3685,15 @@ static int lbmi_io_transfer(lbmi_t * lb, const char * fn, int writing,
 	ifail = lbmi_fail(LBMI_ERR_HIP, "device to host copy of records");
 	break;
       }
+      if (ascii) {
+	lbmi_ascii_from_records((const double *) stage, n/recb, lb->kp.nvel,
+				lb->opts.ndist, text);
+      }
     }
-    while (io < n) {
+    while (io < fn_bytes) {
       ssize_t r = writing
-	? pwrite(fd, (char *) stage + io, n - io, offset + (off_t) (done + io))
-	: pread(fd, (char *) stage + io, n - io, offset + (off_t) (done + io));
+	? pwrite(fd, fbuf + io, fn_bytes - io, foff + (off_t) io)
+	: pread(fd, fbuf + io, fn_bytes - io, foff + (off_t) io);
       if (r <= 0) {
 	ifail = lbmi_fail(LBMI_ERR_ARGUMENT, "%s: %s", fn,
 			  (r == 0) ? "file too short" : strerror(errno));
@@ -3605,6 +3703,11 @@ static int lbmi_io_transfer(lbmi_t * lb, const char * fn, int writing,
     }
     if (ifail) break;
     if (!writing) {
+      if (ascii && lbmi_records_from_ascii(text, n/recb, lb->kp.nvel,
+					   lb->opts.ndist, (double *) stage) != 0) {
+	ifail = lbmi_fail(LBMI_ERR_ARGUMENT, "%s: not a number in a text record", fn);
+	break;
+      }
       if (hipMemcpyAsync((char *) dev + done, stage, n, hipMemcpyHostToDevice,
 			 lb->stream) != hipSuccess ||
 	  hipStreamSynchronize(lb->stream) != hipSuccess) {
@@ -3615,6 +3718,7 @@ static int lbmi_io_transfer(lbmi_t * lb, const char * fn, int writing,
     done += n;
   }
   hipHostFree(stage);
+  free(text);
   if (close(fd) != 0 && ifail == 0) {
     ifail = lbmi_fail(LBMI_ERR_ARGUMENT, "%s: %s", fn, strerror(errno));
   }
@@ -3637,6 +3741,12 @@ static int lbmi_io_args(lbmi_t * lb, const char * dir, int ntotal_x,
   return 0;
 }
 
+int lbmi_io_format_set(lbmi_t * lb, int ascii) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  lb->io_ascii = (ascii != 0);
+  return 0;
+}
+
 int lbmi_lb_io_write(lbmi_t * lb, const char * dir, int timestep,
 		     int ntotal_x, int offset_x) {
   char fn[1024];
@@ -3648,7 +3758,8 @@ int lbmi_lb_io_write(lbmi_t * lb, const char * dir, int timestep,
   if (ifail) return ifail;
   if (offset_x == 0) {
     int ntotal[3] = {ntotal_x, lb->kp.nlocal[Y], lb->kp.nlocal[Z]};
-    ifail = lbmi_io_metadata_write(dir, "dist", lb->kp.nvel*lb->opts.ndist, ntotal);
+    ifail = lbmi_io_metadata_write_fmt(dir, "dist", lb->kp.nvel, lb->opts.ndist,
+				       ntotal, lb->io_ascii);
     if (ifail) return ifail;
   }
   ifail = lbmi_io_filename(dir, "dist", timestep, fn, sizeof(fn));

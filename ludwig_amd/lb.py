@@ -581,6 +581,11 @@ class LB:
         _l.check(self._lib.lbmi_lb_collide_fe(self._h, ctypes.byref(h),
                                               ctypes.byref(fe)))
 
+    def io_format_set(self, ascii=False):
+        """lbmi_io_format_set: binary (default) or text records
+        (distribution_io_format ascii) for lb_io_write / lb_io_read."""
+        _l.check(self._lib.lbmi_io_format_set(self._h, 1 if ascii else 0))
+
     def lb_io_write(self, directory, timestep, ntotal_x=None, offset_x=0):
         """lb_io_write (model.c:1568): dist-metadata.001-001 and
         dist-<timestep>.001-001 in `directory` (MPI-IO mode, one file)."""

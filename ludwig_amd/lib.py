@@ -152,6 +152,9 @@ SYMBOLS = [
     ("lbmi_lb_records_pack", _i, [_vp, _vp]),
     ("lbmi_lb_records_unpack", _i, [_vp, _vp]),
     ("lbmi_lb_io_write", _i, [_vp, ctypes.c_char_p, _i, _i, _i]),
+    ("lbmi_io_format_set", _i, [_vp, _i]),
+    ("lbmi_io_metadata_write_fmt", _i, [ctypes.c_char_p, ctypes.c_char_p, _i, _i,
+                                        ctypes.POINTER(_i), _i]),
     ("lbmi_lb_io_read", _i, [_vp, ctypes.c_char_p, _i, _i, _i]),
     ("lbmi_io_metadata_write", _i, [ctypes.c_char_p, ctypes.c_char_p, _i,
                                     ctypes.POINTER(_i)]),

@@ -286,6 +286,8 @@ IO_CASES = [
     ("io_q19", 19, (6, 5, 4), 7),
     ("io_q27", 27, (5, 4, 6), 123456),
     ("io_q19_2dist", 19, (4, 6, 5), 40, 2),         # ndist = 2: records of 38 doubles
+    ("io_q19_ascii", 19, (6, 4, 3), 12, 1, "ascii"),         # distribution_io_format ascii
+    ("io_q19_2dist_ascii", 19, (3, 4, 5), 3, 2, "ascii"),    # two values per line
 ]
 
 
@@ -298,8 +300,10 @@ def run_io_case(case, tmp, exe=None, env=None):
         exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
     d = os.path.join(tmp, name)
     os.makedirs(d)
+    ascii_ = (len(case) > 5 and case[5] == "ascii")
     subprocess.run([exe, "io", d, *map(str, n), str(timestep)]
-                   + ([str(ndist)] if ndist != 1 else []), check=True,
+                   + ([str(ndist)] if (ndist != 1 or ascii_) else [])
+                   + (["ascii"] if ascii_ else []), check=True,
                    stdout=subprocess.DEVNULL, env=env)
     datafile = "dist-%9.9d.001-001" % timestep
     nall = tuple(m + 2 for m in n)

@@ -777,7 +777,7 @@ static int run_wall(int argc, char ** argv) {
  *
  *  run_io
  *
- *  "io" mode: ref_driver io <dir> nx ny nz timestep
+ *  "io" mode: ref_driver io <dir> nx ny nz timestep [ndist [ascii]]
  *    lb_io_write (model.c:1568-1614, MPI-IO mode) of the synthetic state in
  *    <dir>: the metadata file dist.json and the data file; also <dir>/f0.f64.
  *  "ioread" mode: ref_driver ioread <dir> nx ny nz timestep
@@ -816,9 +816,14 @@ static int run_io(int argc, char ** argv) {
     lb_data_options_t opts = lb_data_options_default();
     opts.ndim = NDIM;
     opts.nvel = NVEL;
-    opts.ndist = (argc == 8) ? atoi(argv[7]) : 1;
+    opts.ndist = (argc >= 8) ? atoi(argv[7]) : 1;
     opts.iodata.input = io_options_with_mode(IO_MODE_MPIIO);
     opts.iodata.output = io_options_with_mode(IO_MODE_MPIIO);
+    if (argc == 9 && strcmp(argv[8], "ascii") == 0) {
+      /* distribution_io_format ascii (io_options_rt.c): text records */
+      opts.iodata.input.iorformat = IO_RECORD_ASCII;
+      opts.iodata.output.iorformat = IO_RECORD_ASCII;
+    }
     lb_data_create(pe, cs, &opts, &lb);
   }
   {
@@ -882,7 +887,7 @@ int main(int argc, char ** argv) {
 		     strcmp(argv[1], "relax") == 0)) {
     return run_binary(argc, argv);
   }
-  if ((argc == 7 || argc == 8) && (strcmp(argv[1], "io") == 0 ||
+  if ((argc >= 7 && argc <= 9) && (strcmp(argv[1], "io") == 0 ||
 				   strcmp(argv[1], "ioread") == 0)) {
     return run_io(argc, argv);
   }

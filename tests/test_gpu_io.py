@@ -183,3 +183,50 @@ def test_large_file_chunks(tmp_path):
     lb.synchronize()
     assert torch.equal(lb.f[:, 1:-1, 1:-1, 1:-1], ref)
     lb.free()
+
+
+@pytest.mark.parametrize("name,ndist", [("io_q19_ascii", 1), ("io_q19_2dist_ascii", 2)])
+def test_text_records_identical_to_reference_files(name, ndist, tmp_path):
+    """distribution_io_format ascii (lb_write_buf_ascii / lb_read_buf_ascii,
+    model.c:1438-1490): per site nvel lines of ndist values " %22.15e". The
+    records are packed on the device, the text is made on the host; the data
+    file and the metadata (MPI_CHAR x nvel*(ndist*23 + 1)) are the compiled
+    reference's byte for byte, and reading them back gives the state to the
+    sixteen digits the text holds. Slabs write their own character ranges of
+    the one file."""
+    import ludwig_amd
+    g = load_io_golden(name)
+    n = _nlocal(g)
+    lb = ludwig_amd.LB(19, n, 1, ndist=ndist, mode=ludwig_amd.FUSED)
+    lb.io_format_set(True)
+    lb.lb_memcpy_h2d(g["f0"])
+    lb.lb_io_write(tmp_path, g["timestep"])
+    lb.synchronize()
+    assert open(tmp_path / "dist-metadata.001-001").read() == g["metadata"]
+    assert open(tmp_path / g["datafile"], "rb").read() == g["data"]
+    lb.free()
+    # the reference's file read back
+    rd = tmp_path / "rd"
+    rd.mkdir()
+    with open(rd / g["datafile"], "wb") as fp:
+        fp.write(g["data"])
+    lb = ludwig_amd.LB(19, n, 1, ndist=ndist)
+    lb.io_format_set(True)
+    lb.lb_io_read(rd, g["timestep"])
+    back = interior(lb.lb_memcpy_d2h(), 1)
+    ref = interior(g["f0"], 1)
+    assert np.max(np.abs(back - ref)) <= 1e-15 * np.max(np.abs(ref))
+    lb.free()
+    # two slabs, each its own range of the one file
+    if ndist == 1 and n[0] % 2 == 0:
+        sl = tmp_path / "slabs"
+        sl.mkdir()
+        half = n[0] // 2
+        for r in (1, 0):
+            lb = ludwig_amd.LB(19, (half, n[1], n[2]), 1)
+            lb.io_format_set(True)
+            lb.lb_memcpy_h2d(np.ascontiguousarray(g["f0"][:, r * half:r * half + half + 2]))
+            lb.lb_io_write(sl, g["timestep"], ntotal_x=n[0], offset_x=r * half)
+            lb.synchronize()
+            lb.free()
+        assert open(sl / g["datafile"], "rb").read() == g["data"]
