@@ -657,6 +657,16 @@ def io_metadata_write(directory, stub, nel, ntotal):
                                                  stub.encode(), int(nel), n))
 
 
+def io_metadata_write_fmt(directory, stub, nvel, ndist, ntotal, ascii=False):
+    """lbmi_io_metadata_write_fmt: the metadata of records of ndist*nvel values
+    in binary or text (distribution_io_format ascii) form. Host only."""
+    lib = _l.library()
+    nt = (ctypes.c_int * 3)(*[int(v) for v in ntotal])
+    _l.check(lib.lbmi_io_metadata_write_fmt(str(directory).encode(), stub.encode(),
+                                            int(nvel), int(ndist), nt,
+                                            1 if ascii else 0))
+
+
 def io_filename(directory, stub, timestep):
     """io_subfile_name: <stub>-%9.9d.001-001. Host only."""
     buf = ctypes.create_string_buffer(1024)

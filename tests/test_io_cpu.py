@@ -78,3 +78,24 @@ def test_reference_reads_our_files(name, nvel, tmp_path):
                    stdout=subprocess.DEVNULL)
     back = np.fromfile(tmp_path / "readback.f.f64", dtype="<f8").reshape(f.shape)
     assert np.array_equal(interior(back, 1), interior(f, 1))
+
+
+@pytest.mark.parametrize("name,ndist", [("io_q19_ascii", 1), ("io_q19_2dist_ascii", 2)])
+def test_text_record_metadata_and_oracle_text(name, ndist, tmp_path):
+    """distribution_io_format ascii: the metadata (MPI_CHAR x nvel*(ndist*23 +
+    1)) byte for byte, and the text of the data file re-made here from the f
+    it was written from: per site nvel lines, line p = f(n, p) for the ndist
+    distributions as " %22.15e" (lb_write_buf_ascii, model.c:1438-1462)."""
+    import ludwig_amd
+    g = load_io_golden(name)
+    n = _nlocal(g)
+    ludwig_amd.io_metadata_write_fmt(tmp_path, "dist", 19, ndist, n, ascii=True)
+    assert open(tmp_path / "dist-metadata.001-001").read() == g["metadata"]
+    f = interior(g["f0"], 1).reshape((ndist, 19) + n)
+    lines = []
+    for ic in range(n[0]):
+        for jc in range(n[1]):
+            for kc in range(n[2]):
+                for p in range(19):
+                    lines.append("".join(" %22.15e" % f[d, p, ic, jc, kc] for d in range(ndist)))
+    assert ("\n".join(lines) + "\n").encode() == g["data"]
