@@ -298,3 +298,63 @@ def test_fluctuations_256(mode):
         ref[k][1:-1, 1:-1, 1:-1] = inner[k]
         assert np.array_equal(s1[k], ref[k])           # halo sites never draw
     lb.free()
+
+
+@pytest.mark.parametrize("n", [128, 256])
+def test_one_kernel_binary_fluid_step_full_size(n):
+    """BASELINE config 4 at its own size (128^3, nhalo 2) and at 256^3 through
+    lbmi_symmetric_lb_step (one kernel per step): the order parameter and the
+    mass are conserved (the Cahn-Hilliard update is a difference of face
+    fluxes, the collision conserves rho), the momentum changes by the
+    thermodynamic force only -- whose sum over a periodic box vanishes -- and
+    the result equals the separate passes (free-energy pass, then the LB
+    kernel reading the force array) to rounding."""
+    import torch
+    import ludwig_amd
+    from ludwig_amd import synthetic
+    a, b, kappa, mob = -0.00625, 0.00625, 0.004, 1.25
+    nsteps = 6
+    h = 2
+    m = ludwig_amd.lb.model(NVEL)
+    out = []
+    for route in ("one_kernel", "separate"):
+        lb = ludwig_amd.LB(NVEL, (n, n, n), h, mode=ludwig_amd.FUSED)
+        lb.relaxation_set("m10", 0.1, 0.3)
+        lb.fe_scheme_set(7, 1)
+        synthetic.fill_device(lb, m["cv"], m["wv"], (n, n, n))
+        hy = ludwig_amd.Hydro(lb.nall, lb.device)
+        hy.force = torch.zeros((3,) + lb.nall, dtype=torch.float64, device=lb.device)
+        g = torch.Generator(device=lb.device)
+        g.manual_seed(99)
+        pa = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+        pa[h:-h, h:-h, h:-h] = 0.05 * (torch.rand((n, n, n), dtype=torch.float64,
+                                                  device=lb.device, generator=g) - 0.5)
+        pb = torch.zeros_like(pa)
+        ua, ub = hy.u, torch.zeros_like(hy.u)
+        torch.cuda.synchronize()
+        lb.hydro_field_set(hy.force, (0.0, 0.0, 0.0))
+        phi0 = float(pa.sum())
+        mom0 = lb.moments()
+        for k in range(nsteps):
+            if route == "one_kernel":
+                hy.u = ub if k % 2 == 0 else ua
+                lb.symmetric_lb_step(hy, ua if k % 2 == 0 else ub, a, b, kappa, mob, pa, pb)
+            else:
+                lb.symmetric_step_periodic(a, b, kappa, mob, pa, hy.u, hy.force, pb,
+                                           accumulate=False)
+                lb.step(hy)
+            pa, pb = pb, pa
+        lb.synchronize()
+        torch.cuda.synchronize()
+        mom1 = lb.moments()
+        phi1 = float(pa[h:-h, h:-h, h:-h].sum())
+        scale = float(pa.abs().sum())
+        assert abs(phi1 - phi0) < 1e-12 * scale
+        assert abs(mom1[1] - mom0[1]) < 1e-12 * mom0[1]
+        lb.lb_flush()
+        lb.synchronize()
+        out.append((pa[h:-h, h:-h, h:-h].clone(), lb.f[:, h:-h, h:-h, h:-h].clone(),
+                    hy.u[:, h:-h, h:-h, h:-h].clone()))
+        lb.free()
+    for x, y in zip(out[0], out[1]):
+        assert float((x - y).abs().max()) <= 1e-13 * float(y.abs().max())
