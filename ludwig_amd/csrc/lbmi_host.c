@@ -400,6 +400,7 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   lb->x_concurrent = 1;
   lb->use_blocked = 1;               /* profiles/r01_blocked_order.txt */
   lb->kp.fe_tiled = 1;
+  lb->kp.fe_stripes = 0;             /* profiles/r03_rejected.txt, 6 */
   lb->nt_store_mode = -1;            /* idem: nontemporal stores when f, fprime
 					exceed the Infinity Cache */
   lb->grad_npt = 7;
@@ -821,6 +822,10 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
     }
     if (lb->hydro_lazy != (value != 0)) lbmi_run_graph_release(lb);
     lb->hydro_lazy = (value != 0);
+    return 0;
+  }
+  if (strcmp(key, "fe_stripes") == 0) {
+    lb->kp.fe_stripes = (value != 0);
     return 0;
   }
   if (strcmp(key, "fe_tiled") == 0) {

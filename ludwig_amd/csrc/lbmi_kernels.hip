@@ -2318,16 +2318,35 @@ void k_symm_lb_step(lbmi_kparam_t kp, const double * __restrict__ f,
 		    const double * __restrict__ phi,
 		    const double * __restrict__ uprev,
 		    double * __restrict__ phi_out, int i0, int i1,
-		    unsigned nblk) {
+		    unsigned nblk, int gstripe) {
 
   static_assert(SPT == 1, "one site per thread");
-  unsigned lb;
-  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
-
   constexpr int ORD = LAY & 3;
-  constexpr int ALIGNV = (ORD == 0) ? LBMI_ALIGN : LBW;
-  const int i = (i0/ALIGNV)*ALIGNV + (int) (lb*BLOCK + threadIdx.x);
-  if (i < i0 || i >= i1) return;
+  int i;
+  if (gstripe > 0) {
+    /* Stripes: the hardware hands block b to XCD b mod 8; here XCD k works on
+     * the k-th eighth of EVERY x plane (gstripe blocks of it), plane after
+     * plane. The 25 values of phi and the velocities a site needs from the
+     * planes x - 2 .. x + 2 are then behind the L2 that has just had them, or
+     * is about to: with blocks dealt out in runs of the 1-d site order every
+     * XCD fetches its own copy of five planes per run (the counters showed
+     * 1.29 x the algorithmic reads). The last stripe of a plane is short:
+     * blocks past its end have nothing to do. (Measured: 3 - 6 % SLOWER --
+     * the distribution streams want all XCDs in one neighbourhood of the 1-d
+     * order more than phi wants one L2: lbmi_tune "fe_stripes", default 0.) */
+    const int xcd = (int) (blockIdx.x & 7u), j = (int) (blockIdx.x >> 3);
+    const int m = j/gstripe, w = j - m*gstripe;
+    const int plane0 = i0 + m*kp.strx;
+    i = plane0 + (xcd*gstripe + w)*BLOCK + (int) threadIdx.x;
+    if (plane0 >= i1 || i >= plane0 + kp.strx) return;
+  }
+  else {
+    unsigned lb;
+    if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+    constexpr int ALIGNV = (ORD == 0) ? LBMI_ALIGN : LBW;
+    i = (i0/ALIGNV)*ALIGNV + (int) (lb*BLOCK + threadIdx.x);
+    if (i < i0 || i >= i1) return;
+  }
 
   const lbmi_xbuf_t none = {nullptr, nullptr, nullptr, nullptr};
   const size_t ns = (size_t) kp.nsite;
@@ -3828,7 +3847,11 @@ static int launch_symm_lb(const lbmi_kparam_t & kp, const double * f,
   const int i1 = (kp.nhalo + kp.nlocal[0])*kp.strx;
   const int i0a = (i0/ALIGNV)*ALIGNV;
   const unsigned nblk = (unsigned) ((i1 - i0a + BLOCK - 1)/BLOCK);
-  dim3 grid(grid_for(nblk, (unsigned) kp.xcd_group)), block(BLOCK);
+  /* stripes (kp.fe_stripes; measured slower, off by default): every XCD an
+   * eighth of every plane */
+  const int gstripe = kp.fe_stripes ? (kp.strx + 8*BLOCK - 1)/(8*BLOCK) : 0;
+  dim3 grid(gstripe ? (unsigned) (kp.nlocal[0]*gstripe*8)
+	    : grid_for(nblk, (unsigned) kp.xcd_group)), block(BLOCK);
   /* no occupancy cap here (launch_pc_hio has one): with the free-energy
    * arithmetic in front of the collision the kernel is bound by latency and
    * issue as much as by HBM, and every resident wave helps
@@ -3838,12 +3861,12 @@ static int launch_symm_lb(const lbmi_kparam_t & kp, const double * f,
   case LBMI_M10:
     hipLaunchKernelGGL((k_symm_lb_step<NVEL, LBMI_M10, LAY>), grid, block, lds,
 		       st, kp, f, fp, h, q, mobility, order, phi, uprev,
-		       phi_out, i0, i1, nblk);
+		       phi_out, i0, i1, nblk, gstripe);
     break;
   case LBMI_BGK:
     hipLaunchKernelGGL((k_symm_lb_step<NVEL, LBMI_BGK, LAY>), grid, block, lds,
 		       st, kp, f, fp, h, q, mobility, order, phi, uprev,
-		       phi_out, i0, i1, nblk);
+		       phi_out, i0, i1, nblk, gstripe);
     break;
   default:
     return (int) hipErrorInvalidValue;
