@@ -769,6 +769,9 @@ def main():
                 "launches_sampled": "every %d-th of %d" % (args.timing_period,
                                                           args.steps),
             }
+            if args.mode == "fused_halo" and world == 1 and not args.selfring \
+                    and args.noise == 0.0 and "halo_fold=0" not in args.tune:
+                roofline["kernel"] = "k_propagate_collide_halo"
             if fe is not None and args.fe_route == "step":
                 # the one kernel of the binary-fluid step: beside the
                 # distributions rho, u stored (32 B), u of the previous step

@@ -56,7 +56,7 @@ extern "C" {
 #include <stdint.h>
 
 #define LBMI_VERSION_MAJOR 0
-#define LBMI_VERSION_MINOR 1
+#define LBMI_VERSION_MINOR 3
 
 typedef struct lbmi_s lbmi_t;           /* opaque handle ~ lb_t + halo_swap_t */
 typedef struct lbmi_ring_s lbmi_ring_t; /* the peer transport: a ring of handles inside one process */
