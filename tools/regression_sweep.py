@@ -227,6 +227,14 @@ def run(args):
                         if line.startswith("liblbmi report:") and len(w) == 5 and w[3].isdigit():
                             calls[w[2]] = [int(w[3]), int(w[4])]
                     rec["calls"] = calls
+                    # ... and how the binding ended up running it: "execution
+                    # mode fused (chosen by the binding); rho, u on demand in
+                    # 10 of 10 collisions"
+                    m = re.search(r"liblbmi report: execution mode (\w+) \(([^)]*)\); rho, u on "
+                                  r"demand in (\d+) of (\d+) collisions", err)
+                    if m:
+                        rec["policy"] = {"mode": m.group(1), "lazy": int(m.group(3)),
+                                         "collisions": int(m.group(4))}
                 if leg == "bound" and "unbound" in outputs:
                     # what the binding changes: the two executables on this GPU
                     b2, w2, f2 = compare(outputs["unbound"], out, args.tol)
@@ -271,7 +279,7 @@ def report(args):
         return "did not finish (rc %s)" % x["rc"]
     print("# %-10s | %-28s | %-28s | %-22s | %s" % (
         "input", "unbound vs the kept log", "bound vs the kept log", "bound vs unbound",
-        "library/original calls: collide halo propagation | others the library took"))
+        "mode at exit, collisions with rho,u on demand | library/original calls: collide halo propagation | others the library took"))
     n_same = n_both = 0
     for name in sorted(rows):
         r = rows[name]
@@ -282,12 +290,23 @@ def report(args):
         c = r.get("calls") or {}
         main = " ".join("%d/%d" % tuple(c.get(k, [0, 0])) for k in ("lb_collide", "lb_halo_swap", "lb_propagation"))
         rest = ",".join(k for k in sorted(c) if k not in ("lb_collide", "lb_halo_swap", "lb_propagation") and c[k][0])
+        pol = r.get("policy")
+        if pol:
+            main = "%s, rho,u on demand %d/%d | %s" % (pol["mode"], pol["lazy"], pol["collisions"], main)
         print("%-12s | %-28s | %-28s | %-22s | %s" % (
             name[7:], cell(r.get("unbound")), cell(r.get("bound")),
             "-" if bu is None else ("identical, %.1e" % bu["worst"] if bu["lines"] == 0
                                     else "%d lines, %.1e" % (bu["lines"], bu["worst"])),
             (main + " | " + rest) if c else "-"))
     print("# bound against unbound: %d of %d logs identical (numbers within the tolerance)" % (n_same, n_both))
+    pols = [r["policy"] for r in rows.values() if r.get("policy")]
+    if pols:
+        print("# of the %d runs that reached a bound lb_collide: %d ended in fused, %d in halo, %d in eager; "
+              "%d left rho, u on demand in every collision, %d in none"
+              % (len(pols), sum(p["mode"] == "fused" for p in pols),
+                 sum(p["mode"] == "halo" for p in pols), sum(p["mode"] == "eager" for p in pols),
+                 sum(p["lazy"] == p["collisions"] and p["collisions"] > 0 for p in pols),
+                 sum(p["lazy"] == 0 for p in pols)))
 
 
 def main():
