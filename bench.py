@@ -107,6 +107,10 @@ def parse():
                     "Cahn-Hilliard in one pass straight from phi, then the LB "
                     "step; grad: gradient arrays first (lbmi_field_grad), then "
                     "the one pass reading them")
+    ap.add_argument("--fe-rho", default="lazy", choices=["lazy", "store"],
+                    help="--fe-route step: hydro->rho on demand (once, inside "
+                    "the timed region; the binding's default with a free "
+                    "energy) or stored by every step")
     ap.add_argument("--fe-halos", type=int, default=0,
                     help="1: keep the field halo swaps of phi and u (the "
                     "reference's structure) on one GPU as well")
@@ -593,6 +597,11 @@ def main():
             # the thermodynamic force is the only contribution and stays in
             # registers: the array is zeroed through the library (not read)
             lb.hydro_field_set(hydro.force, (0.0, 0.0, 0.0))
+            # u is stored by every step (the next one advects with it); rho,
+            # which nothing on the device reads, is formed on demand -- as the
+            # binding runs a free-energy case unconfigured (hydro_lazy 2)
+            if args.fe_rho == "lazy":
+                lb.tune("hydro_lazy", 2)
         torch.cuda.synchronize()
 
     def fe_step():
@@ -681,6 +690,8 @@ def main():
     else:
         for _ in range(args.steps):
             one_step()
+        if args.fe_route == "step" and args.fe_rho == "lazy":
+            lb.hydro_sync()              # rho of the last step, asked for once
     lb.synchronize()
     torch.cuda.synchronize()
     barrier()
@@ -776,10 +787,11 @@ def main():
                 # the one kernel of the binary-fluid step: beside the
                 # distributions rho, u stored (32 B), u of the previous step
                 # (24 B) and phi in and out (16 B)
+                extra = 72 - (8 if args.fe_rho == "lazy" else 0)
                 roofline["kernel"] = "k_symm_lb_step"
                 roofline["achieved_with_hydro_io"] = round(
-                    1e-9 * (pop_bytes + 72) * local_sites / t_launch, 1)
-                roofline["bytes_per_lup_with_hydro_io"] = pop_bytes + 72
+                    1e-9 * (pop_bytes + extra) * local_sites / t_launch, 1)
+                roofline["bytes_per_lup_with_hydro_io"] = pop_bytes + extra
             elif args.hydro == "1":
                 roofline["achieved_with_hydro_io"] = round(
                     1e-9 * (pop_bytes + 56) * local_sites / t_launch, 1)
@@ -831,6 +843,12 @@ def main():
                 "workload": "D3Q%d %s single-fluid %dx%dx%d periodic, "
                             "lb_collide+lb_halo+lb_propagation per step, %s"
                             % (args.nvel, args.scheme.upper(), *ntotal,
+                               ("binary fluid: force + Cahn-Hilliard + LB step in "
+                                "one call; the thermodynamic force stays in "
+                                "registers, u stored every step, rho %s"
+                                % ("on demand" if args.fe_rho == "lazy"
+                                   else "stored every step"))
+                               if (fe is not None and args.fe_route == "step") else
                                {"lazy": "hydro arrays as the binding runs them "
                                 "unconfigured: zero force field not read, "
                                 "rho,u on demand (hydro_every_step: the "
@@ -840,17 +858,24 @@ def main():
                                 "0": "no hydro arrays"}[args.hydro]),
                 "mode": args.mode,
                 "order": order,
-                                "hydro_io": {"lazy": "arrays present; force zeroed through the "
-                             "library (not read); rho,u formed on demand, once, "
-                             "inside the timed region",
-                             "1": "force read and rho,u stored by every collision",
-                             "0": "no hydro arrays"}[args.hydro],
+                "hydro_io": ("force array zeroed through the library, neither "
+                             "written nor read; u stored by every step; rho %s"
+                             % ("formed on demand, once, inside the timed region"
+                                if args.fe_rho == "lazy" else "stored by every step"))
+                if (fe is not None and args.fe_route == "step") else
+                {"lazy": "arrays present; force zeroed through the "
+                 "library (not read); rho,u formed on demand, once, "
+                 "inside the timed region",
+                 "1": "force read and rho,u stored by every collision",
+                 "0": "no hydro arrays"}[args.hydro],
                 "free_energy": args.fe if args.fe == "none" else
                 "%s (%d-point gradients, advection order %d, from %s%s)"
                 % (args.fe, args.fe_grad, args.fe_order,
                    {"step": "phi inside the LB kernel: force, Cahn-Hilliard "
                     "update and collision of a site by one thread "
-                    "(lbmi_symmetric_lb_step)"}.get(args.fe_route, args.fe_route),
+                    "(lbmi_symmetric_lb_step), u stored every step, rho %s"
+                    % ("on demand" if args.fe_rho == "lazy" else "stored every step")
+                    }.get(args.fe_route, args.fe_route),
                    ", periodic wrap by index instead of field halos"
                    if fe["periodic"] else ""),
                 "decomposition": "x-slab %d_1_1" % world

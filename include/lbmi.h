@@ -706,7 +706,9 @@ int lbmi_timing_read_detail(lbmi_t * lb, double ms[3], int * nsample);
  *            beside the interior launch once the halo has arrived (default),
  *            0 = after it on the compute stream;
  * "hydro_lazy": 1 = lbmi_lb_collide leaves hydro->rho, u to lbmi_lb_hydro_sync
- *            (see there), 0 = stored by every collision (default);
+ *            (see there), 2 = hydro->rho only (u stored: somebody reads it
+ *            before the next collision; lbmi_symmetric_lb_step treats 1 as
+ *            2), 0 = both stored by every collision (default);
  * "graph":   1 = lbmi_lb_run on one GPU in FUSED mode issues its steps as
  *            launches of ONE hipGraph holding two steady-state steps (for
  *            lattices whose step is as short as a launch), 0 = step by step

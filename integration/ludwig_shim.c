@@ -244,6 +244,7 @@ typedef struct shim_s {
   int colloids;                   /* bounce_back_on_links has seen colloids */
   int ncollide;                   /* bound collisions so far */
   int nlazy;                      /* ... of which left rho, u on demand */
+  int nlazy_rho;                  /* ... of which left rho alone on demand */
   int automode;                   /* LBMI_MODE unset: fused until a consumer of
 				     the state between lb_collide and
 				     lb_propagation shows up */
@@ -270,9 +271,9 @@ static void shim_report_policy(void) {
   const shim_t * sh = (shim_.h != NULL) ? &shim_ : &shim_ended_;
   if (sh->lb == NULL) return;
   fprintf(stderr, "liblbmi report: execution mode %s (%s); rho, u on demand in "
-	  "%d of %d collisions\n", shim_mode_name(sh->mode),
+	  "%d of %d collisions, rho alone in %d\n", shim_mode_name(sh->mode),
 	  sh->automode ? "chosen by the binding" : "LBMI_MODE",
-	  sh->nlazy, sh->ncollide);
+	  sh->nlazy, sh->ncollide, sh->nlazy_rho);
 }
 
 #define SHIM_CHECK(lb, call)						\
@@ -466,6 +467,7 @@ static lbmi_t * shim_handle(lb_t * lb) {
     shim_.colloids = 0;
     shim_.ncollide = 0;
     shim_.nlazy = 0;
+    shim_.nlazy_rho = 0;
     shim_.automode = (mode == NULL);
 
     shim_device_f(lb, &f, &fprime);
@@ -689,8 +691,19 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
       lazy = (wanted && fe == NULL && visc == NULL && !shim_.colloids &&
 	      lb->ndist == 1 && shim_openbc_ == 0 &&
 	      !(hydro->le && lees_edw_nplane_total(hydro->le) > 0));
-      SHIM_CHECK(lb, lbmi_tune(h, "hydro_lazy", lazy));
       shim_.nlazy += lazy;
+      /* hydro->rho alone has no reader on the device anywhere in the
+       * reference but the open boundaries (lb_bc_inflow_rhou.c:271-502,
+       * lb_bc_outflow_rhou.c:392-504; everything else takes it from the host
+       * copy, through hydro_memcpy): where u must be stored -- a free energy
+       * advects with it, a viscosity model reads it -- the density still need
+       * not be, 8 B/site per step */
+      if (!lazy && wanted && lb->ndist == 1 && shim_openbc_ == 0 &&
+	  !(hydro->le && lees_edw_nplane_total(hydro->le) > 0)) {
+	lazy = 2;
+	shim_.nlazy_rho += 1;
+      }
+      SHIM_CHECK(lb, lbmi_tune(h, "hydro_lazy", lazy));
     }
 
     if (lb->ndist == 2 || (fe && fe->use_stress_relaxation)) {

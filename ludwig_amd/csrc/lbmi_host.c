@@ -820,8 +820,9 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
       ifail = lbmi_hydro_materialise(lb);
       if (ifail) return ifail;
     }
-    if (lb->hydro_lazy != (value != 0)) lbmi_run_graph_release(lb);
-    lb->hydro_lazy = (value != 0);
+    if (value < 0 || value > 2) return lbmi_fail(LBMI_ERR_ARGUMENT, "hydro_lazy = %d (0, 1, 2)", value);
+    if (lb->hydro_lazy != value) lbmi_run_graph_release(lb);
+    lb->hydro_lazy = value;          /* 1: rho and u on demand, 2: rho only */
     return 0;
   }
   if (strcmp(key, "fe_stripes") == 0) {
@@ -1786,13 +1787,29 @@ int lbmi_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro) {
 
   /* whatever an earlier collision still owed is superseded by this one */
   lb->hydro_stale = 0;
-  if (lb->hydro_lazy && lbmi_deferred(lb) && !lbmi_inplace(lb) &&
+  if (lb->hydro_lazy == 1 && lbmi_deferred(lb) && !lbmi_inplace(lb) &&
       (h.rho != NULL || h.u != NULL)) {
     int ifail;
     lb->lazy_h = h;
     for (int ia = 0; ia < 3; ia++) lb->lazy_fbody[ia] = lb->kp.fbody[ia];
     h.rho = NULL;
     h.u = NULL;
+    ifail = lbmi_lb_collide_dev(lb, &h);
+    if (ifail == 0) lb->hydro_stale = 1;
+    return ifail;
+  }
+  if (lb->hydro_lazy == 2 && lbmi_deferred(lb) && !lbmi_inplace(lb) && h.rho != NULL) {
+    /* rho alone on demand: u is stored (somebody reads it before the next
+     * collision: the advection of an order parameter, a viscosity model),
+     * the density has no reader on the device in the reference but the open
+     * boundaries (rho = sum f'_p needs neither the force nor u) */
+    int ifail;
+    lb->lazy_h = h;
+    lb->lazy_h.u = NULL;
+    lb->lazy_h.force = NULL;
+    for (int ia = 0; ia < 3; ia++) lb->lazy_fbody[ia] = lb->kp.fbody[ia];
+    h.rho = NULL;
+    lbmi_known_zero_drop(lb, h.u);
     ifail = lbmi_lb_collide_dev(lb, &h);
     if (ifail == 0) lb->hydro_stale = 1;
     return ifail;
@@ -3392,6 +3409,7 @@ int lbmi_symmetric_lb_step(lbmi_t * lb, const lbmi_hydro_t * hydro,
   if (fused) {
     lbmi_hydro_dev_t h = lbmi_hydro_dev(&hy);
     int lay = lbmi_blocked_ok(lb) ? (lb->blocked ? 2 : 1) : 0;
+    int owed = 0;
     int ifail;
     if (lay == 0 && lb->blocked) {
       ifail = lbmi_unblock(lb);
@@ -3404,10 +3422,21 @@ int lbmi_symmetric_lb_step(lbmi_t * lb, const lbmi_hydro_t * hydro,
       size_t bytes = 2*sizeof(double)*(size_t) lb->kp.nsite*(size_t) lb->kp.nvel;
       lb->kp.nt_store = (bytes > ((size_t) 256 << 20)) ? 1 : 0;
     }
-    lb->hydro_stale = 0;              /* superseded: this collision stores */
-    lbmi_known_zero_drop(lb, h.rho);
+    lb->hydro_stale = 0;              /* superseded by this collision */
     lbmi_known_zero_drop(lb, h.u);
     lbmi_known_zero_drop(lb, phi_out);
+    if (lb->hydro_lazy && h.rho != NULL) {
+      /* u is stored (the next step reads it); rho is owed until asked for */
+      lb->lazy_h = h;
+      lb->lazy_h.u = NULL;
+      lb->lazy_h.force = NULL;
+      for (int ia = 0; ia < 3; ia++) lb->lazy_fbody[ia] = lb->kp.fbody[ia];
+      h.rho = NULL;
+      owed = 1;
+    }
+    else {
+      lbmi_known_zero_drop(lb, h.rho);
+    }
     ifail = lbmi_time_begin(lb);
     if (ifail) return ifail;
     KCHECK(lbmi_k_symm_lb_step(&lb->kp, lb->f, lb->fprime, &h, a, b, kappa,
@@ -3417,6 +3446,7 @@ int lbmi_symmetric_lb_step(lbmi_t * lb, const lbmi_hydro_t * hydro,
     if (ifail) return ifail;
     lb->blocked = (lay != 0);
     lbmi_swapf(lb);
+    lb->hydro_stale = owed;
     /* lb_halo and lb_propagation of this step: pending again, as they were */
     return 0;
   }
@@ -3436,7 +3466,7 @@ int lbmi_symmetric_lb_step(lbmi_t * lb, const lbmi_hydro_t * hydro,
 			       lb->fe_force, phi_out, 0, 1, lb->stream));
     hy.force = lb->fe_force;
     hy.nsite = 0;
-    lb->hydro_lazy = 0;               /* the next step reads this u */
+    lb->hydro_lazy = lazy ? 2 : 0;    /* the next step reads this u */
     ifail = lbmi_one_step(lb, &hy);
     lb->hydro_lazy = lazy;
     return ifail;

@@ -222,6 +222,57 @@ def test_binary_fluid_steps_vs_oracle(npt, order):
     lb.free()
 
 
+@pytest.mark.parametrize("lazy", [0, 2])
+def test_one_kernel_binary_fluid_step_with_rho_on_demand(lazy):
+    """hydro_lazy 2 (what the binding sets where a free energy needs u every
+    step): the one-kernel step stores u and leaves rho until it is asked for;
+    asked after any step (lbmi_lb_hydro_sync) it is the oracle's, and the run
+    is the same bit for bit as with rho stored every step."""
+    import ludwig_amd
+    import torch
+    nlocal, h, nsteps = (12, 10, 8), 2, 5
+    a, b, kappa, mob = -0.00625, 0.00625, 0.004, 1.25
+    p = lbo.make_param(19, nlocal, h, "m10", 0.1, 0.3)
+    rng = np.random.default_rng(12)
+    phi0 = np.zeros(lbo.nall(p))
+    interior(phi0, h)[...] = 0.1 * rng.standard_normal(nlocal)
+    f0 = lbo.init_synthetic(p)
+    lb = ludwig_amd.LB(19, nlocal, h, mode=ludwig_amd.FUSED)
+    lb.relaxation_set("m10", 0.1, 0.3)
+    lb.fe_scheme_set(7, 1)
+    lb.tune("hydro_lazy", lazy)
+    hy = ludwig_amd.Hydro(lb.nall, lb.device)
+    ua, ub = hy.u, torch.zeros_like(hy.u)
+    pa, pb = _dev(lb, phi0), torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+    lb.lb_memcpy_h2d(f0)
+    phi = phi0.copy()
+    f = f0.copy()
+    fp = np.zeros_like(f)
+    u = np.zeros((3,) + phi.shape)
+    rho = np.zeros(phi.shape)
+    for n in range(nsteps):
+        force = np.zeros((3,) + phi.shape)
+        lbo.field_halo(p, phi, 2)
+        grad, delsq = lbo.grad(p, phi, 7)
+        lbo.symm_force(p, a, b, kappa, phi, grad, delsq, force)
+        lbo.field_halo(p, u, 1)
+        lbo.cahn_hilliard(p, a, b, kappa, mob, phi, delsq, u, order=1)
+        u[...] = 0.0
+        f, fp = lbo.step(p, f, fp, force, None, rho, u)
+        hy.u = ub if n % 2 == 0 else ua
+        lb.symmetric_lb_step(hy, ua if n % 2 == 0 else ub, a, b, kappa, mob, pa, pb)
+        pa, pb = pb, pa
+        if n in (1, nsteps - 1):
+            lb.hydro_sync()
+            lb.synchronize()
+            torch.cuda.synchronize()
+            assert relmax(interior(hy.rho.cpu().numpy(), h), interior(rho, h)) < 1e-12, n
+        assert relmax(interior(_host(lb, hy.u), h), interior(u, h)) < 1e-12, n
+    assert relmax(interior(lb.lb_memcpy_d2h(), h), interior(f, h)) < 1e-12
+    assert relmax(interior(_host(lb, pa), h), interior(phi, h)) < 1e-12
+    lb.free()
+
+
 @pytest.mark.parametrize("scheme", ["m10", "bgk"])
 @pytest.mark.parametrize("order", [1, 2, 3, 4])
 def test_one_kernel_binary_fluid_step_vs_oracle(order, scheme):

@@ -343,3 +343,52 @@ def test_hydro_arrays_with_their_own_component_stride(nvel, mode, lazy):
     # nothing between the components has been written, nor read as a force
     assert np.all(u[:, nsite:] == marker)
     lb.free()
+
+
+@pytest.mark.parametrize("mode", [1, 3], ids=["fused", "fused_halo"])
+def test_rho_alone_on_demand(mode):
+    """hydro_lazy 2: u stored by every collision (equal to the oracle's after
+    every step, no sync), rho formed when asked for -- with a force field, solid
+    sites, at several call points; the distributions are untouched by it."""
+    import ludwig_amd
+    import torch
+    nall = tuple(n + 2 for n in NLOCAL)
+    force = _force_field(nall)
+    status = np.zeros(nall, dtype=np.int8)
+    status[3:5, 2:4, 4:7] = 1
+    nsteps = 4
+    p = lbo.make_param(19, NLOCAL, 1, "m10", 0.1, 0.3, 1.0, FBODY)
+    f = lbo.init_synthetic(p)
+    f0 = f.copy()
+    fp = np.zeros_like(f)
+    rho = np.zeros(nall)
+    u = np.zeros((3,) + nall)
+    lb = ludwig_amd.LB(19, NLOCAL, 1, mode=mode)
+    lb.relaxation_set("m10", 0.1, 0.3)
+    lb.body_force_set(FBODY)
+    lb.tune("hydro_lazy", 2)
+    hy = ludwig_amd.Hydro(nall, lb.device, force=force, status=status)
+    lb.lb_memcpy_h2d(f0)
+    fluid = (status == 0)[1:-1, 1:-1, 1:-1]
+    for n in range(nsteps):
+        lbo.collide(p, f, force, status, rho, u)
+        lb.lb_collide(hy)
+        lb.synchronize()
+        torch.cuda.synchronize()
+        assert relmax(interior(hy.u.cpu().numpy(), 1)[:, fluid], interior(u, 1)[:, fluid]) < 1e-12
+        if n == 1:
+            lb.hydro_sync()                       # between lb_collide and lb_halo
+        lbo.halo(p, f)
+        lb.lb_halo()
+        lbo.propagate(p, f, fp)
+        f, fp = fp, f
+        lb.lb_propagation()
+        if n in (1, 2):
+            lb.hydro_sync()                       # with the propagation pending
+            lb.synchronize()
+            torch.cuda.synchronize()
+            assert relmax(interior(hy.rho.cpu().numpy(), 1)[fluid], interior(rho, 1)[fluid]) < 1e-12
+    out = lb.lb_memcpy_d2h()                      # the flush settles what is owed
+    assert relmax(interior(hy.rho.cpu().numpy(), 1)[fluid], interior(rho, 1)[fluid]) < 1e-12
+    assert relmax(interior(out, 1)[:, fluid], interior(f, 1)[:, fluid]) < 1e-12
+    lb.free()
