@@ -593,7 +593,7 @@ int lbmi_symmetric_step_periodic(lbmi_t * lb, double a, double b,
  * densities (NULL: not stored). hydro->force must be NULL or known to hold
  * zeros (lbmi_hydro_field_set): the thermodynamic force is the only
  * contribution and is not stored anywhere. Neither phi nor u needs a halo.
- * In the steady state of LBMI_MODE_FUSED (D3Q19, M10 or BGK, 7-point
+ * In the steady state of LBMI_MODE_FUSED (D3Q19 or D3Q27, M10 or BGK, 7-point
  * gradients of lbmi_fe_scheme_set, any advection order 1..4, no
  * fluctuations, nlocal >= 4) the step is ONE kernel: the thread that
  * collides a site evaluates its force and its Cahn-Hilliard update from the

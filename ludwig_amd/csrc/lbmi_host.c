@@ -401,6 +401,7 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   lb->use_blocked = 1;               /* profiles/r01_blocked_order.txt */
   lb->kp.fe_tiled = 1;
   lb->kp.fe_stripes = 0;             /* profiles/r03_rejected.txt, 6 */
+  lb->kp.fe_xcd_group = 8;
   lb->nt_store_mode = -1;            /* idem: nontemporal stores when f, fprime
 					exceed the Infinity Cache */
   lb->grad_npt = 7;
@@ -803,6 +804,11 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
   if (strcmp(key, "xcd_group") == 0) {
     if (value < 0 || value > 65536) return lbmi_fail(LBMI_ERR_ARGUMENT, "xcd_group");
     lb->kp.xcd_group = value;
+    return 0;
+  }
+  if (strcmp(key, "fe_xcd_group") == 0) {
+    if (value < 0 || value > 65536) return lbmi_fail(LBMI_ERR_ARGUMENT, "fe_xcd_group");
+    lb->kp.fe_xcd_group = value;
     return 0;
   }
   if (strcmp(key, "x_packed") == 0) {
@@ -3400,7 +3406,7 @@ int lbmi_symmetric_lb_step(lbmi_t * lb, const lbmi_hydro_t * hydro,
 
   fused = (lb->opts.mode == LBMI_MODE_FUSED && lb->pending_prop &&
 	   lb->pending_halo && !lb->layout_swapped && lb->noise_state == NULL &&
-	   lb->grad_npt == 7 && lb->opts.nvel == 19 &&
+	   lb->grad_npt == 7 &&
 	   (lb->kp.scheme == LBMI_RELAXATION_M10 ||
 	    lb->kp.scheme == LBMI_RELAXATION_BGK) &&
 	   lb->kp.nlocal[X] >= 4 && lb->kp.nlocal[Y] >= 4 && lb->kp.nlocal[Z] >= 4 &&
@@ -3452,7 +3458,7 @@ int lbmi_symmetric_lb_step(lbmi_t * lb, const lbmi_hydro_t * hydro,
   }
 
   /* Anywhere else (first step after a flush, another mode, 27-point
-   * gradients, TRT, D3Q27, fluctuations ...): the separate calls. The force
+   * gradients, TRT, fluctuations ...): the separate calls. The force
    * needs an array: one of the handle's own. */
   {
     int ifail;

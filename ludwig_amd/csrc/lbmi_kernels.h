@@ -41,6 +41,9 @@ typedef struct lbmi_kparam_s {
   int lds_cap;             /* dynamic LDS bytes per block: occupancy cap */
   int nt_store;            /* blocked order: nontemporal stores of f */
   int fe_tiled;            /* free-energy pass: phi through an LDS tile */
+  int fe_xcd_group;        /* k_symm_lb_step: blocks per XCD interleave group
+			      (8: a little better than the 32 of the LB kernel
+			      in every A/B, profiles/r03_rejected.txt 6) */
   int fe_stripes;          /* k_symm_lb_step: every XCD an eighth of every
 			      x plane (its stencil partners behind one L2);
 			      measured slower, default 0 */

@@ -2342,7 +2342,7 @@ void k_symm_lb_step(lbmi_kparam_t kp, const double * __restrict__ f,
   }
   else {
     unsigned lb;
-    if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+    if (!logical_block(nblk, lb, (unsigned) kp.fe_xcd_group)) return;
     constexpr int ALIGNV = (ORD == 0) ? LBMI_ALIGN : LBW;
     i = (i0/ALIGNV)*ALIGNV + (int) (lb*BLOCK + threadIdx.x);
     if (i < i0 || i >= i1) return;
@@ -3851,7 +3851,7 @@ static int launch_symm_lb(const lbmi_kparam_t & kp, const double * f,
    * eighth of every plane */
   const int gstripe = kp.fe_stripes ? (kp.strx + 8*BLOCK - 1)/(8*BLOCK) : 0;
   dim3 grid(gstripe ? (unsigned) (kp.nlocal[0]*gstripe*8)
-	    : grid_for(nblk, (unsigned) kp.xcd_group)), block(BLOCK);
+	    : grid_for(nblk, (unsigned) kp.fe_xcd_group)), block(BLOCK);
   /* no occupancy cap here (launch_pc_hio has one): with the free-energy
    * arithmetic in front of the collision the kernel is bound by latency and
    * issue as much as by HBM, and every resident wave helps
@@ -3882,16 +3882,28 @@ extern "C" int lbmi_k_symm_lb_step(const lbmi_kparam_t * kp, const double * f,
 				   double * phi_out, int lay, void * stream) {
   hipStream_t st = (hipStream_t) stream;
   const Symm q = {a, b, kappa};
-  if (kp->nvel != 19) return (int) hipErrorInvalidValue;
-  if (lay == 0) return launch_symm_lb<19, 0>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+  if (kp->nvel == 19) {
+    if (lay == 0) return launch_symm_lb<19, 0>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
 #if LBMI_BLOCK*LBMI_SPT == 256
-  if (kp->nt_store & 1) {
-    if (lay == 1) return launch_symm_lb<19, 5>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
-    if (lay == 2) return launch_symm_lb<19, 6>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
-  }
-  if (lay == 1) return launch_symm_lb<19, 1>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
-  if (lay == 2) return launch_symm_lb<19, 2>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+    if (kp->nt_store & 1) {
+      if (lay == 1) return launch_symm_lb<19, 5>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+      if (lay == 2) return launch_symm_lb<19, 6>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+    }
+    if (lay == 1) return launch_symm_lb<19, 1>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+    if (lay == 2) return launch_symm_lb<19, 2>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
 #endif
+  }
+  if (kp->nvel == 27) {
+    if (lay == 0) return launch_symm_lb<27, 0>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+#if LBMI_BLOCK*LBMI_SPT == 256
+    if (kp->nt_store & 1) {
+      if (lay == 1) return launch_symm_lb<27, 5>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+      if (lay == 2) return launch_symm_lb<27, 6>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+    }
+    if (lay == 1) return launch_symm_lb<27, 1>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+    if (lay == 2) return launch_symm_lb<27, 2>(*kp, f, fprime, *h, q, mobility, order, phi, uprev, phi_out, st);
+#endif
+  }
   return (int) hipErrorInvalidValue;
 }
 

@@ -273,9 +273,10 @@ def test_one_kernel_binary_fluid_step_with_rho_on_demand(lazy):
     lb.free()
 
 
-@pytest.mark.parametrize("scheme", ["m10", "bgk"])
-@pytest.mark.parametrize("order", [1, 2, 3, 4])
-def test_one_kernel_binary_fluid_step_vs_oracle(order, scheme):
+@pytest.mark.parametrize("nvel,scheme,order", [(19, "m10", 1), (19, "m10", 2), (19, "m10", 3),
+                                               (19, "m10", 4), (19, "bgk", 1), (19, "bgk", 3),
+                                               (27, "m10", 1), (27, "bgk", 2), (27, "m10", 4)])
+def test_one_kernel_binary_fluid_step_vs_oracle(nvel, order, scheme):
     """lbmi_symmetric_lb_step: the whole step of BASELINE config 4 as ONE
     kernel (force and Cahn-Hilliard update of a site evaluated by the thread
     that collides it, u of the previous step from a second array) against
@@ -287,13 +288,13 @@ def test_one_kernel_binary_fluid_step_vs_oracle(order, scheme):
     import torch
     nlocal, h, nsteps = (12, 10, 8), 2, 5
     a, b, kappa, mob = -0.00625, 0.00625, 0.004, 1.25
-    p = lbo.make_param(19, nlocal, h, scheme, 0.1, 0.3, 1.0, (1e-6, -2e-6, 5e-7))
+    p = lbo.make_param(nvel, nlocal, h, scheme, 0.1, 0.3, 1.0, (1e-6, -2e-6, 5e-7))
     rng = np.random.default_rng(9)
     phi0 = np.zeros(lbo.nall(p))
     interior(phi0, h)[...] = 0.1 * rng.standard_normal(nlocal)
     f0 = lbo.init_synthetic(p)
 
-    lb = ludwig_amd.LB(19, nlocal, h, mode=ludwig_amd.FUSED)
+    lb = ludwig_amd.LB(nvel, nlocal, h, mode=ludwig_amd.FUSED)
     lb.relaxation_set(scheme, 0.1, 0.3)
     lb.body_force_set((1e-6, -2e-6, 5e-7))
     lb.fe_scheme_set(7, order)
