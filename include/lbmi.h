@@ -709,6 +709,13 @@ int lbmi_timing_read_detail(lbmi_t * lb, double ms[3], int * nsample);
  *            (see there), 2 = hydro->rho only (u stored: somebody reads it
  *            before the next collision; lbmi_symmetric_lb_step treats 1 as
  *            2), 0 = both stored by every collision (default);
+ * "halo_fold": 1 = LBMI_MODE_FUSED_HALO on one rank: the kernel of lbmi_lb_collide
+ *            computes the width-1 halo shell of its own result (a shell site =
+ *            the collision of its periodic image), and the lbmi_lb_halo that
+ *            follows has nothing left to do unless f has been written in
+ *            between (default), 0 = three halo launches after it;
+ * "fe_xcd_group" (8), "fe_stripes" (0): block-to-XCD mapping of the one-kernel
+ *            binary-fluid step (lbmi_symmetric_lb_step);
  * "graph":   1 = lbmi_lb_run on one GPU in FUSED mode issues its steps as
  *            launches of ONE hipGraph holding two steady-state steps (for
  *            lattices whose step is as short as a launch), 0 = step by step
