@@ -86,6 +86,7 @@ struct lbmi_s {
    * of handles on one device (lbmi_ring_t: tests, rehearsals) */
   ncclComm_t comm;
   lbmi_ring_t * ring;
+  unsigned long long peers_enabled;  /* devices this one has enabled peer access to */
   int have_comm;
   double * sendlo, * sendhi, * recvlo, * recvhi;   /* staging, any halo swap */
   size_t xbuf_doubles;
@@ -1150,6 +1151,7 @@ static int ring_fail(lbmi_ring_t * r, int code, const char * what) {
 }
 
 static int ring_sendrecv(lbmi_ring_t * r, int me, int mydev,
+			 unsigned long long * peers_enabled,
 			 const lbmi_xop_t * ops, int nops,
 			 double * const base[5], hipStream_t st) {
   unsigned first_mine[LBMI_XOPS_MAX];   /* per op: index of my send in its fifo */
@@ -1194,6 +1196,17 @@ static int ring_sendrecv(lbmi_ring_t * r, int me, int mydev,
 	hipEventCreateWithFlags(&m->done, hipEventDisableTiming) != hipSuccess) {
       return ring_fail(r, LBMI_ERR_HIP, "hipEventCreate");
     }
+    if (m->device != mydev && m->device >= 0 && m->device < 64 &&
+	!(*peers_enabled & (1ULL << m->device))) {
+      /* a neighbour that attached after this rank: its device becomes
+       * reachable now (lbmi_comm_init_ring could only enable those that were
+       * already there) */
+      hipError_t e = hipDeviceEnablePeerAccess(m->device, 0);
+      if (e != hipSuccess) (void) hipGetLastError();   /* already enabled, or
+							  not possible: the copy
+							  below is staged then */
+      *peers_enabled |= (1ULL << m->device);
+    }
     if (hipStreamWaitEvent(st, m->ready, 0) != hipSuccess ||
 	((m->device == mydev)
 	 ? hipMemcpyAsync(base[ops[n].buffer] + ops[n].offset, m->ptr,
@@ -1231,8 +1244,8 @@ static int ring_sendrecv(lbmi_ring_t * r, int me, int mydev,
 static int lbmi_x_sendrecv(lbmi_t * lb, const lbmi_xop_t * ops, int nops,
 			   double * const base[5], hipStream_t st) {
   if (lb->ring) {
-    return ring_sendrecv(lb->ring, lb->opts.cartrank, lb->device, ops, nops,
-			 base, st);
+    return ring_sendrecv(lb->ring, lb->opts.cartrank, lb->device,
+			 &lb->peers_enabled, ops, nops, base, st);
   }
   NCCLCHECK(ncclGroupStart());
   for (int n = 0; n < nops; n++) {
@@ -3986,6 +3999,7 @@ int lbmi_comm_init_ring(lbmi_t * lb, lbmi_ring_t * ring) {
 			 hipGetErrorString(e));
       }
       (void) hipGetLastError();        /* (already enabled is not an error) */
+      if (pdev < 64) lb->peers_enabled |= (1ULL << pdev);
     }
   }
   lb->ring = ring;
