@@ -121,6 +121,10 @@ def parse():
                     "(lbmi_ring_t; no RCCL bootstrap; ranks beyond the number "
                     "of devices share them: a rehearsal). `python bench.py "
                     "--gpus N --transport peer` from a plain shell")
+    ap.add_argument("--cartdim", type=int, default=0, choices=[0, 1, 2],
+                    help="with --selfring 1: the direction of the 1-rank ring "
+                    "(0 X: contiguous planes, interior + boundary launch; 1 Y, "
+                    "2 Z: gathered planes, one launch + the face launch)")
     ap.add_argument("--selfring", type=int, default=0,
                     help="1 GPU only: route the X halo through a 1-rank RCCL "
                     "ring (exercises the N>1 step path: pack, send/recv, "
@@ -506,9 +510,12 @@ def main():
             "inplace": ludwig_amd.INPLACE,
             "fused_soa": ludwig_amd.FUSED_SOA,
             "fused_halo": ludwig_amd.FUSED_HALO}[args.mode]
+    if args.cartdim != 0 and not (world == 1 and args.selfring):
+        raise SystemExit("--cartdim 1 | 2: with --selfring 1 on one GPU (the "
+                         "N-rank runs of this bench cut along X)")
     lb = ludwig_amd.LB(args.nvel, dec.nlocal, args.nhalo, mode=mode,
                        halo_scheme=ludwig_amd.HALO_REDUCED, device=local_rank,
-                       cartsz=world, cartrank=rank,
+                       cartsz=world, cartrank=rank, cartdim=args.cartdim,
                        own_stream=bool(args.own_stream))
     zeta = 0.3 if args.scheme == "m10" else 0.1
     lb.relaxation_set(args.scheme, 0.1, zeta)
@@ -878,7 +885,9 @@ def main():
                     }.get(args.fe_route, args.fe_route),
                    ", periodic wrap by index instead of field halos"
                    if fe["periodic"] else ""),
-                "decomposition": "x-slab %d_1_1" % world
+                "decomposition": ("x-slab %d_1_1" % world if args.cartdim == 0 else
+                                  "%s-slab (1-rank ring along %s)"
+                                  % ("xyz"[args.cartdim], "XYZ"[args.cartdim]))
                                  + (" (1-rank RCCL ring)" if args.selfring else ""),
                 "halo": "index wrap (1 GPU); reduced X planes over RCCL (N>1)",
             },

@@ -329,15 +329,6 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
 
   lb->opts = *opts;
   lb->xdim = opts->cartdim;
-  if (opts->cartsz > 1 && opts->cartdim != X &&
-      (opts->mode == LBMI_MODE_FUSED || opts->mode == LBMI_MODE_INPLACE)) {
-    /* Slabs along Y or Z: the boundary planes are not contiguous runs of x
-     * planes, so the split of the fused step into an interior launch and a
-     * boundary launch against the exchange buffers does not apply: the halo
-     * swap runs where lb_halo is called (the planes over the ring), and the
-     * propagation alone is folded into the next collision */
-    lb->opts.mode = LBMI_MODE_FUSED_HALO;
-  }
   if (opts->device >= 0) {
     if (opts->device >= ndevice) {
       free(lb);
@@ -1542,6 +1533,7 @@ static int lbmi_blocked_ok(const lbmi_t * lb) {
    * fluctuations (their collision has no variant in this order) */
   if (lb->opts.ndist != 1 &&
       (lb->opts.cartsz > 1 || lb->have_comm || lb->noise_state != NULL)) return 0;
+  if (lb->xdim != X && (lb->opts.cartsz > 1 || lb->have_comm)) return 0;
   if (lb->opts.cartsz == 1 && !lb->have_comm) {
     /* every pull is wrapped by index: nothing beyond the interior planes */
     int last = (lb->kp.nhalo + lb->kp.nlocal[X])*lb->kp.strx;
@@ -1615,6 +1607,61 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
     KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
 				    lay, xlo, xhi, 0, -1, NULL, lb->stream));
     lb->blocked = (lay != 0);
+  }
+  else if (lb->xdim != X) {
+    /* A slab along Y or Z. Its boundary planes are not runs of x planes, so
+     * there is no interior launch that leaves them out: ONE launch over all
+     * x planes runs while the messages travel -- what it makes of the first
+     * and the last plane of the decomposed direction comes from halo planes
+     * nobody has filled and is overwritten -- and then the face launch does
+     * those two planes against the exchange buffers and fills the send
+     * buffers of the next exchange, whose messages leave right behind it
+     * (lbmi_k_propagate_collide_face). With fluctuations, or x_direct 0: the
+     * exchange into the halo planes first, then one launch. */
+    const int dim = lb->xdim;
+    const int direct = (lb->x_direct && h->noise == NULL);
+    const lbmi_xbuf_t xbuf = {lb->fx[2], lb->fx[3], lb->fx[0], lb->fx[1]};
+    const int pre = (direct && lb->xsend_valid);
+
+    if (lb->blocked) {
+      ifail = lbmi_unblock(lb);
+      if (ifail) return ifail;
+    }
+    lb->kp.nt_store = 0;
+    HIPCHECK(hipEventRecord(lb->ev_ready, lb->stream));
+    if (!direct) {
+      HIPCHECK(hipStreamWaitEvent(lb->comm_stream, lb->ev_ready, 0));
+      ifail = lbmi_x_exchange_buf(lb, &lb->sel_reduced[dim], lb->f, 0, 0,
+				  lb->fx, 0, 1, lb->comm_stream);
+      if (ifail) return ifail;
+      HIPCHECK(hipEventRecord(lb->ev_halo, lb->comm_stream));
+      HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_halo, 0));
+      KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
+				      0, xlo, xhi, 0, -1, NULL, lb->stream));
+    }
+    else {
+      KCHECK(lbmi_k_propagate_collide(&lb->kp, lb->f, lb->fprime, h, wrapmask,
+				      0, xlo, xhi, 0, -1, NULL, lb->stream));
+      if (!pre) {
+	HIPCHECK(hipStreamWaitEvent(lb->comm_stream, lb->ev_ready, 0));
+	ifail = lbmi_x_exchange_buf(lb, &lb->sel_reduced[dim], lb->f, 0, 0,
+				    lb->fx, 0, 0, lb->comm_stream);
+	if (ifail) return ifail;
+	HIPCHECK(hipEventRecord(lb->ev_halo, lb->comm_stream));
+      }
+      HIPCHECK(hipStreamWaitEvent(lb->stream, lb->ev_halo, 0));
+      KCHECK(lbmi_k_propagate_collide_face(&lb->kp, dim, lb->f, lb->fprime, h,
+					   wrapmask, &xbuf, lb->stream));
+      HIPCHECK(hipEventRecord(lb->ev_bnd, lb->stream));
+      /* the messages of the NEXT step, now */
+      HIPCHECK(hipStreamWaitEvent(lb->comm_stream, lb->ev_bnd, 0));
+      ifail = lbmi_x_exchange_buf(lb, &lb->sel_reduced[dim], lb->fprime, 0, 0,
+				  lb->fx, 1, 0, lb->comm_stream);
+      if (ifail) return ifail;
+      HIPCHECK(hipEventRecord(lb->ev_halo, lb->comm_stream));
+      xsend = 1;
+    }
+    lb->blocked = 0;
   }
   else {
     /* The interior planes need no x halo: enqueue them first so that the
@@ -2853,10 +2900,6 @@ int lbmi_lb_mode_set(lbmi_t * lb, int mode) {
   if (lb->opts.ndist == 2 && mode == LBMI_MODE_INPLACE) {
     return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = 2 needs LBMI_MODE_EAGER, LBMI_MODE_FUSED_HALO or LBMI_MODE_FUSED");
   }
-  if ((mode == LBMI_MODE_FUSED || mode == LBMI_MODE_INPLACE) && lb->xdim != X &&
-      (lb->opts.cartsz > 1 || lb->have_comm)) {
-    mode = LBMI_MODE_FUSED_HALO;     /* slabs along Y or Z: see lbmi_create */
-  }
   if (mode == lb->opts.mode) return 0;
   if (lb->f != NULL) {
     int ifail = lbmi_lb_flush(lb);
@@ -3934,7 +3977,6 @@ int lbmi_comm_init(lbmi_t * lb, const void * id) {
   lb->have_comm = 1;
 
   ifail = lbmi_comm_buffers(lb);
-  if (ifail == 0) ifail = lbmi_lb_mode_set(lb, lb->opts.mode);   /* Y/Z slabs: no FUSED */
   if (ifail) lbmi_comm_free(lb);
   return ifail;
 }
@@ -4005,7 +4047,6 @@ int lbmi_comm_init_ring(lbmi_t * lb, lbmi_ring_t * ring) {
   lb->ring = ring;
   lb->have_comm = 1;
   ifail = lbmi_comm_buffers(lb);
-  if (ifail == 0) ifail = lbmi_lb_mode_set(lb, lb->opts.mode);   /* Y/Z slabs: no FUSED */
   if (ifail) lbmi_comm_free(lb);
   return ifail;
 }

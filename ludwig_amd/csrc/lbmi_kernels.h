@@ -117,6 +117,15 @@ int lbmi_k_propagate_collide(const lbmi_kparam_t * kp, const double * f,
 int lbmi_k_propagate_collide_halo(const lbmi_kparam_t * kp, const double * f,
 				  double * fprime, const lbmi_hydro_dev_t * h,
 				  void * stream);
+/* The first and the last plane of a slab along dim = 1 (Y) or 2 (Z), after
+ * lbmi_k_propagate_collide has run over everything (its results in these two
+ * planes are overwritten): face-crossing populations from xb->recvlo / recvhi,
+ * the rest pulled from f (wrapmask: the two local directions), SoA -> SoA;
+ * fills xb->sendlo / sendhi for the next exchange. No fluctuations. */
+int lbmi_k_propagate_collide_face(const lbmi_kparam_t * kp, int dim,
+				  const double * f, double * fprime,
+				  const lbmi_hydro_dev_t * h, int wrapmask,
+				  const lbmi_xbuf_t * xb, void * stream);
 int lbmi_k_blocked_sites(const lbmi_kparam_t * kp);
 /* rho, u of the collision that left the post-collision state f (SoA, or the
  * blocked order): u = (sum f'_p c_p - F/2)/rho at interior fluid sites */

@@ -2479,6 +2479,113 @@ __device__ __forceinline__ int pull_offset(const lbmi_kparam_t & kp,
   return off;
 }
 
+/* ---- k_propagate_collide_face: the boundary planes of a slab along Y or Z ------------
+ *
+ * The FUSED step of such a slab (lbmi_fused_step): ONE launch of
+ * k_propagate_collide over all interior x planes while the messages travel --
+ * its results in the first and the last plane of the decomposed direction are
+ * made from halo planes nobody has filled and do not count -- then this
+ * kernel for those two planes: a thread per plane site, the populations that
+ * cross the face taken straight from the receive buffers ([k][plane site], k
+ * the rank of p among the populations with c_dim = +1 or -1, plane sites in
+ * the order of the two remaining coordinates), everything else pulled from f
+ * with the two local directions wrapped by index; it collides, overwrites
+ * what the big launch left at the site, and leaves the populations the NEXT
+ * exchange sends in the send buffers. The planes of Y and Z slabs are not
+ * contiguous (rows of nall[Z] values; single values nall[Z] apart): the
+ * accesses of this kernel are gathers, two planes' worth per step. */
+
+template <int NVEL, int DIM>
+__host__ __device__ constexpr int drank(int p, int c) {
+  int k = 0;
+  for (int q = 0; q < p; q++) {
+    if (Model<NVEL>::c(q, DIM) == c) k += 1;
+  }
+  return k;
+}
+
+template <int NVEL, int SCHEME, int DIM, bool HIO>
+__global__ __launch_bounds__(BLOCK)
+void k_propagate_collide_face(lbmi_kparam_t kp, const double * __restrict__ f,
+			      double * __restrict__ fp, lbmi_hydro_dev_t h,
+			      int wrapmask, lbmi_xbuf_t xb) {
+
+  using M = Model<NVEL>;
+  const int psz = plane_size(kp, DIM);
+  const int j = (int) (blockIdx.x*BLOCK + threadIdx.x);
+  if (j >= psz) return;
+  const int nh = kp.nhalo;
+  const int nd = kp.nlocal[DIM];
+  const int coord = (blockIdx.y == 0) ? nh : nh + nd - 1;
+  const bool atlo = (coord == nh), athi = (coord == nh + nd - 1);
+  const int i = (int) plane_site(kp, DIM, j, coord);
+  Site s = decode(kp, i);
+  if (!(s.interior && s.x >= nh && s.x < nh + kp.nlocal[0])) return;
+
+  const size_t ns = (size_t) kp.nsite;
+  const lbmi_xbuf_t none = {nullptr, nullptr, nullptr, nullptr};
+  const WrapAdj w = wrap_adjust(kp, s, wrapmask);      /* the two local directions */
+  const int c3[3] = {s.x, s.y, s.z};
+  PulledSite<NVEL> ps;
+  ps.s = s;
+
+  static_for<0, NVEL>([&](auto P) {
+    constexpr int p = P;
+    constexpr int cd = M::c(p, DIM);
+    bool buffered = false;
+    if constexpr (cd != 0) {
+      if ((cd == 1 && atlo) || (cd == -1 && athi)) {
+	/* the source lies in the neighbour's plane: entry of the receive
+	 * buffer at the source's two other coordinates (wrapped) */
+	int o[3];
+	static_for<0, 3>([&](auto D) {
+	  constexpr int d = D;
+	  int v = c3[d] - M::c(p, d);
+	  if (d != DIM) {
+	    if (v < nh) v += kp.nlocal[d];
+	    else if (v >= nh + kp.nlocal[d]) v -= kp.nlocal[d];
+	  }
+	  o[d] = v;
+	});
+	int jj;
+	if constexpr (DIM == 0) jj = o[1]*kp.nall[2] + o[2];
+	else if constexpr (DIM == 1) jj = o[0]*kp.nall[2] + o[2];
+	else jj = o[0]*kp.nall[1] + o[1];
+	if constexpr (cd == 1) {
+	  constexpr int k = drank<NVEL, DIM>(p, 1);
+	  ps.fl[p] = xb.recvlo[(size_t) k*psz + jj];
+	}
+	else {
+	  constexpr int k = drank<NVEL, DIM>(p, -1);
+	  ps.fl[p] = xb.recvhi[(size_t) k*psz + jj];
+	}
+	buffered = true;
+      }
+    }
+    if (!buffered) {
+      const int off = pull_offset<NVEL, p>(kp, w);
+      ps.fl[p] = f[ns*p + (i - off)];
+    }
+  });
+
+  pc_collide_store<NVEL, SCHEME, false, false, HIO, false>(kp, fp, h, i, ps, none);
+
+  /* what the next exchange sends: of the first plane the populations that
+   * leave downwards, of the last one those that leave upwards */
+  static_for<0, NVEL>([&](auto P) {
+    constexpr int p = P;
+    constexpr int cd = M::c(p, DIM);
+    if constexpr (cd == -1) {
+      constexpr int k = drank<NVEL, DIM>(p, -1);
+      if (atlo) xb.sendlo[(size_t) k*psz + j] = ps.fl[p];
+    }
+    if constexpr (cd == 1) {
+      constexpr int k = drank<NVEL, DIM>(p, 1);
+      if (athi) xb.sendhi[(size_t) k*psz + j] = ps.fl[p];
+    }
+  });
+}
+
 /* RB: f2 is in the blocked order of a deferred two-distribution state,
  * [site/256][n*NVEL + p][site%256] (faddr with 2 NVEL components) */
 template <int NVEL, bool PULL, bool RB = false>
@@ -3451,6 +3558,59 @@ static int launch_pc_halo(const lbmi_kparam_t & kp, const double * f, double * f
     return (int) hipErrorInvalidValue;
   }
   return (int) hipGetLastError();
+}
+
+static int host_plane_size(const lbmi_kparam_t * kp, int dir);
+
+template <int NVEL, int DIM, bool HIO>
+static int launch_pc_face(const lbmi_kparam_t & kp, const double * f, double * fp,
+			  const lbmi_hydro_dev_t & h, int wrapmask,
+			  const lbmi_xbuf_t & xb, hipStream_t st) {
+  const int psz = host_plane_size(&kp, DIM);
+  dim3 grid((unsigned) ((psz + BLOCK - 1)/BLOCK), (kp.nlocal[DIM] > 1) ? 2u : 1u), block(BLOCK);
+  switch (kp.scheme) {
+  case LBMI_M10:
+    hipLaunchKernelGGL((k_propagate_collide_face<NVEL, LBMI_M10, DIM, HIO>), grid, block, 0, st,
+		       kp, f, fp, h, wrapmask, xb);
+    break;
+  case LBMI_BGK:
+    hipLaunchKernelGGL((k_propagate_collide_face<NVEL, LBMI_BGK, DIM, HIO>), grid, block, 0, st,
+		       kp, f, fp, h, wrapmask, xb);
+    break;
+  case LBMI_TRT:
+    if constexpr (NVEL == 19) {
+      hipLaunchKernelGGL((k_propagate_collide_face<NVEL, LBMI_TRT, DIM, HIO>), grid, block, 0, st,
+			 kp, f, fp, h, wrapmask, xb);
+      break;
+    }
+    return (int) hipErrorInvalidValue;
+  default:
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_propagate_collide_face(const lbmi_kparam_t * kp, int dim,
+					     const double * f, double * fprime,
+					     const lbmi_hydro_dev_t * h,
+					     int wrapmask, const lbmi_xbuf_t * xb,
+					     void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  const bool hio = (h->force != nullptr || h->rho != nullptr || h->u != nullptr);
+  if (h->noise != nullptr || xb == nullptr || (dim != 1 && dim != 2)) return (int) hipErrorInvalidValue;
+  if (kp->nvel == 19) {
+    if (dim == 1) return hio ? launch_pc_face<19, 1, true>(*kp, f, fprime, *h, wrapmask, *xb, st)
+      : launch_pc_face<19, 1, false>(*kp, f, fprime, *h, wrapmask, *xb, st);
+    return hio ? launch_pc_face<19, 2, true>(*kp, f, fprime, *h, wrapmask, *xb, st)
+      : launch_pc_face<19, 2, false>(*kp, f, fprime, *h, wrapmask, *xb, st);
+  }
+  if (kp->nvel == 27) {
+    if (dim == 1) return hio ? launch_pc_face<27, 1, true>(*kp, f, fprime, *h, wrapmask, *xb, st)
+      : launch_pc_face<27, 1, false>(*kp, f, fprime, *h, wrapmask, *xb, st);
+    return hio ? launch_pc_face<27, 2, true>(*kp, f, fprime, *h, wrapmask, *xb, st)
+      : launch_pc_face<27, 2, false>(*kp, f, fprime, *h, wrapmask, *xb, st);
+  }
+  return (int) hipErrorInvalidValue;
 }
 
 extern "C" int lbmi_k_propagate_collide_halo(const lbmi_kparam_t * kp,

@@ -298,8 +298,11 @@ def _fuzz(mode, seed, tmp_path, ring):
             script.append(("tune", "halo_fold", int(rng.integers(0, 2))))
 
     def play(run_mode):
+        # (the self-ring along X, Y or Z: slabs of any direction run the same
+        # scripts; Y and Z: gathered planes, the face launch of the fused step)
         lb = ludwig_amd.LB(nvel, nlocal, 1, mode=run_mode,
-                           halo_scheme=2 if ring else 0)
+                           halo_scheme=2 if ring else 0,
+                           cartdim=(seed % 3) if ring else 0)
         if ring:
             lb.comm_init(ludwig_amd.LB.comm_unique_id())
         lb.relaxation_set("m10", 0.1, 0.3)

@@ -155,12 +155,15 @@ def test_rho_u_on_demand_equal_stored_256():
     assert np.array_equal(res[0][2], res[1][2])
 
 
-def test_two_slabs_through_the_ring_equal_one_domain_256():
+@pytest.mark.parametrize("dim", [0, 2], ids=["x_slabs", "z_slabs"])
+def test_two_slabs_through_the_ring_equal_one_domain_256(dim):
     """BASELINE config 3 in the small: the 256^3 box as two slabs of 128 planes
-    (two ranks of the in-process ring on this one GPU: interior launch,
-    boundary launch against the exchange buffers, messages a step ahead) =
-    the single-GPU run after 4 steps, bit for bit (same arithmetic per site;
-    only where the neighbours' populations come from differs)."""
+    (two ranks of the peer ring on this one GPU) = the single-GPU run after 4
+    steps, bit for bit (same arithmetic per site; only where the neighbours'
+    populations come from differs). X slabs: interior launch, boundary launch
+    against the exchange buffers, messages a step ahead. Z slabs (the
+    configuration as BASELINE.json words it): one launch over all planes
+    beside the messages, then the face launch for the two gathered planes."""
     import threading
 
     import ludwig_amd
@@ -169,6 +172,7 @@ def test_two_slabs_through_the_ring_equal_one_domain_256():
     nsteps, world = 4, 2
     lb = _setup(ludwig_amd.FUSED)
     hy = ludwig_amd.Hydro(lb.nall, lb.device, with_rho_u=False)
+    f0 = lb.lb_memcpy_d2h() if dim != 0 else None     # the start, for the z slabs
     lb.run(hy, nsteps)
     ref = lb.lb_memcpy_d2h()[:, 1:-1, 1:-1, 1:-1].copy()
     mref = lb.moments()
@@ -184,14 +188,19 @@ def test_two_slabs_through_the_ring_equal_one_domain_256():
 
     def rank_main(rank):
         try:
-            dec = ludwig_amd.SlabDecomposition((N, N, N), world, rank, 1)
+            dec = ludwig_amd.SlabDecomposition((N, N, N), world, rank, 1, dim=dim)
             lbr = ludwig_amd.LB(NVEL, dec.nlocal, 1, mode=ludwig_amd.FUSED, cartsz=world,
-                                cartrank=rank, own_stream=True,
+                                cartrank=rank, own_stream=True, cartdim=dim,
                                 halo_scheme=ludwig_amd.HALO_REDUCED)
             lbr.relaxation_set("m10", 0.1, 0.3)
             lbr.comm_init_ring(ring)
-            synthetic.fill_device(lbr, m["cv"], m["wv"], (N, N, N),
-                                  xrange=(dec.noffset[0], dec.noffset[0] + dec.nlocal[0]))
+            if dim == 0:
+                synthetic.fill_device(lbr, m["cv"], m["wv"], (N, N, N),
+                                      xrange=(dec.noffset[0], dec.noffset[0] + dec.nlocal[0]))
+            else:
+                sl = [slice(None)] * 4
+                sl[1 + dim] = slice(dec.noffset[dim], dec.noffset[dim] + dec.nlocal[dim] + 2)
+                lbr.lb_memcpy_h2d(np.ascontiguousarray(f0[tuple(sl)]))
             torch.cuda.synchronize()
             hyr = ludwig_amd.Hydro(lbr.nall, lbr.device, with_rho_u=False)
             bar.wait()
@@ -212,7 +221,7 @@ def test_two_slabs_through_the_ring_equal_one_domain_256():
         t.join(timeout=600)
     assert not err, err
     ring.free()
-    got = np.concatenate([out[0][0], out[1][0]], axis=1)
+    got = np.concatenate([out[0][0], out[1][0]], axis=1 + dim)
     assert np.array_equal(got, ref)
     assert abs(out[0][1][1] + out[1][1][1] - mref[1]) / mref[1] < 1e-14
 

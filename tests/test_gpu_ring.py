@@ -377,25 +377,31 @@ def test_bench_peer_transport_line(world):
     assert d["check"]["mass_drift_rel"] < 1e-12
 
 
-@pytest.mark.parametrize("mode", ["eager", "fused_halo", "fused"])
-@pytest.mark.parametrize("world,nvel,dim", [(2, 19, 2), (3, 19, 2), (2, 27, 2), (3, 19, 1), (2, 27, 1)])
+@pytest.mark.parametrize("mode", ["eager", "fused_halo", "fused", "fused_unpack", "fused_lazy"])
+@pytest.mark.parametrize("world,nvel,dim", [(2, 19, 2), (3, 19, 2), (2, 27, 2), (3, 19, 1), (2, 27, 1),
+                                            (4, 19, 2)])
 def test_slabs_along_y_or_z_equal_single_domain(world, nvel, dim, mode):
     """grid 1_1_N (BASELINE config 3 as written: z slabs) and 1_N_1: the
     planes of the decomposed direction are gathered into the message buffers
     and scattered into the halo (k_halo_pack_x / k_halo_unpack_x with a
     direction), the two other passes stay local, in the order X, Y, Z. FUSED
-    on such slabs runs as FUSED_HALO (the exchange where lb_halo is called,
-    only the propagation deferred). With a force field, rho and u checked."""
+    on such slabs: one launch over all planes beside the messages, then the
+    face launch for the two boundary planes against the exchange buffers
+    (k_propagate_collide_face), the next step's messages right behind it.
+    With a force field, rho and u checked."""
     import ludwig_amd
     modes = {"eager": ludwig_amd.EAGER, "fused_halo": ludwig_amd.FUSED_HALO,
-             "fused": ludwig_amd.FUSED}
+             "fused": ludwig_amd.FUSED, "fused_unpack": ludwig_amd.FUSED,
+             "fused_lazy": ludwig_amd.FUSED}
     ntotal = [10, 6, 14]
-    ntotal[dim] = 12
+    ntotal[dim] = 12                 # slabs of 6, 4, 3 planes (4 ranks: 3)
     ntotal = tuple(ntotal)
-    nsteps = 4
+    nsteps = 5
     rng = np.random.default_rng(11)
     force = 1e-6 * rng.standard_normal((3,) + tuple(n + 2 for n in ntotal))
-    out = _run_ring(world, nvel, ntotal, nsteps, modes[mode], force=force, dim=dim)
+    out = _run_ring(world, nvel, ntotal, nsteps, modes[mode], force=force, dim=dim,
+                    tune=(("x_direct", 0),) if mode == "fused_unpack" else (),
+                    lazy=(mode == "fused_lazy"))
     p, f, rho, u = _oracle(nvel, ntotal, nsteps, force=force)
     assert relmax(_join(out, 0, dim), interior(f, 1)) < 1e-12
     assert relmax(_join(out, 1, dim), interior(rho, 1)) < 1e-12
