@@ -141,10 +141,14 @@ typedef struct lbmi_options_s {
 			       step overlaps their exchange with the interior
 			       launch), 1 = Y, 2 = Z (grid 1_N_1 / 1_1_N,
 			       coords_rt.c:46-47: planes are gathered and
-			       scattered, halo_swap.c:1074-1274; the fused
+			       scattered, halo_swap.c:1074-1274. Y: the fused
 			       step overlaps the exchange with ONE launch over
 			       all planes and redoes the two boundary planes
-			       against the exchange buffers afterwards)      */
+			       against the exchange buffers afterwards. Z: a
+			       plane is one value out of every row, FUSED runs
+			       as FUSED_HALO -- the exchange where lb_halo is
+			       called, the propagation folded into the next
+			       collision: measured faster)                   */
   int reserved[6];          /* must be zero                                  */
 } lbmi_options_t;
 

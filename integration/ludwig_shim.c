@@ -485,8 +485,8 @@ static lbmi_t * shim_handle(lb_t * lb) {
       if (rank == 0) SHIM_CHECK(lb, lbmi_comm_unique_id(id));
       MPI_Bcast(id, LBMI_UNIQUE_ID_BYTES, MPI_BYTE, 0, comm);
       SHIM_CHECK(lb, lbmi_comm_init(shim_.h, id));
-      if (slabdim != X && shim_.mode == LBMI_MODE_FUSED) {
-	/* slabs along Y or Z: the library runs fused as halo (lbmi_create) */
+      if (slabdim == Z && shim_.mode == LBMI_MODE_FUSED) {
+	/* slabs along Z: the library runs fused as halo (lbmi_create) */
 	shim_.mode = LBMI_MODE_FUSED_HALO;
       }
     }

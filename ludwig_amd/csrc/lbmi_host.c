@@ -329,6 +329,18 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
 
   lb->opts = *opts;
   lb->xdim = opts->cartdim;
+  if (opts->cartsz > 1 && opts->cartdim == Z &&
+      (opts->mode == LBMI_MODE_FUSED || opts->mode == LBMI_MODE_INPLACE)) {
+    /* Slabs along Z: a boundary plane is one value out of every row of the
+     * array, and a launch that redoes those two planes against the exchange
+     * buffers (what Y slabs do, lbmi_fused_step) costs more in 64-byte
+     * sectors touched for 8 bytes than the overlap buys: measured on a
+     * 256 x 256 x 32 slab 0.273 ms per step against 0.195 ms with the exchange
+     * where lb_halo is called and the propagation alone folded into the next
+     * collision (profiles/r03_slab_directions.txt). So that is what FUSED
+     * means on Z slabs. */
+    lb->opts.mode = LBMI_MODE_FUSED_HALO;
+  }
   if (opts->device >= 0) {
     if (opts->device >= ndevice) {
       free(lb);
@@ -1609,7 +1621,8 @@ static int lbmi_fused_step(lbmi_t * lb, const lbmi_hydro_dev_t * h) {
     lb->blocked = (lay != 0);
   }
   else if (lb->xdim != X) {
-    /* A slab along Y or Z. Its boundary planes are not runs of x planes, so
+    /* A slab along Y (Z slabs never get here: lbmi_create; the code serves
+     * either). Its boundary planes are not runs of x planes, so
      * there is no interior launch that leaves them out: ONE launch over all
      * x planes runs while the messages travel -- what it makes of the first
      * and the last plane of the decomposed direction comes from halo planes
@@ -2900,6 +2913,10 @@ int lbmi_lb_mode_set(lbmi_t * lb, int mode) {
   if (lb->opts.ndist == 2 && mode == LBMI_MODE_INPLACE) {
     return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = 2 needs LBMI_MODE_EAGER, LBMI_MODE_FUSED_HALO or LBMI_MODE_FUSED");
   }
+  if ((mode == LBMI_MODE_FUSED || mode == LBMI_MODE_INPLACE) && lb->xdim == Z &&
+      (lb->opts.cartsz > 1 || lb->have_comm)) {
+    mode = LBMI_MODE_FUSED_HALO;     /* slabs along Z: see lbmi_create */
+  }
   if (mode == lb->opts.mode) return 0;
   if (lb->f != NULL) {
     int ifail = lbmi_lb_flush(lb);
@@ -3977,6 +3994,7 @@ int lbmi_comm_init(lbmi_t * lb, const void * id) {
   lb->have_comm = 1;
 
   ifail = lbmi_comm_buffers(lb);
+  if (ifail == 0) ifail = lbmi_lb_mode_set(lb, lb->opts.mode);   /* Z slabs: no FUSED */
   if (ifail) lbmi_comm_free(lb);
   return ifail;
 }
@@ -4047,6 +4065,7 @@ int lbmi_comm_init_ring(lbmi_t * lb, lbmi_ring_t * ring) {
   lb->ring = ring;
   lb->have_comm = 1;
   ifail = lbmi_comm_buffers(lb);
+  if (ifail == 0) ifail = lbmi_lb_mode_set(lb, lb->opts.mode);   /* Z slabs: no FUSED */
   if (ifail) lbmi_comm_free(lb);
   return ifail;
 }
