@@ -650,7 +650,20 @@ int lbmi_lb_io_write(lbmi_t * lb, const char * dir, int timestep,
  * model.c:1438-1490): per site nvel lines, line p = the ndist values f(n, p)
  * as " %22.15e", and metadata that says MPI_CHAR x nvel*(ndist*23 + 1). The
  * records are still packed on the device; the text is made on the host. */
-int lbmi_io_format_set(lbmi_t * lb, int ascii);
+int lbmi_io_format_set(lbmi_t * lb, int fmt);
+/* fmt: 0, LBMI_IO_ASCII, or LBMI_IO_SINGLE = the old-style i/o a run gets
+ * when its input names no i/o mode (io_options_default(): IO_MODE_SINGLE;
+ * lb_io_write, model.c:1583-1587 -> io_write_data_s, io_harness.c; the
+ * io_info_t path). Binary records only, the same record stream in
+ *   <dir>/dist-%8.8d.001-001 (timestep)
+ * with metadata that says "single", and the text file the old style keeps,
+ *   <dir>/dist.001-001.meta   (io_write_metadata_file, io_harness.c:369-466),
+ * written by the rank at offset_x == 0 with one line per rank, the slabs cut
+ * as cs_init cuts them (coords.c:577-592). lb_io_read of that mode seeks to
+ * the global position of every row (io_file_offset, single_file_read): the
+ * same byte range per X slab. Text records in this mode have no fixed size in
+ * the reference and are refused (LBMI_ERR_UNSUPPORTED). */
+enum {LBMI_IO_ASCII = 1, LBMI_IO_SINGLE = 2};
 int lbmi_lb_io_read(lbmi_t * lb, const char * dir, int timestep,
 		    int ntotal_x, int offset_x);
 
@@ -659,12 +672,19 @@ int lbmi_lb_io_read(lbmi_t * lb, const char * dir, int timestep,
  * name of a time step (io_subfile_name, io_subfile.c). */
 int lbmi_io_metadata_write(const char * dir, const char * stub, int nel,
 			   const int ntotal[3]);
-/* the same for records of ndist*nvel values in either format (ascii != 0:
- * text records) */
+/* the same for records of ndist*nvel values in any format (fmt as for
+ * lbmi_io_format_set) */
 int lbmi_io_metadata_write_fmt(const char * dir, const char * stub, int nvel,
-			       int ndist, const int ntotal[3], int ascii);
+			       int ndist, const int ntotal[3], int fmt);
 int lbmi_io_filename(const char * dir, const char * stub, int timestep,
 		     char * buf, size_t bufsz);
+int lbmi_io_filename_fmt(const char * dir, const char * stub, int timestep,
+			 int fmt, char * buf, size_t bufsz);
+/* <dir>/<stub>.001-001.meta of the single mode: cartsz slabs along cartdim,
+ * nslab[r] planes in slab r (NULL for one rank) */
+int lbmi_io_single_metadata_write(const char * dir, const char * stub, int nvel,
+				  int ndist, const int ntotal[3], int cartdim,
+				  int cartsz, const int * nslab);
 
 /* ---- streams / synchronisation ----------------------------------------- */
 

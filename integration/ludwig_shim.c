@@ -1062,51 +1062,89 @@ int lb_memcpy(lb_t * lb, tdpMemcpyKind flag) {
  *  writes through MPI-IO. In its MPI-IO mode with one file (i/o grid 1_1_1)
  *  and binary records, an X slab is one contiguous byte range of that file:
  *  the records are packed on the device and written from there, the files
- *  are the same byte for byte. Anything else (old-style i/o, several files,
- *  the legacy io_info_t path) goes to the original. Text records
- *  (distribution_io_format ascii) are the library's as well: packed on the
- *  device, formatted on the host as lb_write_buf_ascii formats them.
+ *  are the same byte for byte. Text records (distribution_io_format ascii)
+ *  are the library's as well: packed on the device, formatted on the host as
+ *  lb_write_buf_ascii formats them. So is the old-style i/o of a run whose
+ *  input names no i/o mode (io_harness.c, through lb->io_info) while it keeps
+ *  one file of binary records: the same record stream under the old name
+ *  with the old text metadata beside it. Anything else (several files, the
+ *  old text records) goes to the original.
  *
  *****************************************************************************/
 
-static int shim_io_supported(lb_t * lb, const io_metadata_t * meta) {
+/* Returns 0 (the original does it), or 1 + the format for lbmi_io_format_set */
+
+static int shim_io_supported(lb_t * lb, const io_metadata_t * meta, int reading) {
   int dim = X;
+  int fmt = 0;
   if (!shim_supported(lb)) return 0;
   /* (a slab along Y or Z is not one byte range of the file) */
   if (!shim_slab_dim(lb, &dim) || dim != X) return 0;
-  if (meta->options.mode != IO_MODE_MPIIO) return 0;
-  if (meta->options.iorformat != IO_RECORD_BINARY &&
-      meta->options.iorformat != IO_RECORD_ASCII) return 0;
   if (meta->options.iogrid[X] != 1 || meta->options.iogrid[Y] != 1 ||
       meta->options.iogrid[Z] != 1) return 0;
-  return 1;
+  if (meta->options.mode == IO_MODE_MPIIO) {
+    if (meta->options.iorformat == IO_RECORD_ASCII) fmt = LBMI_IO_ASCII;
+    else if (meta->options.iorformat != IO_RECORD_BINARY) return 0;
+    return 1 + fmt;
+  }
+  /* Old-style (model.c:1583-1587, 1629-1633): what lb_io_info_set installed
+   * decides, not the metadata. One file of binary records, read by global
+   * position: the same record stream under the old name. */
+  {
+    const io_info_t * info = lb->io_info;
+    if (info == NULL || info->io_comm == NULL) return 0;
+    if (info->io_comm->n_io != 1) return 0;
+    if (reading) {
+      if (info->read_data == NULL || info->read_data != info->read_binary) return 0;
+      if (!info->single_file_read || !info->processor_independent) return 0;
+    }
+    else {
+      if (info->write_data == NULL || info->write_data != info->write_binary) return 0;
+      if (info->args.output.mode == IO_MODE_MULTIPLE) return 0;
+      if (info->args.output.report) return 0;          /* its own timing line */
+      if (info->bytesize != sizeof(double)*(size_t) lb->nvel*lb->ndist) return 0;
+      if (strcmp(info->metadata_stub, "dist") != 0) return 0;
+    }
+  }
+  return 1 + LBMI_IO_SINGLE;
 }
 
 int lb_io_write(lb_t * lb, int timestep, io_event_t * event) {
 
+  int fmt = 0;
+
   assert(lb);
   assert(event);
 
-  if (!shim_io_supported(lb, &lb->output)) {
+  fmt = shim_io_supported(lb, &lb->output, 0);
+  if (fmt == 0) {
     return lb_io_write_ref(lb, timestep, event);   /* via lb_memcpy: flushes */
   }
+  fmt -= 1;
 
   {
     int ntotal[3], noffset[3];
     cs_ntotal(lb->cs, ntotal);
     cs_nlocal_offset(lb->cs, noffset);
-    io_event_record(event, IO_EVENT_AGGR);
-    io_event_record(event, IO_EVENT_WRITE);
-    /* the metadata file (rank at offset 0) and this rank's byte range */
+    if (!(fmt & LBMI_IO_SINGLE)) {
+      io_event_record(event, IO_EVENT_AGGR);
+      io_event_record(event, IO_EVENT_WRITE);
+    }
+    /* the metadata file(s) (rank at offset 0) and this rank's byte range */
     shim_note(S_LB_IO_WRITE, 1);
-    /* binary records, or distribution_io_format ascii (model.c:1438-1462) */
-    SHIM_CHECK(lb, lbmi_io_format_set(shim_handle(lb),
-				      lb->output.options.iorformat == IO_RECORD_ASCII));
+    /* binary records, distribution_io_format ascii (model.c:1438-1462), or
+     * the old-style files */
+    SHIM_CHECK(lb, lbmi_io_format_set(shim_handle(lb), fmt));
     SHIM_CHECK(lb, lbmi_lb_io_write(shim_handle(lb), ".", timestep, ntotal[X],
 				    noffset[X]));
     shim_sync_pointers(lb, shim_.h);                /* a flush may have swapped */
     lb->output.iswriten = 1;
-    io_event_report(event, &lb->output, "dist");
+    if (fmt & LBMI_IO_SINGLE) {
+      lb->io_info->metadata_written = 1;
+    }
+    else {
+      io_event_report(event, &lb->output, "dist");
+    }
   }
 
   return 0;
@@ -1114,10 +1152,13 @@ int lb_io_write(lb_t * lb, int timestep, io_event_t * event) {
 
 int lb_io_read(lb_t * lb, int timestep, io_event_t * event) {
 
+  int fmt = 0;
+
   assert(lb);
   assert(event);
 
-  if (!shim_io_supported(lb, &lb->input)) {
+  fmt = shim_io_supported(lb, &lb->input, 1);
+  if (fmt == 0) {
     if (shim_.h && shim_.lb == lb) {
       /* the original fills the HOST copy; nothing deferred may survive it */
       SHIM_CHECK(lb, lbmi_lb_flush(shim_.h));
@@ -1125,14 +1166,14 @@ int lb_io_read(lb_t * lb, int timestep, io_event_t * event) {
     }
     return lb_io_read_ref(lb, timestep, event);
   }
+  fmt -= 1;
 
   {
     int ntotal[3], noffset[3];
     cs_ntotal(lb->cs, ntotal);
     cs_nlocal_offset(lb->cs, noffset);
     shim_note(S_LB_IO_READ, 1);
-    SHIM_CHECK(lb, lbmi_io_format_set(shim_handle(lb),
-				      lb->input.options.iorformat == IO_RECORD_ASCII));
+    SHIM_CHECK(lb, lbmi_io_format_set(shim_handle(lb), fmt));
     SHIM_CHECK(lb, lbmi_lb_io_read(shim_handle(lb), ".", timestep, ntotal[X],
 				   noffset[X]));
     shim_sync_pointers(lb, shim_.h);

@@ -3613,14 +3613,26 @@ int lbmi_lb_records_unpack(lbmi_t * lb, const double * records) {
  *
  *****************************************************************************/
 
-int lbmi_io_filename(const char * dir, const char * stub, int timestep,
-		     char * buf, size_t bufsz) {
+int lbmi_io_filename_fmt(const char * dir, const char * stub, int timestep,
+			 int fmt, char * buf, size_t bufsz) {
   int n;
   if (dir == NULL || stub == NULL || buf == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
-  /* io_subfile_name: "%s-%9.9d.%3.3d-%3.3d", file index 1 of 1 */
-  n = snprintf(buf, bufsz, "%s/%s-%9.9d.%3.3d-%3.3d", dir, stub, timestep, 1, 1);
+  if (fmt & LBMI_IO_SINGLE) {
+    /* lb_io_write, model.c:1583-1587: "dist-%8.8d", then io_write_data_s
+     * (io_harness.c): "%s.%3.3d-%3.3d" with 1, 1 */
+    n = snprintf(buf, bufsz, "%s/%s-%8.8d.%3.3d-%3.3d", dir, stub, timestep, 1, 1);
+  }
+  else {
+    /* io_subfile_name: "%s-%9.9d.%3.3d-%3.3d", file index 1 of 1 */
+    n = snprintf(buf, bufsz, "%s/%s-%9.9d.%3.3d-%3.3d", dir, stub, timestep, 1, 1);
+  }
   if (n < 0 || (size_t) n >= bufsz) return lbmi_fail(LBMI_ERR_ARGUMENT, "file name too long");
   return 0;
+}
+
+int lbmi_io_filename(const char * dir, const char * stub, int timestep,
+		     char * buf, size_t bufsz) {
+  return lbmi_io_filename_fmt(dir, stub, timestep, 0, buf, bufsz);
 }
 
 /* Text records (io_options_t::iorformat == IO_RECORD_ASCII, the input key
@@ -3640,8 +3652,10 @@ int lbmi_io_metadata_write(const char * dir, const char * stub, int nel,
 }
 
 int lbmi_io_metadata_write_fmt(const char * dir, const char * stub, int nvel,
-			       int ndist, const int ntotal[3], int ascii) {
+			       int ndist, const int ntotal[3], int fmt) {
   const int nel = nvel*ndist;
+  const int ascii = (fmt & LBMI_IO_ASCII);
+  const int single = (fmt & LBMI_IO_SINGLE);
   char fn[1024];
   FILE * fp = NULL;
   int n;
@@ -3667,10 +3681,12 @@ int lbmi_io_metadata_write_fmt(const char * dir, const char * stub, int nvel,
   fprintf(fp, "\t\t}\n");
   fprintf(fp, "\t},\n");
   fprintf(fp, "\t\"io_options\":\t{\n");
-  fprintf(fp, "\t\t\"Mode\":\t\"mpiio\",\n");
+  /* io_options_with_mode(IO_MODE_MPIIO), or io_options_default() = the
+   * single mode (io_options.c:27-45, 198-222) */
+  fprintf(fp, "\t\t\"Mode\":\t\"%s\",\n", single ? "single" : "mpiio");
   fprintf(fp, "\t\t\"Record format\":\t\"%s\",\n", ascii ? "ascii" : "binary");
-  fprintf(fp, "\t\t\"Metadata version\":\t3,\n");
-  fprintf(fp, "\t\t\"Report\":\ttrue,\n");
+  fprintf(fp, "\t\t\"Metadata version\":\t%d,\n", single ? 1 : 3);
+  fprintf(fp, "\t\t\"Report\":\t%s,\n", single ? "false" : "true");
   fprintf(fp, "\t\t\"Asynchronous\":\tfalse,\n");
   fprintf(fp, "\t\t\"Compression level\":\t0,\n");
   fprintf(fp, "\t\t\"I/O grid\":\t[1, 1, 1]\n");
@@ -3702,6 +3718,72 @@ int lbmi_io_metadata_write_fmt(const char * dir, const char * stub, int nvel,
   fprintf(fp, "}");
   if (fclose(fp) != 0) return lbmi_fail(LBMI_ERR_ARGUMENT, "%s: %s", fn, strerror(errno));
   return 0;
+}
+
+/* The text file the old-style i/o keeps beside its data (io_write_metadata_file,
+ * io_harness.c:369-466): a stub and one line per rank of the i/o group in
+ * rank order. Slabs along cartdim: rank r has Cartesian coordinate r in that
+ * direction, nslab[r] planes. */
+
+int lbmi_io_single_metadata_write(const char * dir, const char * stub, int nvel,
+				  int ndist, const int ntotal[3], int cartdim,
+				  int cartsz, const int * nslab) {
+  char fn[1024];
+  FILE * fp = NULL;
+  int n, off = 0;
+  if (dir == NULL || stub == NULL || ntotal == NULL || nvel < 1 || ndist < 1 ||
+      cartdim < X || cartdim > Z || cartsz < 1 || (cartsz > 1 && nslab == NULL)) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_io_single_metadata_write: bad argument");
+  }
+  for (int r = 0; r < cartsz && cartsz > 1; r++) off += nslab[r];
+  if (cartsz > 1 && off != ntotal[cartdim]) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "slabs of %d planes in all, %d sites",
+		     off, ntotal[cartdim]);
+  }
+  n = snprintf(fn, sizeof(fn), "%s/%s.%3.3d-%3.3d.meta", dir, stub, 1, 1);
+  if (n < 0 || (size_t) n >= sizeof(fn)) return lbmi_fail(LBMI_ERR_ARGUMENT, "file name too long");
+  fp = fopen(fn, "w");
+  if (fp == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "%s: %s", fn, strerror(errno));
+  {
+    int sz[3] = {1, 1, 1};
+    sz[cartdim] = cartsz;
+    fprintf(fp, "Metadata for file set prefix:    %s\n", stub);
+    /* lb_io_info_set, model.c:457 */
+    fprintf(fp, "Data description:                %1d x Distribution: d3q%d\n", ndist, nvel);
+    fprintf(fp, "Data size per site (bytes):      %d\n", (int) sizeof(double)*nvel*ndist);
+    fprintf(fp, "is_bigendian():                  %d\n", 0);
+    fprintf(fp, "Number of processors:            %d\n", cartsz);
+    fprintf(fp, "Cartesian communicator topology: %d %d %d\n", sz[X], sz[Y], sz[Z]);
+    fprintf(fp, "Total system size:               %d %d %d\n", ntotal[X], ntotal[Y], ntotal[Z]);
+    fprintf(fp, "Lees-Edwards planes:             %d\n", 0);
+    fprintf(fp, "Lees-Edwards plane speed         %16.14f\n", 0.0);
+    fprintf(fp, "Number of I/O groups (files):    %d\n", 1);
+    fprintf(fp, "I/O communicator topology:       %d %d %d\n", 1, 1, 1);
+    fprintf(fp, "Write order:\n");
+  }
+  off = 0;
+  for (int r = 0; r < cartsz; r++) {
+    int coords[3] = {0, 0, 0};
+    int nlocal[3] = {ntotal[X], ntotal[Y], ntotal[Z]};
+    int noff[3] = {0, 0, 0};
+    coords[cartdim] = r;
+    if (cartsz > 1) nlocal[cartdim] = nslab[r];
+    noff[cartdim] = off;
+    off += nlocal[cartdim];
+    fprintf(fp, "%3d %3d %3d %3d %d %d %d %d %d %d\n", r, coords[X], coords[Y], coords[Z],
+	    nlocal[X], nlocal[Y], nlocal[Z], noff[X], noff[Y], noff[Z]);
+  }
+  if (fclose(fp) != 0) return lbmi_fail(LBMI_ERR_ARGUMENT, "%s: %s", fn, strerror(errno));
+  return 0;
+}
+
+/* How cs_init cuts ntotal sites into sz parts (coords.c:577-592): the
+ * quotient each, and one more for the parts 1 + n*(sz/nremainder) */
+
+static void lbmi_cs_parts(int ntotal, int sz, int * nslab) {
+  const int nrem = ntotal % sz;
+  for (int r = 0; r < sz; r++) nslab[r] = ntotal/sz;
+  for (int n = 0; n < nrem; n++) nslab[1 + n*(sz/nrem)] += 1;
 }
 
 /* records <-> file through a pinned staging buffer; dev = fprime */
@@ -3758,7 +3840,7 @@ static int lbmi_io_transfer(lbmi_t * lb, const char * fn, int writing,
 			    double * dev, size_t nbytes, off_t offset) {
   void * stage = NULL;
   char * text = NULL;
-  const int ascii = lb->io_ascii;
+  const int ascii = (lb->io_ascii & LBMI_IO_ASCII);
   const size_t recb = sizeof(double)*(size_t) lb->kp.nvel*(size_t) lb->opts.ndist;
   const size_t rect = lbmi_ascii_record(lb->kp.nvel, lb->opts.ndist);
   const size_t chunk = (LBMI_IO_CHUNK/recb)*recb;       /* whole records */
@@ -3855,9 +3937,19 @@ static int lbmi_io_args(lbmi_t * lb, const char * dir, int ntotal_x,
   return 0;
 }
 
-int lbmi_io_format_set(lbmi_t * lb, int ascii) {
+int lbmi_io_format_set(lbmi_t * lb, int fmt) {
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
-  lb->io_ascii = (ascii != 0);
+  if (fmt < 0 || fmt > (LBMI_IO_ASCII | LBMI_IO_SINGLE)) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_io_format_set: %d", fmt);
+  }
+  if (fmt == (LBMI_IO_ASCII | LBMI_IO_SINGLE)) {
+    /* lb_f_write_ascii (model.c:1341-1383) writes "%d %d %d " and "%le " items
+     * of no fixed width, and lb_io_info_set gives the text record no size, so
+     * io_write_data_s buffers nothing: there is no file of the reference to
+     * be equal to */
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "text records in the single mode");
+  }
+  lb->io_ascii = fmt;
   return 0;
 }
 
@@ -3875,8 +3967,25 @@ int lbmi_lb_io_write(lbmi_t * lb, const char * dir, int timestep,
     ifail = lbmi_io_metadata_write_fmt(dir, "dist", lb->kp.nvel, lb->opts.ndist,
 				       ntotal, lb->io_ascii);
     if (ifail) return ifail;
+    if (lb->io_ascii & LBMI_IO_SINGLE) {
+      /* io_write_data_s -> io_write_metadata; the lines of the other ranks
+       * by the rule cs_init cut the lattice with, which this rank's own
+       * planes have to agree with */
+      int nslab[LBMI_RING_MAX];
+      const int sz = lb->opts.cartsz;
+      if (sz > LBMI_RING_MAX) return lbmi_fail(LBMI_ERR_UNSUPPORTED, "%d ranks", sz);
+      lbmi_cs_parts(ntotal_x, sz, nslab);
+      if (nslab[0] != lb->kp.nlocal[X]) {
+	return lbmi_fail(LBMI_ERR_UNSUPPORTED, "slabs not cut as cs_init cuts them: "
+			 "write %s.001-001.meta with lbmi_io_single_metadata_write",
+			 "dist");
+      }
+      ifail = lbmi_io_single_metadata_write(dir, "dist", lb->kp.nvel, lb->opts.ndist,
+					    ntotal, X, sz, nslab);
+      if (ifail) return ifail;
+    }
   }
-  ifail = lbmi_io_filename(dir, "dist", timestep, fn, sizeof(fn));
+  ifail = lbmi_io_filename_fmt(dir, "dist", timestep, lb->io_ascii, fn, sizeof(fn));
   if (ifail) return ifail;
   /* fprime is dead between steps once nothing is pending: pack there */
   KCHECK(lbmi_k_records(&lb->kp, lb->opts.ndist, lb->f, lb->fprime, 1, lb->stream));
@@ -3893,7 +4002,7 @@ int lbmi_lb_io_read(lbmi_t * lb, const char * dir, int timestep,
   int ifail = lbmi_io_args(lb, dir, ntotal_x, offset_x);
   if (ifail) return ifail;
   HIPCHECK(hipSetDevice(lb->device));
-  ifail = lbmi_io_filename(dir, "dist", timestep, fn, sizeof(fn));
+  ifail = lbmi_io_filename_fmt(dir, "dist", timestep, lb->io_ascii, fn, sizeof(fn));
   if (ifail) return ifail;
   plane = sizeof(double)*(size_t) lb->kp.nvel*lb->opts.ndist*lb->kp.nlocal[Y]*lb->kp.nlocal[Z];
   nbytes = plane*(size_t) lb->kp.nlocal[X];

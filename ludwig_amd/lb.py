@@ -581,10 +581,13 @@ class LB:
         _l.check(self._lib.lbmi_lb_collide_fe(self._h, ctypes.byref(h),
                                               ctypes.byref(fe)))
 
-    def io_format_set(self, ascii=False):
+    def io_format_set(self, ascii=False, single=False):
         """lbmi_io_format_set: binary (default) or text records
-        (distribution_io_format ascii) for lb_io_write / lb_io_read."""
-        _l.check(self._lib.lbmi_io_format_set(self._h, 1 if ascii else 0))
+        (distribution_io_format ascii) for lb_io_write / lb_io_read;
+        single: the old-style files of a run that names no i/o mode
+        (io_harness.c: dist-%8.8d.001-001 and dist.001-001.meta)."""
+        _l.check(self._lib.lbmi_io_format_set(
+            self._h, (IO_ASCII if ascii else 0) | (IO_SINGLE if single else 0)))
 
     def lb_io_write(self, directory, timestep, ntotal_x=None, offset_x=0):
         """lb_io_write (model.c:1568): dist-metadata.001-001 and
@@ -657,21 +660,41 @@ def io_metadata_write(directory, stub, nel, ntotal):
                                                  stub.encode(), int(nel), n))
 
 
-def io_metadata_write_fmt(directory, stub, nvel, ndist, ntotal, ascii=False):
+IO_ASCII, IO_SINGLE = 1, 2           # lbmi.h: LBMI_IO_ASCII, LBMI_IO_SINGLE
+
+
+def io_metadata_write_fmt(directory, stub, nvel, ndist, ntotal, ascii=False,
+                          single=False):
     """lbmi_io_metadata_write_fmt: the metadata of records of ndist*nvel values
-    in binary or text (distribution_io_format ascii) form. Host only."""
+    in binary or text (distribution_io_format ascii) form, of the MPI-IO or
+    the single mode. Host only."""
     lib = _l.library()
     nt = (ctypes.c_int * 3)(*[int(v) for v in ntotal])
     _l.check(lib.lbmi_io_metadata_write_fmt(str(directory).encode(), stub.encode(),
                                             int(nvel), int(ndist), nt,
-                                            1 if ascii else 0))
+                                            (IO_ASCII if ascii else 0)
+                                            | (IO_SINGLE if single else 0)))
 
 
-def io_filename(directory, stub, timestep):
-    """io_subfile_name: <stub>-%9.9d.001-001. Host only."""
+def io_single_metadata_write(directory, stub, nvel, ndist, ntotal, cartdim=0,
+                             nslab=None):
+    """lbmi_io_single_metadata_write: <stub>.001-001.meta of the old-style
+    i/o (io_write_metadata_file, io_harness.c:369-466). Host only."""
+    nt = (ctypes.c_int * 3)(*[int(v) for v in ntotal])
+    sz = 1 if nslab is None else len(nslab)
+    ns = None if nslab is None else (ctypes.c_int * sz)(*[int(v) for v in nslab])
+    _l.check(_l.library().lbmi_io_single_metadata_write(
+        str(directory).encode(), stub.encode(), int(nvel), int(ndist), nt,
+        int(cartdim), sz, ns))
+
+
+def io_filename(directory, stub, timestep, single=False):
+    """io_subfile_name: <stub>-%9.9d.001-001 (single: the old style's
+    <stub>-%8.8d.001-001). Host only."""
     buf = ctypes.create_string_buffer(1024)
-    _l.check(_l.library().lbmi_io_filename(str(directory).encode(),
-                                           stub.encode(), int(timestep), buf, 1024))
+    _l.check(_l.library().lbmi_io_filename_fmt(str(directory).encode(),
+                                               stub.encode(), int(timestep),
+                                               IO_SINGLE if single else 0, buf, 1024))
     return buf.value.decode()
 
 

@@ -160,6 +160,11 @@ SYMBOLS = [
                                     ctypes.POINTER(_i)]),
     ("lbmi_io_filename", _i, [ctypes.c_char_p, ctypes.c_char_p, _i,
                               ctypes.c_char_p, ctypes.c_size_t]),
+    ("lbmi_io_filename_fmt", _i, [ctypes.c_char_p, ctypes.c_char_p, _i, _i,
+                                  ctypes.c_char_p, ctypes.c_size_t]),
+    ("lbmi_io_single_metadata_write", _i, [ctypes.c_char_p, ctypes.c_char_p, _i, _i,
+                                           ctypes.POINTER(_i), _i, _i,
+                                           ctypes.POINTER(_i)]),
     ("lbmi_synchronize", _i, [_vp]),
     ("lbmi_stream", _i, [_vp, ctypes.POINTER(_vp)]),
     ("lbmi_set_stream", _i, [_vp, _vp]),

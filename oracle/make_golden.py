@@ -288,6 +288,10 @@ IO_CASES = [
     ("io_q19_2dist", 19, (4, 6, 5), 40, 2),         # ndist = 2: records of 38 doubles
     ("io_q19_ascii", 19, (6, 4, 3), 12, 1, "ascii"),         # distribution_io_format ascii
     ("io_q19_2dist_ascii", 19, (3, 4, 5), 3, 2, "ascii"),    # two values per line
+    # no i/o mode named in the input (io_options_default(): single): the
+    # old-style files of io_harness.c
+    ("io_q19_single", 19, (5, 6, 4), 20, 1, "single"),
+    ("io_q27_2dist_single", 27, (4, 3, 5), 1234567, 2, "single"),
 ]
 
 
@@ -300,14 +304,21 @@ def run_io_case(case, tmp, exe=None, env=None):
         exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
     d = os.path.join(tmp, name)
     os.makedirs(d)
-    ascii_ = (len(case) > 5 and case[5] == "ascii")
-    subprocess.run([exe, "io", d, *map(str, n), str(timestep)]
-                   + ([str(ndist)] if (ndist != 1 or ascii_) else [])
-                   + (["ascii"] if ascii_ else []), check=True,
-                   stdout=subprocess.DEVNULL, env=env)
-    datafile = "dist-%9.9d.001-001" % timestep
+    variant = case[5] if len(case) > 5 else None               # "ascii" | "single"
+    r = subprocess.run([exe, "io", d, *map(str, n), str(timestep)]
+                       + ([str(ndist)] if (ndist != 1 or variant) else [])
+                       + ([variant] if variant else []), check=True,
+                       stdout=subprocess.DEVNULL, env=env,
+                       stderr=(subprocess.PIPE if env else None), text=True)
+    datafile = ("dist-%8.8d.001-001" if variant == "single" else "dist-%9.9d.001-001") % timestep
     nall = tuple(m + 2 for m in n)
-    return {"metadata": np.array(open(os.path.join(d, "dist-metadata.001-001")).read()),
+    extra = {}
+    if env:
+        extra["stderr"] = np.array(r.stderr)      # (a test's run, not a fixture)
+    if variant == "single":
+        extra["meta_text"] = np.array(open(os.path.join(d, "dist.001-001.meta")).read())
+    return {**extra,
+            "metadata": np.array(open(os.path.join(d, "dist-metadata.001-001")).read()),
             "datafile": np.array(datafile),
             "data": np.fromfile(os.path.join(d, datafile), dtype=np.uint8),
             "f0": np.fromfile(os.path.join(d, "written.f0.f64"),

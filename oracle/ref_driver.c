@@ -777,8 +777,9 @@ static int run_wall(int argc, char ** argv) {
  *
  *  run_io
  *
- *  "io" mode: ref_driver io <dir> nx ny nz timestep [ndist [ascii]]
- *    lb_io_write (model.c:1568-1614, MPI-IO mode) of the synthetic state in
+ *  "io" mode: ref_driver io <dir> nx ny nz timestep [ndist [ascii|single]]
+ *    lb_io_write (model.c:1568-1614, MPI-IO mode; "single": the old-style
+ *    i/o of a run without i/o keys, io_harness.c) of the synthetic state in
  *    <dir>: the metadata file dist.json and the data file; also <dir>/f0.f64.
  *  "ioread" mode: ref_driver ioread <dir> nx ny nz timestep
  *    lb_io_read (model.c:1622-1649) of the data file found in <dir>, then
@@ -824,7 +825,21 @@ static int run_io(int argc, char ** argv) {
       opts.iodata.input.iorformat = IO_RECORD_ASCII;
       opts.iodata.output.iorformat = IO_RECORD_ASCII;
     }
+    if (argc == 9 && strcmp(argv[8], "single") == 0) {
+      /* what a run with no i/o key in its input has (io_options_default():
+       * IO_MODE_SINGLE): the old-style files of io_harness.c */
+      opts.iodata.input = io_options_default();
+      opts.iodata.output = io_options_default();
+    }
     lb_data_create(pe, cs, &opts, &lb);
+    if (argc == 9 && strcmp(argv[8], "single") == 0) {
+      /* as distribution_rt.c:258-273 */
+      io_info_t * io_info = NULL;
+      io_info_args_t tmp = io_info_args_default();
+      io_info_create(pe, cs, &tmp, &io_info);
+      io_info_metadata_filestub_set(io_info, "dist");
+      lb_io_info_set(lb, io_info, IO_FORMAT_BINARY, IO_FORMAT_BINARY);
+    }
   }
   {
     io_event_t event = {0};

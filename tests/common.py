@@ -61,9 +61,12 @@ def load_io_golden(name):
     """Files written by the reference's lb_io_write (io_q19, io_q27): the
     metadata text, the data file name and bytes, and the f they hold."""
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
-    return {"metadata": str(z["metadata"]), "datafile": str(z["datafile"]),
-            "data": z["data"].tobytes(), "f0": z["f0"],
-            "timestep": int(z["timestep"])}
+    g = {"metadata": str(z["metadata"]), "datafile": str(z["datafile"]),
+         "data": z["data"].tobytes(), "f0": z["f0"],
+         "timestep": int(z["timestep"])}
+    if "meta_text" in z.files:          # the single mode's dist.001-001.meta
+        g["meta_text"] = str(z["meta_text"])
+    return g
 
 
 def load_golden(name):

@@ -230,3 +230,52 @@ def test_text_records_identical_to_reference_files(name, ndist, tmp_path):
             lb.synchronize()
             lb.free()
         assert open(sl / g["datafile"], "rb").read() == g["data"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,nvel", [("io_q19_single", 19), ("io_q27_2dist_single", 27)])
+def test_single_mode_files(name, nvel, tmp_path):
+    """The old-style i/o of a run that names no i/o mode (io_options_default():
+    single; io_harness.c): dist-%8.8d.001-001, dist.001-001.meta and the JSON
+    metadata that says "single" -- all three byte for byte what the compiled
+    reference wrote; read back exactly; two slabs write their ranges of the
+    one file; text records are refused in this mode (the reference gives them
+    no size)."""
+    import ludwig_amd
+    g = load_io_golden(name)
+    n = tuple(m - 2 for m in g["f0"].shape[1:])
+    ndist = g["f0"].shape[0] // nvel
+    lb = ludwig_amd.LB(nvel, n, 1, ndist=ndist, mode=ludwig_amd.FUSED)
+    lb.io_format_set(single=True)
+    lb.lb_memcpy_h2d(g["f0"])
+    lb.lb_io_write(tmp_path, g["timestep"])
+    lb.synchronize()
+    assert sorted(os.listdir(tmp_path)) == sorted(["dist-metadata.001-001", "dist.001-001.meta",
+                                                   g["datafile"]])
+    assert open(tmp_path / "dist-metadata.001-001").read() == g["metadata"]
+    assert open(tmp_path / "dist.001-001.meta").read() == g["meta_text"]
+    assert open(tmp_path / g["datafile"], "rb").read() == g["data"]
+    with pytest.raises(Exception):
+        lb.io_format_set(ascii=True, single=True)
+    lb.free()
+    lb = ludwig_amd.LB(nvel, n, 1, ndist=ndist)
+    lb.io_format_set(single=True)
+    lb.lb_io_read(tmp_path, g["timestep"])
+    assert np.array_equal(interior(lb.lb_memcpy_d2h(), 1), interior(g["f0"], 1))
+    lb.free()
+    if n[0] % 2 == 0:
+        sl = tmp_path / "slabs"
+        sl.mkdir()
+        half = n[0] // 2
+        for r in (1, 0):
+            lb = ludwig_amd.LB(nvel, (half, n[1], n[2]), 1, ndist=ndist, cartsz=2, cartrank=r)
+            lb.io_format_set(single=True)
+            lb.lb_memcpy_h2d(np.ascontiguousarray(g["f0"][:, r * half:r * half + half + 2]))
+            lb.lb_io_write(sl, g["timestep"], ntotal_x=n[0], offset_x=r * half)
+            lb.synchronize()
+            lb.free()
+        assert open(sl / g["datafile"], "rb").read() == g["data"]
+        meta = open(sl / "dist.001-001.meta").read().splitlines()
+        assert meta[4] == "Number of processors:            2"
+        assert meta[12:] == ["%3d %3d %3d %3d %d %d %d %d %d %d" % (r, r, 0, 0, half, n[1], n[2],
+                                                                     r * half, 0, 0) for r in (0, 1)]

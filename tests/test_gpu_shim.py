@@ -143,17 +143,23 @@ def test_shim_lb_io_write_and_read(case, tmp_path):
     nvel, n, timestep = case[1], case[2], case[3]
     ndist = case[4] if len(case) > 4 else 1
     exe = _exe(nvel, shim=True)
-    env = _env(None)
+    env = _env(None, LBMI_REPORT="1")
     out = mg.run_io_case(case, str(tmp_path), exe=exe, env=env)
+    # the binding wrote them, not the original it can hand back to
+    assert _re.search(r"liblbmi report: lb_io_write\s+1\s+0\b", str(out["stderr"])), out["stderr"]
     g = np.load(os.path.join(HERE, "golden", case[0] + ".npz"))
     assert str(out["metadata"]) == str(g["metadata"])
     assert out["data"].tobytes() == g["data"].tobytes()
     d = os.path.join(str(tmp_path), case[0])
-    ascii_ = (len(case) > 5 and case[5] == "ascii")       # distribution_io_format ascii
-    subprocess.run([exe, "ioread", d, *map(str, n), str(timestep)]
-                   + ([str(ndist)] if (ndist != 1 or ascii_) else [])
-                   + (["ascii"] if ascii_ else []), check=True, env=env,
-                   stdout=subprocess.DEVNULL)
+    variant = case[5] if len(case) > 5 else None
+    ascii_ = (variant == "ascii")                         # distribution_io_format ascii
+    if variant == "single":                               # no i/o mode named: old-style files
+        assert str(out["meta_text"]) == str(g["meta_text"])
+    r = subprocess.run([exe, "ioread", d, *map(str, n), str(timestep)]
+                       + ([str(ndist)] if (ndist != 1 or variant) else [])
+                       + ([variant] if variant else []), check=True, env=env,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    assert _re.search(r"liblbmi report: lb_io_read\s+1\s+0\b", r.stderr), r.stderr
     back = np.fromfile(os.path.join(d, "readback.f.f64"), dtype="<f8").reshape(g["f0"].shape)
     if ascii_:
         # sixteen significant digits in the text

@@ -99,3 +99,70 @@ def test_text_record_metadata_and_oracle_text(name, ndist, tmp_path):
                 for p in range(19):
                     lines.append("".join(" %22.15e" % f[d, p, ic, jc, kc] for d in range(ndist)))
     assert ("\n".join(lines) + "\n").encode() == g["data"]
+
+
+SINGLE = [("io_q19_single", 19), ("io_q27_2dist_single", 27)]
+
+
+@pytest.mark.parametrize("name,nvel", SINGLE)
+def test_single_mode_files_of_a_run_that_names_no_io_mode(name, nvel, tmp_path):
+    """io_options_default() is IO_MODE_SINGLE: lb_io_write goes old-style
+    (model.c:1583-1587 -> io_write_data_s, io_harness.c). Three files: the
+    JSON metadata (it says "single", version 1), the text file
+    dist.001-001.meta, and the data under dist-%8.8d.001-001 -- the same
+    record stream as the MPI-IO mode writes. The first two and the name are
+    host-only entry points of the C-ABI; byte for byte against what the
+    compiled reference wrote."""
+    import ludwig_amd
+    g = load_io_golden(name)
+    n = _nlocal(g)
+    nd = _ndist(g, nvel)
+    ludwig_amd.io_metadata_write_fmt(tmp_path, "dist", nvel, nd, n, single=True)
+    assert open(tmp_path / "dist-metadata.001-001").read() == g["metadata"]
+    ludwig_amd.io_single_metadata_write(tmp_path, "dist", nvel, nd, n)
+    assert open(tmp_path / "dist.001-001.meta").read() == g["meta_text"]
+    assert ludwig_amd.io_filename(tmp_path, "dist", g["timestep"], single=True) \
+        == str(tmp_path / g["datafile"])
+    p = lbo.make_param(nvel, n, 1)
+    assert lbo.records_pack(p, np.ascontiguousarray(g["f0"]), nd).tobytes() == g["data"]
+
+
+def test_single_mode_metadata_lists_the_slabs_in_rank_order(tmp_path):
+    """More than one rank: one line per rank (rank, Cartesian coordinates,
+    nlocal, offset) as io_write_metadata_file prints them (io_harness.c:410-415).
+    No serial run of the reference can write this: the lines are checked
+    against that format, not against a file of the reference (unpinned)."""
+    import ludwig_amd
+    ludwig_amd.io_single_metadata_write(tmp_path, "dist", 19, 1, (10, 4, 6), cartdim=0,
+                                        nslab=[3, 4, 3])
+    lines = open(tmp_path / "dist.001-001.meta").read().splitlines()
+    assert lines[4] == "Number of processors:            3"
+    assert lines[5] == "Cartesian communicator topology: 3 1 1"
+    assert lines[12:] == ["%3d %3d %3d %3d %d %d %d %d %d %d" % (r, r, 0, 0, nx, 4, 6, off, 0, 0)
+                          for r, nx, off in ((0, 3, 0), (1, 4, 3), (2, 3, 7))]
+    with pytest.raises(Exception):
+        ludwig_amd.io_single_metadata_write(tmp_path, "dist", 19, 1, (10, 4, 6), nslab=[3, 3, 3])
+
+
+@pytest.mark.parametrize("name,nvel", SINGLE)
+def test_reference_reads_our_single_mode_file(name, nvel, tmp_path):
+    """lb_io_read of the compiled reference in its default mode
+    (io_read_data, single_file_read: a seek per row to its global position)
+    on a record stream made here."""
+    exe = os.path.join(REF, "ref_driver_d3q%d" % nvel)
+    if not os.path.exists(exe):
+        pytest.skip("compiled reference (oracle/_ref) not present")
+    import ludwig_amd
+    g = load_io_golden(name)
+    n = _nlocal(g)
+    nd = _ndist(g, nvel)
+    p = lbo.make_param(nvel, n, 1)
+    rng = np.random.default_rng(5)
+    f = np.zeros_like(g["f0"])
+    interior(f, 1)[...] = rng.random((nd * nvel,) + n)
+    with open(ludwig_amd.io_filename(tmp_path, "dist", 9, single=True), "wb") as fp:
+        fp.write(lbo.records_pack(p, f, nd).tobytes())
+    subprocess.run([exe, "ioread", str(tmp_path), *map(str, n), "9", str(nd), "single"],
+                   check=True, stdout=subprocess.DEVNULL)
+    back = np.fromfile(tmp_path / "readback.f.f64", dtype="<f8").reshape(f.shape)
+    assert np.array_equal(interior(back, 1), interior(f, 1))
