@@ -664,6 +664,29 @@ int lbmi_io_format_set(lbmi_t * lb, int fmt);
  * same byte range per X slab. Text records in this mode have no fixed size in
  * the reference and are refused (LBMI_ERR_UNSUPPORTED). */
 enum {LBMI_IO_ASCII = 1, LBMI_IO_SINGLE = 2};
+
+/* Several files: the reference's i/o grid (input key distribution_io_grid,
+ * io_subfile_create, io_subfile.c:49-91) cut along the slab direction,
+ * {nfile, 1, 1}. The ranks of a group write ONE file that holds the group's
+ * block of planes in the same record order: file `index` of `nfile` is
+ *   <dir>/dist-%9.9d.%3.3d-%3.3d   (timestep, 1 + index, nfile)
+ * with its own <dir>/dist-metadata.%3.3d-%3.3d, written by the rank whose
+ * offset_x is file_x0. A rank's byte range starts at its planes' position in
+ * the FILE (io_impl_mpio.c:179-272). periodic: what cs_periodic says, printed
+ * in the metadata (1, 1, 1 when nothing is set). MPI-IO mode only.
+ * Parity: the one-file case is pinned by the reference's files; no serial run
+ * of the reference can write several, so for nfile > 1 the keys and the
+ * arithmetic follow the code cited and the tests check them against the
+ * one-file stream (cut at the file boundaries) -- unpinned. */
+typedef struct lbmi_io_file_s {
+  int nfile;         /* files in all (the i/o grid's X extent)                */
+  int index;         /* this rank's file, 0 .. nfile-1                        */
+  int file_nx;       /* planes in that file (io_subfile_t::sizes[X])          */
+  int file_x0;       /* global index of its first plane (::offset[X])         */
+  int periodic[3];   /* cs_periodic, for the metadata                         */
+} lbmi_io_file_t;
+/* file == NULL: back to one file of the whole lattice, periodic */
+int lbmi_io_file_set(lbmi_t * lb, const lbmi_io_file_t * file);
 int lbmi_lb_io_read(lbmi_t * lb, const char * dir, int timestep,
 		    int ntotal_x, int offset_x);
 
@@ -676,6 +699,10 @@ int lbmi_io_metadata_write(const char * dir, const char * stub, int nel,
  * lbmi_io_format_set) */
 int lbmi_io_metadata_write_fmt(const char * dir, const char * stub, int nvel,
 			       int ndist, const int ntotal[3], int fmt);
+/* ... and of one file of several (file == NULL: the one file) */
+int lbmi_io_metadata_write_file(const char * dir, const char * stub, int nvel,
+				int ndist, const int ntotal[3], int fmt,
+				const lbmi_io_file_t * file);
 int lbmi_io_filename(const char * dir, const char * stub, int timestep,
 		     char * buf, size_t bufsz);
 int lbmi_io_filename_fmt(const char * dir, const char * stub, int timestep,

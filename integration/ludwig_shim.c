@@ -1067,8 +1067,10 @@ int lb_memcpy(lb_t * lb, tdpMemcpyKind flag) {
  *  lb_write_buf_ascii formats them. So is the old-style i/o of a run whose
  *  input names no i/o mode (io_harness.c, through lb->io_info) while it keeps
  *  one file of binary records: the same record stream under the old name
- *  with the old text metadata beside it. Anything else (several files, the
- *  old text records) goes to the original.
+ *  with the old text metadata beside it. Several files (distribution_io_grid
+ *  N_1_1 over X slabs, MPI-IO mode): each group of slabs one file of its
+ *  planes. Anything else (an i/o grid across the slabs, several old-style
+ *  files, the old text records) goes to the original.
  *
  *****************************************************************************/
 
@@ -1080,8 +1082,11 @@ static int shim_io_supported(lb_t * lb, const io_metadata_t * meta, int reading)
   if (!shim_supported(lb)) return 0;
   /* (a slab along Y or Z is not one byte range of the file) */
   if (!shim_slab_dim(lb, &dim) || dim != X) return 0;
-  if (meta->options.iogrid[X] != 1 || meta->options.iogrid[Y] != 1 ||
-      meta->options.iogrid[Z] != 1) return 0;
+  /* several files: along the slab direction only (a group of slabs is then a
+   * block of planes, one byte range per slab of its file) */
+  if (meta->options.iogrid[Y] != 1 || meta->options.iogrid[Z] != 1) return 0;
+  if (meta->options.iogrid[X] != 1 && meta->options.mode != IO_MODE_MPIIO) return 0;
+  if (meta->subfile.nfile != meta->options.iogrid[X]) return 0;
   if (meta->options.mode == IO_MODE_MPIIO) {
     if (meta->options.iorformat == IO_RECORD_ASCII) fmt = LBMI_IO_ASCII;
     else if (meta->options.iorformat != IO_RECORD_BINARY) return 0;
@@ -1107,6 +1112,19 @@ static int shim_io_supported(lb_t * lb, const io_metadata_t * meta, int reading)
     }
   }
   return 1 + LBMI_IO_SINGLE;
+}
+
+/* the file of this rank's i/o group (io_subfile_t) and the periodicity the
+ * metadata prints */
+
+static void shim_io_file(lb_t * lb, const io_metadata_t * meta) {
+  lbmi_io_file_t file = {0};
+  file.nfile = meta->subfile.nfile;
+  file.index = meta->subfile.index;
+  file.file_nx = meta->subfile.sizes[X];
+  file.file_x0 = meta->subfile.offset[X];
+  cs_periodic(lb->cs, file.periodic);
+  SHIM_CHECK(lb, lbmi_io_file_set(shim_handle(lb), &file));
 }
 
 int lb_io_write(lb_t * lb, int timestep, io_event_t * event) {
@@ -1135,6 +1153,7 @@ int lb_io_write(lb_t * lb, int timestep, io_event_t * event) {
     /* binary records, distribution_io_format ascii (model.c:1438-1462), or
      * the old-style files */
     SHIM_CHECK(lb, lbmi_io_format_set(shim_handle(lb), fmt));
+    shim_io_file(lb, &lb->output);
     SHIM_CHECK(lb, lbmi_lb_io_write(shim_handle(lb), ".", timestep, ntotal[X],
 				    noffset[X]));
     shim_sync_pointers(lb, shim_.h);                /* a flush may have swapped */
@@ -1174,6 +1193,7 @@ int lb_io_read(lb_t * lb, int timestep, io_event_t * event) {
     cs_nlocal_offset(lb->cs, noffset);
     shim_note(S_LB_IO_READ, 1);
     SHIM_CHECK(lb, lbmi_io_format_set(shim_handle(lb), fmt));
+    shim_io_file(lb, &lb->input);
     SHIM_CHECK(lb, lbmi_lb_io_read(shim_handle(lb), ".", timestep, ntotal[X],
 				   noffset[X]));
     shim_sync_pointers(lb, shim_.h);

@@ -106,6 +106,8 @@ struct lbmi_s {
   int grad_npt;
   int adv_order;
   int io_ascii;                      /* distribution files: text records */
+  lbmi_io_file_t io_file;            /* i/o grid {nfile,1,1}: this rank's file; periodicity */
+  int io_file_set;
   double * fe_force;                 /* lbmi_symmetric_lb_step off the fused
 					route: the thermodynamic force */
 
@@ -3613,6 +3615,21 @@ int lbmi_lb_records_unpack(lbmi_t * lb, const double * records) {
  *
  *****************************************************************************/
 
+static int lbmi_io_filename_file(const char * dir, const char * stub, int timestep,
+				 int fmt, const lbmi_io_file_t * file,
+				 char * buf, size_t bufsz) {
+  int n;
+  if (file == NULL || file->nfile <= 1) {
+    return lbmi_io_filename_fmt(dir, stub, timestep, fmt, buf, bufsz);
+  }
+  if (dir == NULL || stub == NULL || buf == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  /* io_subfile_name (io_subfile.c): 1 + index of nfile */
+  n = snprintf(buf, bufsz, "%s/%s-%9.9d.%3.3d-%3.3d", dir, stub, timestep,
+	       1 + file->index, file->nfile);
+  if (n < 0 || (size_t) n >= bufsz) return lbmi_fail(LBMI_ERR_ARGUMENT, "file name too long");
+  return 0;
+}
+
 int lbmi_io_filename_fmt(const char * dir, const char * stub, int timestep,
 			 int fmt, char * buf, size_t bufsz) {
   int n;
@@ -3653,16 +3670,38 @@ int lbmi_io_metadata_write(const char * dir, const char * stub, int nel,
 
 int lbmi_io_metadata_write_fmt(const char * dir, const char * stub, int nvel,
 			       int ndist, const int ntotal[3], int fmt) {
+  return lbmi_io_metadata_write_file(dir, stub, nvel, ndist, ntotal, fmt, NULL);
+}
+
+int lbmi_io_metadata_write_file(const char * dir, const char * stub, int nvel,
+				int ndist, const int ntotal[3], int fmt,
+				const lbmi_io_file_t * file) {
   const int nel = nvel*ndist;
   const int ascii = (fmt & LBMI_IO_ASCII);
   const int single = (fmt & LBMI_IO_SINGLE);
+  /* io_subfile_create (io_subfile.c:49-91) for an i/o grid {nfile, 1, 1} */
+  lbmi_io_file_t one = {1, 0, 0, 0, {1, 1, 1}};
   char fn[1024];
   FILE * fp = NULL;
   int n;
   if (dir == NULL || stub == NULL || ntotal == NULL || nvel < 1 || ndist < 1) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_io_metadata_write: bad argument");
   }
-  n = snprintf(fn, sizeof(fn), "%s/%s-metadata.%3.3d-%3.3d", dir, stub, 1, 1);
+  one.file_nx = ntotal[0];
+  if (file == NULL) file = &one;
+  if (file->nfile < 1 || file->index < 0 || file->index >= file->nfile ||
+      file->file_x0 < 0 || file->file_nx < 1 ||
+      file->file_x0 + file->file_nx > ntotal[0] ||
+      (file->nfile == 1 && (file->file_x0 != 0 || file->file_nx != ntotal[0]))) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "file %d of %d, planes %d + %d of %d",
+		     file->index, file->nfile, file->file_x0, file->file_nx, ntotal[0]);
+  }
+  if (file->nfile > 1 && single) {
+    /* (several old-style files are IO_MODE_MULTIPLE, io_write_data_p) */
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "the single mode has one file");
+  }
+  n = snprintf(fn, sizeof(fn), "%s/%s-metadata.%3.3d-%3.3d", dir, stub,
+	       1 + file->index, file->nfile);
   if (n < 0 || (size_t) n >= sizeof(fn)) return lbmi_fail(LBMI_ERR_ARGUMENT, "file name too long");
   fp = fopen(fn, "w");
   if (fp == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "%s: %s", fn, strerror(errno));
@@ -3673,7 +3712,8 @@ int lbmi_io_metadata_write_fmt(const char * dir, const char * stub, int nvel,
   fprintf(fp, "\t\"coords\":\t{\n");
   fprintf(fp, "\t\t\"options\":\t{\n");
   fprintf(fp, "\t\t\t\"System size (total)\":\t[%d, %d, %d],\n", ntotal[0], ntotal[1], ntotal[2]);
-  fprintf(fp, "\t\t\t\"Periodic boundaries\":\t[1, 1, 1],\n");
+  fprintf(fp, "\t\t\t\"Periodic boundaries\":\t[%d, %d, %d],\n",
+	  file->periodic[0], file->periodic[1], file->periodic[2]);
   fprintf(fp, "\t\t\t\"Left-end limit Lmin\":\t[0.5, 0.5, 0.5]\n");
   fprintf(fp, "\t\t},\n");
   fprintf(fp, "\t\t\"lees_edwards\":\t{\n");
@@ -3689,7 +3729,7 @@ int lbmi_io_metadata_write_fmt(const char * dir, const char * stub, int nvel,
   fprintf(fp, "\t\t\"Report\":\t%s,\n", single ? "false" : "true");
   fprintf(fp, "\t\t\"Asynchronous\":\tfalse,\n");
   fprintf(fp, "\t\t\"Compression level\":\t0,\n");
-  fprintf(fp, "\t\t\"I/O grid\":\t[1, 1, 1]\n");
+  fprintf(fp, "\t\t\"I/O grid\":\t[%d, 1, 1]\n", file->nfile);
   fprintf(fp, "\t},\n");
   fprintf(fp, "\t\"io_element\":\t{\n");
   if (ascii) {
@@ -3707,13 +3747,13 @@ int lbmi_io_metadata_write_fmt(const char * dir, const char * stub, int nvel,
   fprintf(fp, "\t\t\"Endianness\":\t\"LITTLE_ENDIAN\"\n");
   fprintf(fp, "\t},\n");
   fprintf(fp, "\t\"io_subfile\":\t{\n");
-  fprintf(fp, "\t\t\"Number of files\":\t1,\n");
-  fprintf(fp, "\t\t\"File index\":\t0,\n");
-  fprintf(fp, "\t\t\"Topology\":\t[1, 1, 1],\n");
-  fprintf(fp, "\t\t\"Coordinate\":\t[0, 0, 0],\n");
+  fprintf(fp, "\t\t\"Number of files\":\t%d,\n", file->nfile);
+  fprintf(fp, "\t\t\"File index\":\t%d,\n", file->index);
+  fprintf(fp, "\t\t\"Topology\":\t[%d, 1, 1],\n", file->nfile);
+  fprintf(fp, "\t\t\"Coordinate\":\t[%d, 0, 0],\n", file->index);
   fprintf(fp, "\t\t\"Data ndims\":\t3,\n");
-  fprintf(fp, "\t\t\"File size (sites)\":\t[%d, %d, %d],\n", ntotal[0], ntotal[1], ntotal[2]);
-  fprintf(fp, "\t\t\"File offset (sites)\":\t[0, 0, 0]\n");
+  fprintf(fp, "\t\t\"File size (sites)\":\t[%d, %d, %d],\n", file->file_nx, ntotal[1], ntotal[2]);
+  fprintf(fp, "\t\t\"File offset (sites)\":\t[%d, 0, 0]\n", file->file_x0);
   fprintf(fp, "\t}\n");
   fprintf(fp, "}");
   if (fclose(fp) != 0) return lbmi_fail(LBMI_ERR_ARGUMENT, "%s: %s", fn, strerror(errno));
@@ -3937,6 +3977,52 @@ static int lbmi_io_args(lbmi_t * lb, const char * dir, int ntotal_x,
   return 0;
 }
 
+int lbmi_io_file_set(lbmi_t * lb, const lbmi_io_file_t * file) {
+  if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (file == NULL) {
+    lb->io_file_set = 0;
+    return 0;
+  }
+  if (file->nfile < 1 || file->index < 0 || file->index >= file->nfile ||
+      file->file_x0 < 0 || file->file_nx < 1) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_io_file_set: file %d of %d, planes %d + %d",
+		     file->index, file->nfile, file->file_x0, file->file_nx);
+  }
+  for (int ia = 0; ia < 3; ia++) {
+    if (file->periodic[ia] != 0 && file->periodic[ia] != 1) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_io_file_set: periodic[%d] = %d", ia,
+		       file->periodic[ia]);
+    }
+  }
+  lb->io_file = *file;
+  lb->io_file_set = 1;
+  return 0;
+}
+
+/* this rank's file: the whole lattice unless lbmi_io_file_set said otherwise */
+
+static int lbmi_io_file(lbmi_t * lb, int ntotal_x, int offset_x, lbmi_io_file_t * file) {
+  lbmi_io_file_t one = {1, 0, 0, 0, {1, 1, 1}};
+  one.file_nx = ntotal_x;
+  *file = lb->io_file_set ? lb->io_file : one;
+  if (file->nfile == 1) {
+    file->file_x0 = 0;
+    file->file_nx = ntotal_x;
+  }
+  if (file->nfile > 1 && (lb->io_ascii & LBMI_IO_SINGLE)) {
+    return lbmi_fail(LBMI_ERR_UNSUPPORTED, "the single mode has one file");
+  }
+  if (offset_x < file->file_x0 ||
+      offset_x + lb->kp.nlocal[X] > file->file_x0 + file->file_nx ||
+      file->file_x0 + file->file_nx > ntotal_x) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "planes %d..%d are not in file %d of %d "
+		     "(planes %d..%d of %d)", offset_x, offset_x + lb->kp.nlocal[X] - 1,
+		     file->index, file->nfile, file->file_x0,
+		     file->file_x0 + file->file_nx - 1, ntotal_x);
+  }
+  return 0;
+}
+
 int lbmi_io_format_set(lbmi_t * lb, int fmt) {
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (fmt < 0 || fmt > (LBMI_IO_ASCII | LBMI_IO_SINGLE)) {
@@ -3957,15 +4043,19 @@ int lbmi_lb_io_write(lbmi_t * lb, const char * dir, int timestep,
 		     int ntotal_x, int offset_x) {
   char fn[1024];
   size_t plane, nbytes;
+  lbmi_io_file_t file;
   int ifail = lbmi_io_args(lb, dir, ntotal_x, offset_x);
+  if (ifail) return ifail;
+  ifail = lbmi_io_file(lb, ntotal_x, offset_x, &file);
   if (ifail) return ifail;
   HIPCHECK(hipSetDevice(lb->device));
   ifail = lbmi_lb_flush(lb);
   if (ifail) return ifail;
-  if (offset_x == 0) {
+  if (offset_x == file.file_x0) {
+    /* (io_metadata_write: rank 0 of the file's communicator) */
     int ntotal[3] = {ntotal_x, lb->kp.nlocal[Y], lb->kp.nlocal[Z]};
-    ifail = lbmi_io_metadata_write_fmt(dir, "dist", lb->kp.nvel, lb->opts.ndist,
-				       ntotal, lb->io_ascii);
+    ifail = lbmi_io_metadata_write_file(dir, "dist", lb->kp.nvel, lb->opts.ndist,
+					ntotal, lb->io_ascii, &file);
     if (ifail) return ifail;
     if (lb->io_ascii & LBMI_IO_SINGLE) {
       /* io_write_data_s -> io_write_metadata; the lines of the other ranks
@@ -3985,29 +4075,34 @@ int lbmi_lb_io_write(lbmi_t * lb, const char * dir, int timestep,
       if (ifail) return ifail;
     }
   }
-  ifail = lbmi_io_filename_fmt(dir, "dist", timestep, lb->io_ascii, fn, sizeof(fn));
+  ifail = lbmi_io_filename_file(dir, "dist", timestep, lb->io_ascii, &file, fn, sizeof(fn));
   if (ifail) return ifail;
   /* fprime is dead between steps once nothing is pending: pack there */
   KCHECK(lbmi_k_records(&lb->kp, lb->opts.ndist, lb->f, lb->fprime, 1, lb->stream));
   plane = sizeof(double)*(size_t) lb->kp.nvel*lb->opts.ndist*lb->kp.nlocal[Y]*lb->kp.nlocal[Z];
   nbytes = plane*(size_t) lb->kp.nlocal[X];
+  /* (io_impl_mpio.c:179-272: the file view is the rank's block at its
+   * position in the FILE's block) */
   return lbmi_io_transfer(lb, fn, 1, lb->fprime, nbytes,
-			  (off_t) (plane*(size_t) offset_x));
+			  (off_t) (plane*(size_t) (offset_x - file.file_x0)));
 }
 
 int lbmi_lb_io_read(lbmi_t * lb, const char * dir, int timestep,
 		    int ntotal_x, int offset_x) {
   char fn[1024];
   size_t plane, nbytes;
+  lbmi_io_file_t file;
   int ifail = lbmi_io_args(lb, dir, ntotal_x, offset_x);
   if (ifail) return ifail;
+  ifail = lbmi_io_file(lb, ntotal_x, offset_x, &file);
+  if (ifail) return ifail;
   HIPCHECK(hipSetDevice(lb->device));
-  ifail = lbmi_io_filename_fmt(dir, "dist", timestep, lb->io_ascii, fn, sizeof(fn));
+  ifail = lbmi_io_filename_file(dir, "dist", timestep, lb->io_ascii, &file, fn, sizeof(fn));
   if (ifail) return ifail;
   plane = sizeof(double)*(size_t) lb->kp.nvel*lb->opts.ndist*lb->kp.nlocal[Y]*lb->kp.nlocal[Z];
   nbytes = plane*(size_t) lb->kp.nlocal[X];
   ifail = lbmi_io_transfer(lb, fn, 0, lb->fprime, nbytes,
-			   (off_t) (plane*(size_t) offset_x));
+			   (off_t) (plane*(size_t) (offset_x - file.file_x0)));
   if (ifail) return ifail;
   /* replaces the state: whatever was pending is dropped */
   return lbmi_lb_records_unpack(lb, lb->fprime);

@@ -589,6 +589,16 @@ class LB:
         _l.check(self._lib.lbmi_io_format_set(
             self._h, (IO_ASCII if ascii else 0) | (IO_SINGLE if single else 0)))
 
+    def io_file_set(self, nfile=1, index=0, file_nx=0, file_x0=0, periodic=(1, 1, 1)):
+        """lbmi_io_file_set: this rank's file of the i/o grid {nfile, 1, 1}
+        (io_subfile_create, io_subfile.c:49-91) and the periodicity the
+        metadata prints; nfile=None: back to one periodic file."""
+        if nfile is None:
+            _l.check(self._lib.lbmi_io_file_set(self._h, None))
+            return
+        _l.check(self._lib.lbmi_io_file_set(self._h, ctypes.byref(
+            _io_file(nfile, index, file_nx, file_x0, periodic))))
+
     def lb_io_write(self, directory, timestep, ntotal_x=None, offset_x=0):
         """lb_io_write (model.c:1568): dist-metadata.001-001 and
         dist-<timestep>.001-001 in `directory` (MPI-IO mode, one file)."""
@@ -674,6 +684,26 @@ def io_metadata_write_fmt(directory, stub, nvel, ndist, ntotal, ascii=False,
                                             int(nvel), int(ndist), nt,
                                             (IO_ASCII if ascii else 0)
                                             | (IO_SINGLE if single else 0)))
+
+
+def _io_file(nfile, index, file_nx, file_x0, periodic):
+    f = _l.IoFile()
+    f.nfile, f.index, f.file_nx, f.file_x0 = int(nfile), int(index), int(file_nx), int(file_x0)
+    for ia in range(3):
+        f.periodic[ia] = int(periodic[ia])
+    return f
+
+
+def io_metadata_write_file(directory, stub, nvel, ndist, ntotal, nfile=1, index=0,
+                           file_nx=None, file_x0=0, periodic=(1, 1, 1), ascii=False,
+                           single=False):
+    """lbmi_io_metadata_write_file: <stub>-metadata.<1+index>-<nfile> of one
+    file of the i/o grid {nfile, 1, 1}. Host only."""
+    nt = (ctypes.c_int * 3)(*[int(v) for v in ntotal])
+    f = _io_file(nfile, index, ntotal[0] if file_nx is None else file_nx, file_x0, periodic)
+    _l.check(_l.library().lbmi_io_metadata_write_file(
+        str(directory).encode(), stub.encode(), int(nvel), int(ndist), nt,
+        (IO_ASCII if ascii else 0) | (IO_SINGLE if single else 0), ctypes.byref(f)))
 
 
 def io_single_metadata_write(directory, stub, nvel, ndist, ntotal, cartdim=0,

@@ -71,6 +71,13 @@ _vp = ctypes.c_void_p
 _i = ctypes.c_int
 _d = ctypes.c_double
 _pd = ctypes.POINTER(ctypes.c_double)
+class IoFile(ctypes.Structure):
+    """lbmi_io_file_t: one file of the i/o grid {nfile, 1, 1}."""
+    _fields_ = [("nfile", ctypes.c_int), ("index", ctypes.c_int),
+                ("file_nx", ctypes.c_int), ("file_x0", ctypes.c_int),
+                ("periodic", ctypes.c_int * 3)]
+
+
 SYMBOLS = [
     ("lbmi_options_default", _i, [ctypes.POINTER(Options)]),
     ("lbmi_create", _i, [ctypes.POINTER(Options), ctypes.POINTER(_vp)]),
@@ -160,6 +167,9 @@ SYMBOLS = [
                                     ctypes.POINTER(_i)]),
     ("lbmi_io_filename", _i, [ctypes.c_char_p, ctypes.c_char_p, _i,
                               ctypes.c_char_p, ctypes.c_size_t]),
+    ("lbmi_io_file_set", _i, [_vp, ctypes.POINTER(IoFile)]),
+    ("lbmi_io_metadata_write_file", _i, [ctypes.c_char_p, ctypes.c_char_p, _i, _i,
+                                         ctypes.POINTER(_i), _i, ctypes.POINTER(IoFile)]),
     ("lbmi_io_filename_fmt", _i, [ctypes.c_char_p, ctypes.c_char_p, _i, _i,
                                   ctypes.c_char_p, ctypes.c_size_t]),
     ("lbmi_io_single_metadata_write", _i, [ctypes.c_char_p, ctypes.c_char_p, _i, _i,

@@ -292,6 +292,8 @@ IO_CASES = [
     # old-style files of io_harness.c
     ("io_q19_single", 19, (5, 6, 4), 20, 1, "single"),
     ("io_q27_2dist_single", 27, (4, 3, 5), 1234567, 2, "single"),
+    # not periodic in z (a run with walls there): the metadata says so
+    ("io_q19_wallz", 19, (4, 4, 3), 8, 1, "wallz"),
 ]
 
 
@@ -304,7 +306,7 @@ def run_io_case(case, tmp, exe=None, env=None):
         exe = os.path.join(HERE, "_ref", "ref_driver_d3q%d" % nvel)
     d = os.path.join(tmp, name)
     os.makedirs(d)
-    variant = case[5] if len(case) > 5 else None               # "ascii" | "single"
+    variant = case[5] if len(case) > 5 else None      # "ascii" | "single" | "wallz"
     r = subprocess.run([exe, "io", d, *map(str, n), str(timestep)]
                        + ([str(ndist)] if (ndist != 1 or variant) else [])
                        + ([variant] if variant else []), check=True,

@@ -777,7 +777,7 @@ static int run_wall(int argc, char ** argv) {
  *
  *  run_io
  *
- *  "io" mode: ref_driver io <dir> nx ny nz timestep [ndist [ascii|single]]
+ *  "io" mode: ref_driver io <dir> nx ny nz timestep [ndist [ascii|single|wallz]]
  *    lb_io_write (model.c:1568-1614, MPI-IO mode; "single": the old-style
  *    i/o of a run without i/o keys, io_harness.c) of the synthetic state in
  *    <dir>: the metadata file dist.json and the data file; also <dir>/f0.f64.
@@ -812,6 +812,11 @@ static int run_io(int argc, char ** argv) {
   cs_create(pe, &cs);
   cs_ntotal_set(cs, c.ntotal);
   cs_nhalo_set(cs, c.nhalo);
+  if (argc == 9 && strcmp(argv[8], "wallz") == 0) {
+    /* as a run with walls in z has it: the metadata prints the periodicity */
+    int periodic[3] = {1, 1, 0};
+    cs_periodicity_set(cs, periodic);
+  }
   cs_init(cs);
   {
     lb_data_options_t opts = lb_data_options_default();

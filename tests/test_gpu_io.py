@@ -279,3 +279,86 @@ def test_single_mode_files(name, nvel, tmp_path):
         assert meta[4] == "Number of processors:            2"
         assert meta[12:] == ["%3d %3d %3d %3d %d %d %d %d %d %d" % (r, r, 0, 0, half, n[1], n[2],
                                                                      r * half, 0, 0) for r in (0, 1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ascii_", [False, True], ids=["binary", "ascii"])
+def test_several_files_along_the_slabs(ascii_, tmp_path):
+    """distribution_io_grid 2_1_1 over four X slabs (io_subfile_create,
+    io_subfile.c:49-91): slabs 0, 1 write file 1 of 2, slabs 2, 3 file 2 of 2,
+    each its byte range at its planes' position in the FILE
+    (io_impl_mpio.c:179-272). The two files one after the other are the
+    one-file record stream of the whole lattice (which is pinned by the
+    reference's files); each has its metadata; reading them back into the
+    slabs restores the state; planes outside the file named are refused."""
+    import json
+    import ludwig_amd
+    rng = np.random.default_rng(11)
+    n = (8, 5, 4)
+    nslab = [2, 2, 3, 1]                # (cs_init allows unequal parts)
+    f = np.zeros((19, n[0] + 2, n[1] + 2, n[2] + 2))
+    interior(f, 1)[...] = rng.random((19,) + n)
+    whole = tmp_path / "whole"
+    whole.mkdir()
+    lb = ludwig_amd.LB(19, n, 1)
+    lb.io_format_set(ascii_)
+    lb.lb_memcpy_h2d(f)
+    lb.lb_io_write(whole, 5)
+    lb.synchronize()
+    lb.free()
+    stream = open(whole / "dist-000000005.001-001", "rb").read()
+
+    x0 = [0, 2, 4, 7]
+    files = [(0, 4, 0), (0, 4, 0), (1, 4, 4), (1, 4, 4)]        # index, planes, first plane
+    for r in (3, 1, 0, 2):
+        lb = ludwig_amd.LB(19, (nslab[r], n[1], n[2]), 1, cartsz=4, cartrank=r)
+        lb.io_format_set(ascii_)
+        lb.io_file_set(2, files[r][0], files[r][1], files[r][2])
+        lb.lb_memcpy_h2d(np.ascontiguousarray(f[:, x0[r]:x0[r] + nslab[r] + 2]))
+        lb.lb_io_write(tmp_path, 5, ntotal_x=n[0], offset_x=x0[r])
+        lb.synchronize()
+        if r == 3:
+            with pytest.raises(Exception):
+                lb.io_file_set(2, 0, 4, 0)             # plane 7 is not in file 1
+                lb.lb_io_write(tmp_path, 5, ntotal_x=n[0], offset_x=x0[r])
+        lb.free()
+    one = open(tmp_path / "dist-000000005.001-002", "rb").read()
+    two = open(tmp_path / "dist-000000005.002-002", "rb").read()
+    assert one + two == stream and len(one) == len(two)
+    for i in (0, 1):
+        m = json.load(open(tmp_path / ("dist-metadata.%3.3d-002" % (i + 1))))
+        assert m["io_subfile"]["File index"] == i and m["io_subfile"]["Number of files"] == 2
+        assert m["io_subfile"]["File size (sites)"] == [4, 5, 4]
+        assert m["io_subfile"]["File offset (sites)"] == [4 * i, 0, 0]
+    for r in range(4):
+        lb = ludwig_amd.LB(19, (nslab[r], n[1], n[2]), 1, cartsz=4, cartrank=r)
+        lb.io_format_set(ascii_)
+        lb.io_file_set(2, files[r][0], files[r][1], files[r][2])
+        lb.lb_io_read(tmp_path, 5, ntotal_x=n[0], offset_x=x0[r])
+        back = interior(lb.lb_memcpy_d2h(), 1)
+        ref = f[:, x0[r] + 1:x0[r] + 1 + nslab[r], 1:-1, 1:-1]
+        if ascii_:
+            assert np.max(np.abs(back - ref)) <= 1e-15
+        else:
+            assert np.array_equal(back, ref)
+        lb.free()
+
+
+@pytest.mark.gpu
+def test_metadata_says_what_is_periodic(tmp_path):
+    """A run with walls in z: lb_io_write prints [1, 1, 0] (fixture from the
+    compiled reference with cs_periodicity_set)."""
+    import ludwig_amd
+    g = load_io_golden("io_q19_wallz")
+    n = _nlocal(g)
+    lb = ludwig_amd.LB(19, n, 1)
+    lb.io_file_set(1, 0, n[0], 0, periodic=(1, 1, 0))
+    lb.lb_memcpy_h2d(g["f0"])
+    lb.lb_io_write(tmp_path, g["timestep"])
+    lb.synchronize()
+    assert open(tmp_path / "dist-metadata.001-001").read() == g["metadata"]
+    assert open(tmp_path / g["datafile"], "rb").read() == g["data"]
+    lb.io_file_set(None)
+    lb.lb_io_write(tmp_path, g["timestep"])
+    assert "[1, 1, 1]" in open(tmp_path / "dist-metadata.001-001").read()
+    lb.free()

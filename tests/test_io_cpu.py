@@ -166,3 +166,43 @@ def test_reference_reads_our_single_mode_file(name, nvel, tmp_path):
                    check=True, stdout=subprocess.DEVNULL)
     back = np.fromfile(tmp_path / "readback.f.f64", dtype="<f8").reshape(f.shape)
     assert np.array_equal(interior(back, 1), interior(f, 1))
+
+
+def test_metadata_of_a_lattice_that_is_not_periodic(tmp_path):
+    """cs_to_json prints the periodicity: a run with walls in z writes
+    [1, 1, 0] (fixture from the compiled reference)."""
+    import ludwig_amd
+    g = load_io_golden("io_q19_wallz")
+    ludwig_amd.io_metadata_write_file(tmp_path, "dist", 19, 1, _nlocal(g), periodic=(1, 1, 0))
+    assert open(tmp_path / "dist-metadata.001-001").read() == g["metadata"]
+
+
+def test_metadata_of_one_file_of_several(tmp_path):
+    """distribution_io_grid 3_1_1 over slabs: file 2 of 3 holding planes
+    4..7 of 10. The keys io_subfile_to_json / io_options_to_json print
+    (io_subfile.c:102-130) with the values io_subfile_create computes
+    (:49-91); everything else as in the one-file metadata, which is pinned.
+    No serial run of the reference writes several files: unpinned."""
+    import json
+    import ludwig_amd
+    n = (10, 4, 6)
+    ludwig_amd.io_metadata_write_file(tmp_path, "dist", 19, 1, n)
+    one = json.load(open(tmp_path / "dist-metadata.001-001"))
+    ludwig_amd.io_metadata_write_file(tmp_path, "dist", 19, 1, n, nfile=3, index=1,
+                                      file_nx=4, file_x0=3)
+    text = open(tmp_path / "dist-metadata.002-003").read()
+    two = json.loads(text)
+    assert two["io_subfile"] == {"Number of files": 3, "File index": 1, "Topology": [3, 1, 1],
+                                 "Coordinate": [1, 0, 0], "Data ndims": 3,
+                                 "File size (sites)": [4, 4, 6], "File offset (sites)": [3, 0, 0]}
+    assert two["io_options"]["I/O grid"] == [3, 1, 1]
+    two["io_subfile"] = one["io_subfile"]
+    two["io_options"]["I/O grid"] = [1, 1, 1]
+    assert two == one
+    assert list(two) == list(one) and text.startswith('{\n\t"coords":\t{\n')
+    with pytest.raises(Exception):       # planes outside the lattice
+        ludwig_amd.io_metadata_write_file(tmp_path, "dist", 19, 1, n, nfile=3, index=2,
+                                          file_nx=4, file_x0=8)
+    with pytest.raises(Exception):       # several old-style files are another mode
+        ludwig_amd.io_metadata_write_file(tmp_path, "dist", 19, 1, n, nfile=2, index=0,
+                                          file_nx=5, file_x0=0, single=True)
