@@ -451,3 +451,94 @@ def test_f_rewritten_between_collide_and_halo_of_a_fused_slab_step(world, blocke
         lbo.propagate(p, f, fp)
         f, fp = fp, f
     assert relmax(_join(out, 0), interior(f, 1)) < 1e-12
+
+
+@pytest.mark.parametrize("mode_name", ["eager", "fused_halo"])
+@pytest.mark.parametrize("dim", [0, 2], ids=["x", "z"])
+@pytest.mark.parametrize("bnd", [(1, 0, 0), (0, 1, 1), (1, 1, 1)], ids=["x", "yz", "xyz"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_walls_on_slabs_equal_single_domain(world, bnd, dim, mode_name):
+    """Flat moving walls (wall_init_map, wall_init_boundaries, wall_bbl:
+    wall.c:399-451, 960-1107, 1219-1268) on a lattice cut into slabs: every
+    rank marks and links ITS part -- in the decomposed direction only the
+    first rank has the low wall and only the last one the high wall (noffset
+    in wall.c:1236-1240) -- and bounces back between lb_halo and
+    lb_propagation. The joined slabs are the single domain's distributions
+    (whose wall steps are checked against the compiled reference's fixtures in
+    test_gpu_wall.py) and the ranks' wall momenta add up to its momentum."""
+    import ludwig_amd
+    import torch
+    mode = {"eager": ludwig_amd.EAGER, "fused_halo": ludwig_amd.FUSED_HALO}[mode_name]
+    nvel, ntotal, nsteps = 19, (12, 6, 12), 6
+    ubot, utop = (0.0, 0.01, 0.002), (0.003, -0.02, 0.0)
+    p = lbo.make_param(nvel, ntotal, 1, "m10", 0.1, 0.3, 1.0, FBODY)
+    f0 = lbo.init_synthetic(p)
+
+    def steps(lb, hy):
+        for _ in range(nsteps):
+            lb.lb_collide(hy)
+            lb.lb_halo()
+            lb.wall_bbl()
+            lb.lb_propagation()
+
+    def walls(lb):
+        hy = ludwig_amd.Hydro(lb.nall, lb.device, status=np.zeros(lb.nall, dtype=np.int8))
+        torch.cuda.synchronize()
+        lb.wall_map(bnd, hy.status)
+        n = lb.wall_links_build(hy.status, bnd)
+        lb.wall_velocity_set(ubot, utop)
+        return hy, n
+
+    lb = ludwig_amd.LB(nvel, ntotal, 1, mode=mode)
+    lb.relaxation_set("m10", 0.1, 0.3)
+    lb.body_force_set(FBODY)
+    hy, nlink = walls(lb)
+    lb.lb_memcpy_h2d(f0)
+    steps(lb, hy)
+    ref = interior(lb.lb_memcpy_d2h(), 1).copy()
+    fnet = lb.wall_momentum()
+    lb.free()
+
+    ring = ludwig_amd.Ring(world)
+    out = [None] * world
+    err = []
+    start = threading.Barrier(world)
+
+    def rank_main(rank):
+        try:
+            dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, 1, dim=dim)
+            lb = ludwig_amd.LB(nvel, dec.nlocal, 1, mode=mode, cartsz=world,
+                               cartrank=rank, own_stream=True, cartdim=dim)
+            lb.relaxation_set("m10", 0.1, 0.3)
+            lb.body_force_set(FBODY)
+            lb.comm_init_ring(ring)
+            hy, n = walls(lb)
+            sl = [slice(None)] * 4
+            sl[1 + dim] = slice(dec.noffset[dim], dec.noffset[dim] + dec.nlocal[dim] + 2)
+            lb.lb_memcpy_h2d(np.ascontiguousarray(f0[tuple(sl)]))
+            start.wait()
+            steps(lb, hy)
+            f = interior(lb.lb_memcpy_d2h(), 1).copy()
+            out[rank] = (f, lb.wall_momentum(), n)
+            lb.synchronize()
+            torch.cuda.synchronize()
+            start.wait()
+            lb.free()
+        except Exception as e:           # noqa: BLE001
+            err.append((rank, repr(e)))
+            ring.abort()
+            start.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not err, err
+    assert all(not t.is_alive() for t in threads)
+    ring.free()
+    assert sum(o[2] for o in out) == nlink
+    got = _join(out, 0, dim)
+    # (sites next to a wall in the decomposed direction included)
+    assert relmax(got, ref) < 1e-13
+    assert np.max(np.abs(sum(o[1] for o in out) - fnet)) < 1e-12 * max(1.0, np.abs(fnet).max())
