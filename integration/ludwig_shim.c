@@ -36,8 +36,8 @@
  *      cahn_hilliard_stats(), cahn_hilliard_stats_time0()
  *                        cahn_hilliard_stats.h: the statistics of phi
  *      phi_force_calculation() phi_force.h, phi_cahn_hilliard()
- *                        phi_cahn_hilliard.h: with LBMI_FE=1 and the symmetric
- *                        free energy in the plain periodic fluid case
+ *                        phi_cahn_hilliard.h: the symmetric free energy in
+ *                        the plain periodic fluid case (LBMI_FE=0: never)
  *
  *  by unpacking lb_t / hydro_t / map_t and calling the C-ABI of
  *  include/lbmi.h. The other contents of collision.c / model.c /
@@ -1436,7 +1436,7 @@ int stats_distribution_momentum(lb_t * lb, map_t * map, double g[3]) {
 /*****************************************************************************
  *
  *  phi_force_calculation (phi_force.c:74-136), phi_cahn_hilliard
- *  (phi_cahn_hilliard.c:206-284): row f2, with LBMI_FE=1
+ *  (phi_cahn_hilliard.c:206-284): row f2 (LBMI_FE=0 leaves them to the original)
  *
  *  One kernel each in place of pth_stress_compute + pth_force_fluid_driver
  *  (a 9-component stress array in between) and of advection_x + the flux
@@ -1453,8 +1453,10 @@ int stats_distribution_momentum(lb_t * lb, map_t * map, double g[3]) {
 static int shim_fe_wanted(void) {
   static int wanted = -1;
   if (wanted < 0) {
+    /* on unless LBMI_FE=0: every call checks the one case it was written
+     * for and runs the original otherwise */
     const char * e = getenv("LBMI_FE");
-    wanted = (e != NULL && e[0] == '1');
+    wanted = !(e != NULL && e[0] == '0');
   }
   return wanted;
 }
@@ -1498,7 +1500,7 @@ int phi_force_calculation(pe_t * pe, cs_t * cs, lees_edw_t * le, wall_t * wall,
     shim_grad_arrays(fs->dphi, &grad, &delsq);
     {
       static int told = 0;
-      if (!told) pe_info(pe, "liblbmi: phi_force_calculation bound (LBMI_FE=1)\n");
+      if (!told) pe_info(pe, "liblbmi: phi_force_calculation bound (LBMI_FE=0: the original)\n");
       told = 1;
     }
     /* F_a -= d_b P_ab at the interior sites, from the arrays the (bound)
@@ -1557,7 +1559,7 @@ int phi_cahn_hilliard(phi_ch_t * pch, fe_t * fe, field_t * phi,
     }
     {
       static int told = 0;
-      if (!told) pe_info(pch->pe, "liblbmi: phi_cahn_hilliard bound (LBMI_FE=1)\n");
+      if (!told) pe_info(pch->pe, "liblbmi: phi_cahn_hilliard bound (LBMI_FE=0: the original)\n");
       told = 1;
     }
     SHIM_CHECK(shim_.lb, lbmi_fe_scheme_set(shim_.h, npt, order));

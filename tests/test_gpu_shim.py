@@ -415,26 +415,30 @@ def _droplet_checks(log, ref):
 
 @pytest.mark.parametrize("mode", ["halo", "fused"])
 def test_ludwig_droplet_with_the_free_energy_sector_bound(mode):
-    """LBMI_FE=1: phi_force_calculation and phi_cahn_hilliard of the binding
+    """No switch set: phi_force_calculation and phi_cahn_hilliard of the binding
     (one kernel each, no stress array, no flux arrays) in place of the
     reference's pth_* / advection_* / phi_ch_* kernels, on top of everything
     else: twenty coupled steps of the relaxing droplet iodrop-mpi1-io1 (27-point
     gradients, second-order advection), the report after step 20."""
     ref = _json.load(open(os.path.join(HERE, "golden", "regression_symmetric_drop.json")))
     ref = ref["iodrop-mpi1-io1"]["reports"]["20"]
-    log = _ludwig("iodrop.inp", mode, extra_env={"LBMI_FE": "1"})
+    log = _ludwig("iodrop.inp", mode)
     assert "phi_force_calculation bound" in log and "phi_cahn_hilliard bound" in log
+    _droplet_checks(log, ref)
+    # LBMI_FE=0: the reference's own kernels for the free-energy sector
+    log = _ludwig("iodrop.inp", mode, extra_env={"LBMI_FE": "0"})
+    assert "phi_force_calculation bound" not in log and "phi_cahn_hilliard bound" not in log
     _droplet_checks(log, ref)
 
 
 @pytest.mark.parametrize("name", ["spin_fd1", "symm_pat"])
 def test_ludwig_more_regressions_with_the_free_energy_sector_bound(name):
     """spin_fd1 (spinodal quench, ten steps), symm_pat (ONE step from a patchy
-    phi: steep gradients, large forces) with LBMI_FE=1: the handle of the
+    phi: steep gradients, large forces), no switch set: the handle of the
     binding exists from the lb_memcpy of ludwig.c:507 on, so the first step's
     free-energy sector is bound as well."""
     ref = _json.load(open(os.path.join(HERE, "golden", "regression_app_extra.json")))[name]
-    log = _ludwig(name + ".inp", None, extra_env={"LBMI_FE": "1"})
+    log = _ludwig(name + ".inp", None)
     assert "phi_force_calculation bound" in log and "phi_cahn_hilliard bound" in log
     rho = _last(log, "[rho]")
     assert rho[0] == ref["rho"][0]
@@ -451,12 +455,12 @@ def test_ludwig_more_regressions_with_the_free_energy_sector_bound(name):
 
 
 def test_the_free_energy_binding_leaves_other_cases_to_the_reference():
-    """LBMI_FE=1 on a case outside its conditions (symmetric_lb: two
-    distributions, no finite-difference order parameter): nothing is bound,
-    the log is the reference's."""
+    """A case outside the conditions of the free-energy binding
+    (symmetric_lb: two distributions, no finite-difference order parameter):
+    nothing of that sector is bound, the log is the reference's."""
     ref = _json.load(open(os.path.join(HERE, "golden", "regression_app_extra.json")))["spin_lb1"]
-    log = _ludwig("spin_lb1.inp", None, extra_env={"LBMI_FE": "1"})
-    assert "bound (LBMI_FE=1)" not in log
+    log = _ludwig("spin_lb1.inp", None)
+    assert "phi_force_calculation bound" not in log and "phi_cahn_hilliard bound" not in log
     rho = _last(log, "[rho]")
     assert rho[0] == ref["rho"][0] and abs(rho[2] - ref["rho"][2]) <= 1e-12
 
