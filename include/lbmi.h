@@ -610,6 +610,16 @@ int lbmi_symmetric_lb_step(lbmi_t * lb, const lbmi_hydro_t * hydro,
 			   const double * u_prev, double a, double b,
 			   double kappa, double mobility, const double * phi,
 			   double * phi_out);
+/* The same up to and including lb_collide -- hydro_f_zero,
+ * phi_force_calculation, phi_cahn_hilliard, lb_collide in one call, ONE kernel
+ * under the same conditions -- for a caller whose loop goes on to call lb_halo
+ * and lb_propagation itself (ludwig.c does; the binding defers the calls of
+ * the free-energy sector up to lb_collide and lands here): afterwards the
+ * handle is where lbmi_lb_collide leaves it. */
+int lbmi_symmetric_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro,
+			      const double * u_prev, double a, double b,
+			      double kappa, double mobility, const double * phi,
+			      double * phi_out);
 
 /* The same single pass, with the gradients taken from the arrays grad and
  * delsq of lbmi_field_grad (valid on the interior and one layer around it)

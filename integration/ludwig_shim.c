@@ -121,6 +121,7 @@
 #include "fe_force_method.h"
 #include "lb_bc_inflow_rhou.h"
 #include "lb_bc_outflow_rhou.h"
+#include "control.h"
 
 #include "lbmi.h"
 
@@ -255,6 +256,51 @@ typedef struct shim_s {
 static shim_t shim_;              /* zero: no handle, LBMI_MODE_EAGER */
 static int shim_openbc_ = 0;      /* open-boundary objects created (below) */
 
+/* The free-energy sector folded into the collision (the symmetric free energy
+ * in the plain periodic one-rank case, BASELINE config 4): ludwig.c:563-802
+ * calls field_halo(phi), field_grad_compute, phi_force_calculation,
+ * phi_cahn_hilliard, hydro_u_zero and lb_collide one after the other. When
+ * the step before went through all of them in the case the binding covers,
+ * the calls of this step are only noted as they come, and lb_collide runs
+ * lbmi_symmetric_lb_collide: ONE kernel in which the thread that collides a
+ * site evaluates its force and its Cahn-Hilliard update from the phi around
+ * it (no gradient arrays, no force array, no halo swaps of phi and u).
+ * Whatever comes out of turn -- any other bound symbol, another object, a
+ * call that does not qualify -- first runs what was noted, in order
+ * (shim_fuse_flush). Not on a step that reports or writes anything
+ * (control.c's is_*_step): there every array is what the reference has.
+ * What stays behind on a folded step: the halo of phi, the gradient arrays
+ * and hydro->force are not refreshed (their readers are the calls folded),
+ * phi and hydro->u hold the new values at the interior sites. */
+
+enum {FUSE_NONE = 0, FUSE_HALO, FUSE_GRAD, FUSE_FORCE, FUSE_CH, FUSE_UZERO};
+
+typedef struct shim_fuse_s {
+  int armed;                      /* the step before qualified */
+  int stage;                      /* what has been noted this step */
+  int cand;                       /* normal step: bit 0 force, bit 1 CH bound */
+  /* the objects of the sequence */
+  field_t * phi;
+  field_grad_t * fgrad;
+  hydro_t * hydro;
+  phi_ch_t * pch;
+  fe_t * fe;
+  /* the arguments of the noted calls */
+  pe_t * pe; cs_t * cs; lees_edw_t * le; wall_t * wall; pth_t * pth;
+  map_t * map_force; map_t * map_ch; noise_t * noise;
+  double uzero[3];
+  /* candidates seen on a normal step */
+  field_grad_t * seen_fgrad;
+  /* device scratch: the new phi, the old u */
+  double * phinew; double * uprev; size_t sites;
+  int nfused;                     /* collisions that took the sector along */
+} shim_fuse_t;
+
+static shim_fuse_t fuse_;
+
+static void shim_fuse_flush(void);
+static int shim_fuse_wanted(void);
+
 static const char * shim_mode_name(int mode) {
   if (mode == LBMI_MODE_FUSED) return "fused";
   if (mode == LBMI_MODE_FUSED_HALO) return "halo";
@@ -271,9 +317,10 @@ static void shim_report_policy(void) {
   const shim_t * sh = (shim_.h != NULL) ? &shim_ : &shim_ended_;
   if (sh->lb == NULL) return;
   fprintf(stderr, "liblbmi report: execution mode %s (%s); rho, u on demand in "
-	  "%d of %d collisions, rho alone in %d\n", shim_mode_name(sh->mode),
+	  "%d of %d collisions, rho alone in %d; free-energy sector folded into "
+	  "%d\n", shim_mode_name(sh->mode),
 	  sh->automode ? "chosen by the binding" : "LBMI_MODE",
-	  sh->nlazy, sh->ncollide, sh->nlazy_rho);
+	  sh->nlazy, sh->ncollide, sh->nlazy_rho, fuse_.nfused);
 }
 
 #define SHIM_CHECK(lb, call)						\
@@ -540,6 +587,8 @@ static void shim_hydro_foreign(hydro_t * hydro) {
 }
 
 static void shim_needs_canonical_f(lb_t * lb, const char * who);
+static int shim_fuse_collide_ok(lb_t * lb, hydro_t * hydro, noise_t * noise,
+				fe_t * fe, visc_t * visc);
 
 /*****************************************************************************
  *
@@ -554,6 +603,14 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
 
   assert(lb);
   assert(map);
+
+  /* the free-energy sector noted on the way here: taken along below if this
+   * collision qualifies, run now if not */
+  if (fuse_.stage != FUSE_NONE &&
+      !(fuse_.stage == FUSE_UZERO &&
+	shim_fuse_collide_ok(lb, hydro, noise, fe, visc))) {
+    shim_fuse_flush();
+  }
 
   /* Not covered by liblbmi: fluctuations, stress relaxation with a free
    * energy other than the symmetric one; two
@@ -581,6 +638,8 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
        * remembers about their contents holds after this call */
       shim_hydro_foreign(hydro);
     }
+    fuse_.armed = 0;
+    fuse_.cand = 0;
     return lb_collide_ref(lb, hydro, map, noise, fe, visc);
   }
 
@@ -656,7 +715,10 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
      * subgrid_force_from_particles (colloids, ludwig.c:2071, 2149) -- is
      * outside the library: with a free energy or colloids the force is taken
      * to have been written every step. */
-    if (fe != NULL || shim_.colloids || shim_.ncollide == 0) {
+    if (fuse_.stage == FUSE_UZERO) {
+      /* (folded step: nobody has written to the force since hydro_f_zero) */
+    }
+    else if (fe != NULL || shim_.colloids || shim_.ncollide == 0) {
       /* (the first collision: colloids show at the first
        * bounce_back_on_links, after it) */
       SHIM_CHECK(lb, lbmi_hydro_field_dirty(h, hy.force));
@@ -710,7 +772,49 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
       SHIM_CHECK(lb, lbmi_tune(h, "hydro_lazy", lazy));
     }
 
-    if (lb->ndist == 2 || (fe && fe->use_stress_relaxation)) {
+    if (fuse_.stage == FUSE_UZERO) {
+      /* hydro_f_zero .. lb_collide of this step in one call */
+      fe_symm_t * fs = (fe_symm_t *) fe;
+      fe_symm_param_t param;
+      double mobility = 0.0;
+      int order = 0;
+      size_t nsites = (size_t) fuse_.phi->nsites;
+      double * phid = shim_field_data(fuse_.phi);
+      fe_symm_param(fs, &param);
+      physics_mobility(phys, &mobility);
+      advection_order(&order);
+      if (fuse_.sites < nsites) {
+	if (fuse_.phinew) tdpAssert(tdpFree(fuse_.phinew));
+	if (fuse_.uprev) tdpAssert(tdpFree(fuse_.uprev));
+	tdpAssert(tdpMalloc((void **) &fuse_.phinew, sizeof(double)*nsites));
+	tdpAssert(tdpMalloc((void **) &fuse_.uprev, 3*sizeof(double)*nsites));
+	fuse_.sites = nsites;
+      }
+      {
+	static int told = 0;
+	if (!told) pe_info(lb->pe, "liblbmi: free-energy sector folded into lb_collide "
+			   "(LBMI_FE=1: call by call)\n");
+	told = 1;
+      }
+      SHIM_CHECK(lb, lbmi_fe_scheme_set(h, fuse_.fgrad->d2 == grad_3d_7pt_fluid_d2 ? 7 : 27,
+					order));
+      /* the velocities of the previous collision are read at the neighbours
+       * while the new ones are written: from a copy (ONE hydro->u here) */
+      SHIM_CHECK(lb, lbmi_field_interior_copy(h, 3, hy.u, fuse_.uprev));
+      SHIM_CHECK(lb, lbmi_symmetric_lb_collide(h, &hy, fuse_.uprev, param.a, param.b,
+					       param.kappa, mobility, phid,
+					       fuse_.phinew));
+      /* the reference updates phi in place */
+      SHIM_CHECK(lb, lbmi_field_interior_copy(h, 1, fuse_.phinew, phid));
+      shim_note(S_FIELD_HALO, 1);
+      shim_note(S_FIELD_GRAD_COMPUTE, 1);
+      shim_note(S_PHI_FORCE_CALCULATION, 1);
+      shim_note(S_PHI_CAHN_HILLIARD, 1);
+      shim_note(S_HYDRO_U_ZERO, 1);
+      fuse_.stage = FUSE_NONE;
+      fuse_.nfused += 1;
+    }
+    else if (lb->ndist == 2 || (fe && fe->use_stress_relaxation)) {
       /* lb_collision_binary (collision.c:610-1027), or the single-fluid
        * collision with the symmetric stress relaxed (:413-429) */
       fe_symm_t * fs = (fe_symm_t *) fe;
@@ -736,6 +840,15 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
     }
     shim_note(S_LB_COLLIDE, 1);
     shim_sync_pointers(lb, h);                   /* FUSED swaps here */
+
+    /* did this step go through the whole sequence in the case covered? Then
+     * the next one may be folded */
+    if (!fuse_.armed && fuse_.cand == 3 && shim_fuse_wanted() &&
+	fuse_.seen_fgrad != NULL && fuse_.seen_fgrad->field == fuse_.phi) {
+      fuse_.fgrad = fuse_.seen_fgrad;
+      fuse_.armed = shim_fuse_collide_ok(lb, hydro, noise, fe, visc);
+    }
+    fuse_.cand = 0;
   }
 
   return 0;
@@ -748,6 +861,7 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
  *****************************************************************************/
 
 int phi_lb_to_field(field_t * phi, lb_t * lb) {
+  shim_fuse_flush();
 
   assert(phi);
   assert(lb);
@@ -814,6 +928,7 @@ static void shim_needs_canonical_f(lb_t * lb, const char * who) {
 }
 
 int wall_bbl(wall_t * wall) {
+  shim_fuse_flush();
 
   assert(wall);
   assert(wall->target);
@@ -851,6 +966,7 @@ int wall_bbl(wall_t * wall) {
  *****************************************************************************/
 
 int wall_set_wall_distributions(wall_t * wall) {
+  shim_fuse_flush();
 
   assert(wall);
 
@@ -862,6 +978,7 @@ int wall_set_wall_distributions(wall_t * wall) {
 
 int bounce_back_on_links(bbl_t * bbl, lb_t * lb, wall_t * wall,
 			 colloids_info_t * cinfo) {
+  shim_fuse_flush();
   int ntotal = 0;
 
   assert(lb);
@@ -914,6 +1031,9 @@ int lb_bc_outflow_rhou_create(pe_t * pe, cs_t * cs,
  *****************************************************************************/
 
 int lb_free(lb_t * lb) {
+  shim_fuse_flush();
+  fuse_.armed = 0;
+  fuse_.cand = 0;
   assert(lb);
   if (shim_.lb == lb) {
     /* the handle borrows lb->target->f / fprime: it goes first */
@@ -927,6 +1047,12 @@ int lb_free(lb_t * lb) {
 }
 
 int field_free(field_t * obj) {
+  shim_fuse_flush();
+  if (obj == fuse_.phi) {
+    fuse_.armed = 0;
+    fuse_.cand = 0;
+    fuse_.phi = NULL;
+  }
   if (shim_.h != NULL && obj != NULL) {
     /* "known to hold zeros" is kept by device address: the next allocation
      * may get this one */
@@ -941,6 +1067,12 @@ int field_free(field_t * obj) {
 }
 
 void field_grad_free(field_grad_t * obj) {
+  shim_fuse_flush();
+  if (obj == fuse_.fgrad || obj == fuse_.seen_fgrad) {
+    fuse_.armed = 0;
+    fuse_.fgrad = NULL;
+    fuse_.seen_fgrad = NULL;
+  }
   if (obj) {
     shim_forget(&obj->grad);
     shim_forget(&obj->delsq);
@@ -975,6 +1107,7 @@ int wall_free(wall_t * wall) {
  *****************************************************************************/
 
 int lb_halo_swap(lb_t * lb, lb_halo_enum_t flag) {
+  shim_fuse_flush();
 
   assert(lb);
 
@@ -1002,6 +1135,7 @@ int lb_halo(lb_t * lb) {
  *****************************************************************************/
 
 int lb_propagation(lb_t * lb) {
+  shim_fuse_flush();
 
   assert(lb);
 
@@ -1027,6 +1161,7 @@ int lb_propagation(lb_t * lb) {
  *****************************************************************************/
 
 int lb_memcpy(lb_t * lb, tdpMemcpyKind flag) {
+  shim_fuse_flush();
 
   assert(lb);
 
@@ -1128,6 +1263,7 @@ static void shim_io_file(lb_t * lb, const io_metadata_t * meta) {
 }
 
 int lb_io_write(lb_t * lb, int timestep, io_event_t * event) {
+  shim_fuse_flush();
 
   int fmt = 0;
 
@@ -1170,6 +1306,7 @@ int lb_io_write(lb_t * lb, int timestep, io_event_t * event) {
 }
 
 int lb_io_read(lb_t * lb, int timestep, io_event_t * event) {
+  shim_fuse_flush();
 
   int fmt = 0;
 
@@ -1235,6 +1372,7 @@ static lbmi_t * shim_handle_if_any(cs_t * cs) {
 }
 
 int hydro_memcpy(hydro_t * hydro, tdpMemcpyKind flag) {
+  shim_fuse_flush();
   assert(hydro);
   if (shim_.h != NULL) {
     /* device -> host: rho, u still owed by a lazy collision are formed first;
@@ -1252,7 +1390,22 @@ int hydro_memcpy(hydro_t * hydro, tdpMemcpyKind flag) {
   }
 }
 
+static int shim_hydro_u_zero_now(hydro_t * hydro, const double uzero[3]);
+
 int hydro_u_zero(hydro_t * hydro, const double uzero[3]) {
+  assert(hydro);
+  if (fuse_.stage == FUSE_CH && hydro == fuse_.hydro &&
+      uzero[X] == 0.0 && uzero[Y] == 0.0 && uzero[Z] == 0.0) {
+    /* (the collision that follows writes u at every interior site, and the
+     * Cahn-Hilliard update noted before it still wants the old values) */
+    fuse_.stage = FUSE_UZERO;
+    return 0;
+  }
+  shim_fuse_flush();
+  return shim_hydro_u_zero_now(hydro, uzero);
+}
+
+static int shim_hydro_u_zero_now(hydro_t * hydro, const double uzero[3]) {
   lbmi_t * h = NULL;
   assert(hydro);
   h = shim_handle_if_any(hydro->cs);
@@ -1265,6 +1418,7 @@ int hydro_u_zero(hydro_t * hydro, const double uzero[3]) {
 int hydro_f_zero(hydro_t * hydro, const double fzero[3]) {
   lbmi_t * h = NULL;
   assert(hydro);
+  shim_fuse_flush();
   h = shim_handle_if_any(hydro->cs);
   if (h == NULL || hydro->nsite != shim_.lb->nsite) return hydro_f_zero_ref(hydro, fzero);
   shim_note(S_HYDRO_F_ZERO, 1);
@@ -1276,7 +1430,21 @@ int hydro_f_zero(hydro_t * hydro, const double fzero[3]) {
  * the halo of the lattice (hydro_u_halo comes through here as well,
  * hydro.c:190-197) */
 
+static int shim_field_halo_now(field_t * field);
+static int shim_fuse_special_step(void);
+
 int field_halo(field_t * field) {
+  assert(field);
+  if (fuse_.armed && fuse_.stage == FUSE_NONE && field == fuse_.phi &&
+      shim_.h != NULL && shim_.mode == LBMI_MODE_FUSED && !shim_fuse_special_step()) {
+    fuse_.stage = FUSE_HALO;
+    return 0;
+  }
+  shim_fuse_flush();
+  return shim_field_halo_now(field);
+}
+
+static int shim_field_halo_now(field_t * field) {
   lbmi_t * h = NULL;
   int nhalo = 0;
   int nlocal[3];
@@ -1302,7 +1470,19 @@ int field_halo(field_t * field) {
 /* field_grad_compute for a scalar with the fluid-only 7- or 27-point
  * stencils at level 2 (grad and delsq); anything else is the original */
 
+static int shim_field_grad_compute_now(field_grad_t * fgrad);
+
 int field_grad_compute(field_grad_t * fgrad) {
+  assert(fgrad);
+  if (fuse_.stage == FUSE_HALO && fgrad == fuse_.fgrad) {
+    fuse_.stage = FUSE_GRAD;
+    return 0;
+  }
+  shim_fuse_flush();
+  return shim_field_grad_compute_now(fgrad);
+}
+
+static int shim_field_grad_compute_now(field_grad_t * fgrad) {
   lbmi_t * h = NULL;
   double * grad = NULL;
   double * delsq = NULL;
@@ -1317,6 +1497,7 @@ int field_grad_compute(field_grad_t * fgrad) {
     return field_grad_compute_ref(fgrad);
   }
   shim_note(S_FIELD_GRAD_COMPUTE, 1);
+  if (fgrad->nf == 1) fuse_.seen_fgrad = fgrad;   /* (a candidate for the sequence) */
   shim_grad_arrays(fgrad, &grad, &delsq);
   if (npt == 7) {
     SHIM_CHECK(shim_.lb, lbmi_field_grad_7pt(h, shim_field_data(fgrad->field),
@@ -1347,6 +1528,7 @@ int field_grad_compute(field_grad_t * fgrad) {
  *****************************************************************************/
 
 int stats_distribution_print(lb_t * lb, map_t * map) {
+  shim_fuse_flush();
 
   assert(lb);
   assert(map);
@@ -1404,6 +1586,7 @@ int stats_distribution_print(lb_t * lb, map_t * map) {
 }
 
 int stats_distribution_momentum(lb_t * lb, map_t * map, double g[3]) {
+  shim_fuse_flush();
 
   assert(lb);
   assert(map);
@@ -1454,11 +1637,84 @@ static int shim_fe_wanted(void) {
   static int wanted = -1;
   if (wanted < 0) {
     /* on unless LBMI_FE=0: every call checks the one case it was written
-     * for and runs the original otherwise */
+     * for and runs the original otherwise. LBMI_FE=1: bound call by call,
+     * never folded into the collision. */
     const char * e = getenv("LBMI_FE");
     wanted = !(e != NULL && e[0] == '0');
+    if (wanted && e != NULL && e[0] == '1') wanted = 2;
   }
   return wanted;
+}
+
+static int shim_fuse_wanted(void) {
+  return shim_fe_wanted() == 1;
+}
+
+/* a step on which ludwig.c reports or writes something (ludwig.c:868-960) */
+
+static int shim_fuse_special_step(void) {
+  return is_statistics_step() || is_measurement_step() || is_config_step() ||
+    is_colloid_io_step() || is_phi_output_step() || is_vel_output_step() ||
+    is_psi_output_step() || is_fed_output_step() ||
+    is_shear_measurement_step() || is_shear_output_step();
+}
+
+/* lb_collide with the sector noted in front of it: the plain periodic
+ * one-rank two-phase fluid, nothing else at work on f, u or phi */
+
+static int shim_fuse_collide_ok(lb_t * lb, hydro_t * hydro, noise_t * noise,
+				fe_t * fe, visc_t * visc) {
+  int cartsz[3], periodic[3], nlocal[3];
+  int nhalo = 0;
+  if (!shim_fuse_wanted() || !shim_supported(lb)) return 0;
+  if (shim_.h == NULL || shim_.lb != lb || shim_.mode != LBMI_MODE_FUSED) return 0;
+  if (lb->ndist != 1 || visc != NULL || shim_.colloids || shim_openbc_ != 0) return 0;
+  if (noise != NULL && noise->on[NOISE_RHO]) return 0;
+  if (fe == NULL || fe != fuse_.fe || fe->id != FE_SYMMETRIC ||
+      fe->use_stress_relaxation) return 0;
+  if (hydro != fuse_.hydro || hydro->nsite != lb->nsite) return 0;
+  if (hydro->le && lees_edw_nplane_total(hydro->le) > 0) return 0;
+  if (fuse_.phi == NULL || (size_t) fuse_.phi->nsites != (size_t) lb->nsite) return 0;
+  cs_cartsz(lb->cs, cartsz);
+  cs_periodic(lb->cs, periodic);
+  cs_nlocal(lb->cs, nlocal);
+  cs_nhalo(lb->cs, &nhalo);
+  if (nhalo < 2) return 0;
+  for (int ia = 0; ia < 3; ia++) {
+    if (cartsz[ia] != 1 || periodic[ia] != 1 || nlocal[ia] < 4) return 0;
+  }
+  return 1;
+}
+
+static int shim_phi_force_calculation_now(pe_t * pe, cs_t * cs, lees_edw_t * le,
+					  wall_t * wall, pth_t * pth, fe_t * fe,
+					  map_t * map, field_t * phi, hydro_t * hydro);
+static int shim_phi_cahn_hilliard_now(phi_ch_t * pch, fe_t * fe, field_t * phi,
+				      hydro_t * hydro, map_t * map, noise_t * noise);
+static int shim_phi_force_ok(lees_edw_t * le, wall_t * wall, pth_t * pth, fe_t * fe,
+			     field_t * phi, hydro_t * hydro, int * npt);
+static int shim_phi_ch_ok(phi_ch_t * pch, fe_t * fe, field_t * phi, hydro_t * hydro,
+			  map_t * map, noise_t * noise, int * npt, int * order);
+
+/* What has been noted this step, run now and in order: some call came that
+ * is not the next one of the sequence */
+
+static void shim_fuse_flush(void) {
+  const int stage = fuse_.stage;
+  if (stage == FUSE_NONE) return;
+  fuse_.stage = FUSE_NONE;
+  fuse_.armed = 0;                               /* a normal step arms again */
+  if (stage >= FUSE_HALO) shim_field_halo_now(fuse_.phi);
+  if (stage >= FUSE_GRAD) shim_field_grad_compute_now(fuse_.fgrad);
+  if (stage >= FUSE_FORCE) {
+    shim_phi_force_calculation_now(fuse_.pe, fuse_.cs, fuse_.le, fuse_.wall, fuse_.pth,
+				   fuse_.fe, fuse_.map_force, fuse_.phi, fuse_.hydro);
+  }
+  if (stage >= FUSE_CH) {
+    shim_phi_cahn_hilliard_now(fuse_.pch, fuse_.fe, fuse_.phi, fuse_.hydro,
+			       fuse_.map_ch, fuse_.noise);
+  }
+  if (stage >= FUSE_UZERO) shim_hydro_u_zero_now(fuse_.hydro, fuse_.uzero);
 }
 
 static int shim_fe_symm_ok(fe_t * fe, field_t * phi, lees_edw_t * le, int * npt) {
@@ -1474,20 +1730,44 @@ static int shim_fe_symm_ok(fe_t * fe, field_t * phi, lees_edw_t * le, int * npt)
   return (*npt != 0 && fs->dphi->level == 2);
 }
 
+static int shim_phi_force_ok(lees_edw_t * le, wall_t * wall, pth_t * pth, fe_t * fe,
+			     field_t * phi, hydro_t * hydro, int * npt) {
+  int is_pm = 0;
+  if (hydro == NULL) return 0;
+  if (wall) wall_is_pm(wall, &is_pm);
+  if (pth->method != FE_FORCE_METHOD_STRESS_DIVERGENCE || is_pm ||
+      (wall && wall_present(wall)) || !shim_fe_symm_ok(fe, phi, le, npt)) return 0;
+  return 1;
+}
+
 int phi_force_calculation(pe_t * pe, cs_t * cs, lees_edw_t * le, wall_t * wall,
 			  pth_t * pth, fe_t * fe, map_t * map, field_t * phi,
 			  hydro_t * hydro) {
   int npt = 0;
-  int is_pm = 0;
+  assert(pth);
+  if (fuse_.stage == FUSE_GRAD && phi == fuse_.phi && fe == fuse_.fe &&
+      hydro == fuse_.hydro && shim_phi_force_ok(le, wall, pth, fe, phi, hydro, &npt) &&
+      ((fe_symm_t *) fe)->dphi == fuse_.fgrad) {
+    fuse_.pe = pe; fuse_.cs = cs; fuse_.le = le; fuse_.wall = wall; fuse_.pth = pth;
+    fuse_.map_force = map;
+    fuse_.stage = FUSE_FORCE;
+    return 0;
+  }
+  shim_fuse_flush();
+  return shim_phi_force_calculation_now(pe, cs, le, wall, pth, fe, map, phi, hydro);
+}
+
+static int shim_phi_force_calculation_now(pe_t * pe, cs_t * cs, lees_edw_t * le,
+					  wall_t * wall, pth_t * pth, fe_t * fe,
+					  map_t * map, field_t * phi, hydro_t * hydro) {
+  int npt = 0;
 
   assert(pth);
 
   if (hydro == NULL) return 0;                               /* phi_force.c:86 */
   if (pth->method == FE_FORCE_METHOD_NO_FORCE) return 0;
 
-  if (wall) wall_is_pm(wall, &is_pm);
-  if (pth->method != FE_FORCE_METHOD_STRESS_DIVERGENCE || is_pm ||
-      (wall && wall_present(wall)) || !shim_fe_symm_ok(fe, phi, le, &npt)) {
+  if (!shim_phi_force_ok(le, wall, pth, fe, phi, hydro, &npt)) {
     return phi_force_calculation_ref(pe, cs, le, wall, pth, fe, map, phi, hydro);
   }
 
@@ -1506,6 +1786,9 @@ int phi_force_calculation(pe_t * pe, cs_t * cs, lees_edw_t * le, wall_t * wall,
     /* F_a -= d_b P_ab at the interior sites, from the arrays the (bound)
      * field_grad_compute has just filled */
     shim_note(S_PHI_FORCE_CALCULATION, 1);
+    /* (a candidate for the sequence folded into lb_collide) */
+    fuse_.cand |= 1;
+    fuse_.phi = phi; fuse_.fe = fe; fuse_.hydro = hydro;
     SHIM_CHECK(shim_.lb, lbmi_symmetric_force(shim_.h, param.a, param.b,
 					      param.kappa, shim_field_data(phi),
 					      grad, delsq,
@@ -1515,12 +1798,44 @@ int phi_force_calculation(pe_t * pe, cs_t * cs, lees_edw_t * le, wall_t * wall,
   return 0;
 }
 
+static int shim_phi_ch_ok(phi_ch_t * pch, fe_t * fe, field_t * phi, hydro_t * hydro,
+			  map_t * map, noise_t * noise, int * npt, int * order) {
+  int noise_phi = 0, ispm = 0;
+  double gm[3] = {0.0, 0.0, 0.0};
+  physics_t * phys = NULL;
+  physics_ref(&phys);
+  physics_grad_mu(phys, gm);
+  advection_order(order);
+  if (noise) noise_present(noise, NOISE_PHI, &noise_phi);
+  if (map) map_pm(map, &ispm);
+  if (hydro == NULL || noise_phi || ispm || pch->info.conserve != 0 ||
+      *order < 1 || *order > 4 || gm[X] != 0.0 || gm[Y] != 0.0 || gm[Z] != 0.0 ||
+      !shim_fe_symm_ok(fe, phi, pch->le, npt)) return 0;
+  return 1;
+}
+
 int phi_cahn_hilliard(phi_ch_t * pch, fe_t * fe, field_t * phi,
 		      hydro_t * hydro, map_t * map, noise_t * noise) {
+  int npt = 0, order = 0;
+  assert(pch);
+  assert(fe);
+  assert(phi);
+  if (fuse_.stage == FUSE_FORCE && pch == fuse_.pch && phi == fuse_.phi &&
+      fe == fuse_.fe && hydro == fuse_.hydro &&
+      shim_phi_ch_ok(pch, fe, phi, hydro, map, noise, &npt, &order)) {
+    fuse_.map_ch = map; fuse_.noise = noise;
+    fuse_.stage = FUSE_CH;
+    return 0;
+  }
+  shim_fuse_flush();
+  return shim_phi_cahn_hilliard_now(pch, fe, phi, hydro, map, noise);
+}
+
+static int shim_phi_cahn_hilliard_now(phi_ch_t * pch, fe_t * fe, field_t * phi,
+				      hydro_t * hydro, map_t * map, noise_t * noise) {
   static double * scratch = NULL;        /* the new phi, nsite doubles (device) */
   static size_t scratch_sites = 0;
-  int npt = 0, order = 0, noise_phi = 0, ispm = 0;
-  double gm[3] = {0.0, 0.0, 0.0};
+  int npt = 0, order = 0;
   physics_t * phys = NULL;
 
   assert(pch);
@@ -1528,14 +1843,8 @@ int phi_cahn_hilliard(phi_ch_t * pch, fe_t * fe, field_t * phi,
   assert(phi);
 
   physics_ref(&phys);
-  physics_grad_mu(phys, gm);
-  advection_order(&order);
-  if (noise) noise_present(noise, NOISE_PHI, &noise_phi);
-  if (map) map_pm(map, &ispm);
 
-  if (hydro == NULL || noise_phi || ispm || pch->info.conserve != 0 ||
-      order < 1 || order > 4 || gm[X] != 0.0 || gm[Y] != 0.0 || gm[Z] != 0.0 ||
-      !shim_fe_symm_ok(fe, phi, pch->le, &npt)) {
+  if (!shim_phi_ch_ok(pch, fe, phi, hydro, map, noise, &npt, &order)) {
     return phi_cahn_hilliard_ref(pch, fe, phi, hydro, map, noise);
   }
 
@@ -1568,6 +1877,10 @@ int phi_cahn_hilliard(phi_ch_t * pch, fe_t * fe, field_t * phi,
      * place, so the new interior goes back into its array */
     SHIM_CHECK(shim_.lb, lbmi_field_halo_n(shim_.h, 3, 1, u));
     shim_note(S_PHI_CAHN_HILLIARD, 1);
+    if (phi == fuse_.phi && fe == fuse_.fe && hydro == fuse_.hydro) {
+      fuse_.cand |= 2;
+      fuse_.pch = pch;
+    }
     SHIM_CHECK(shim_.lb, lbmi_cahn_hilliard(shim_.h, param.a, param.b,
 					    param.kappa, mobility, phid, delsq,
 					    u, scratch));
@@ -1650,6 +1963,7 @@ static int shim_phi_stats(phi_ch_t * pch, field_t * phi, map_t * map,
 }
 
 int cahn_hilliard_stats_time0(phi_ch_t * pch, field_t * phi, map_t * map) {
+  shim_fuse_flush();
   double stats[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   MPI_Comm comm;
   assert(pch);
@@ -1666,6 +1980,7 @@ int cahn_hilliard_stats_time0(phi_ch_t * pch, field_t * phi, map_t * map) {
 }
 
 int cahn_hilliard_stats(phi_ch_t * pch, field_t * phi, map_t * map) {
+  shim_fuse_flush();
   double stats[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   assert(pch);
   assert(phi);

@@ -3435,10 +3435,31 @@ int lbmi_symmetric_step_periodic(lbmi_t * lb, double a, double b,
  * state of LBMI_MODE_FUSED on one rank that is ONE launch (k_symm_lb_step);
  * anywhere else the same results come from the separate calls. */
 
+static int lbmi_symmetric_lb_impl(lbmi_t * lb, const lbmi_hydro_t * hydro,
+				  const double * u_prev, double a, double b,
+				  double kappa, double mobility, const double * phi,
+				  double * phi_out, int whole_step);
+
 int lbmi_symmetric_lb_step(lbmi_t * lb, const lbmi_hydro_t * hydro,
 			   const double * u_prev, double a, double b,
 			   double kappa, double mobility, const double * phi,
 			   double * phi_out) {
+  return lbmi_symmetric_lb_impl(lb, hydro, u_prev, a, b, kappa, mobility, phi,
+				phi_out, 1);
+}
+
+int lbmi_symmetric_lb_collide(lbmi_t * lb, const lbmi_hydro_t * hydro,
+			      const double * u_prev, double a, double b,
+			      double kappa, double mobility, const double * phi,
+			      double * phi_out) {
+  return lbmi_symmetric_lb_impl(lb, hydro, u_prev, a, b, kappa, mobility, phi,
+				phi_out, 0);
+}
+
+static int lbmi_symmetric_lb_impl(lbmi_t * lb, const lbmi_hydro_t * hydro,
+				  const double * u_prev, double a, double b,
+				  double kappa, double mobility, const double * phi,
+				  double * phi_out, int whole_step) {
   lbmi_hydro_t hy;
   int fused;
   if (lb == NULL || hydro == NULL || !u_prev || !phi || !phi_out) {
@@ -3485,7 +3506,7 @@ int lbmi_symmetric_lb_step(lbmi_t * lb, const lbmi_hydro_t * hydro,
 	   (lb->kp.scheme == LBMI_RELAXATION_M10 ||
 	    lb->kp.scheme == LBMI_RELAXATION_BGK) &&
 	   lb->kp.nlocal[X] >= 4 && lb->kp.nlocal[Y] >= 4 && lb->kp.nlocal[Z] >= 4 &&
-	   hydro->nsite == 0);
+	   (hydro->nsite == 0 || hydro->nsite == lb->kp.nsite));
 
   if (fused) {
     lbmi_hydro_dev_t h = lbmi_hydro_dev(&hy);
@@ -3528,7 +3549,14 @@ int lbmi_symmetric_lb_step(lbmi_t * lb, const lbmi_hydro_t * hydro,
     lb->blocked = (lay != 0);
     lbmi_swapf(lb);
     lb->hydro_stale = owed;
-    /* lb_halo and lb_propagation of this step: pending again, as they were */
+    if (!whole_step) {
+      /* where lbmi_lb_collide leaves the handle: lb_halo and lb_propagation
+       * of this step are the caller's to call */
+      lb->pending_prop = 0;
+      lb->pending_halo = 0;
+      lb->halo_done = 0;
+    }
+    /* (the whole step: lb_halo and lb_propagation pending again, as they were) */
     return 0;
   }
 
@@ -3548,7 +3576,7 @@ int lbmi_symmetric_lb_step(lbmi_t * lb, const lbmi_hydro_t * hydro,
     hy.force = lb->fe_force;
     hy.nsite = 0;
     lb->hydro_lazy = lazy ? 2 : 0;    /* the next step reads this u */
-    ifail = lbmi_one_step(lb, &hy);
+    ifail = whole_step ? lbmi_one_step(lb, &hy) : lbmi_lb_collide(lb, &hy);
     lb->hydro_lazy = lazy;
     return ifail;
   }

@@ -412,6 +412,15 @@ class LB:
             self._h, ctypes.byref(h), _ptr(u_prev), a, b, kappa, mobility,
             _ptr(phi), _ptr(phi_out)))
 
+    def symmetric_lb_collide(self, hydro, u_prev, a, b, kappa, mobility, phi, phi_out):
+        """lbmi_symmetric_lb_collide: the same up to and including lb_collide;
+        lb_halo and lb_propagation are the caller's."""
+        self._zeros_still_hold()
+        h = hydro.ptrs()
+        _l.check(self._lib.lbmi_symmetric_lb_collide(
+            self._h, ctypes.byref(h), _ptr(u_prev), a, b, kappa, mobility,
+            _ptr(phi), _ptr(phi_out)))
+
     def symmetric_step_grad(self, a, b, kappa, mobility, phi, grad, delsq, u,
                             force, phi_out, accumulate=True):
         """symmetric_step with the gradients read from the arrays of

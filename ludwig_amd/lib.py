@@ -156,6 +156,8 @@ SYMBOLS = [
                                       _vp, _vp, _i]),
     ("lbmi_symmetric_lb_step", _i, [_vp, ctypes.POINTER(HydroPtrs), _vp, _d, _d,
                                     _d, _d, _vp, _vp]),
+    ("lbmi_symmetric_lb_collide", _i, [_vp, ctypes.POINTER(HydroPtrs), _vp, _d, _d,
+                                       _d, _d, _vp, _vp]),
     ("lbmi_lb_records_pack", _i, [_vp, _vp]),
     ("lbmi_lb_records_unpack", _i, [_vp, _vp]),
     ("lbmi_lb_io_write", _i, [_vp, ctypes.c_char_p, _i, _i, _i]),

@@ -276,8 +276,11 @@ def test_one_kernel_binary_fluid_step_with_rho_on_demand(lazy):
 @pytest.mark.parametrize("nvel,scheme,order", [(19, "m10", 1), (19, "m10", 2), (19, "m10", 3),
                                                (19, "m10", 4), (19, "bgk", 1), (19, "bgk", 3),
                                                (27, "m10", 1), (27, "bgk", 2), (27, "m10", 4)])
-def test_one_kernel_binary_fluid_step_vs_oracle(nvel, order, scheme):
-    """lbmi_symmetric_lb_step: the whole step of BASELINE config 4 as ONE
+@pytest.mark.parametrize("split", [False, True], ids=["step", "collide"])
+def test_one_kernel_binary_fluid_step_vs_oracle(nvel, order, scheme, split):
+    """(split: lbmi_symmetric_lb_collide, then lb_halo and lb_propagation by
+    the caller -- the form the binding uses, ludwig.c calls those two itself.)
+    lbmi_symmetric_lb_step: the whole step of BASELINE config 4 as ONE
     kernel (force and Cahn-Hilliard update of a site evaluated by the thread
     that collides it, u of the previous step from a second array) against
     the oracle running the reference's order of calls (ludwig.c:537-860):
@@ -323,7 +326,13 @@ def test_one_kernel_binary_fluid_step_vs_oracle(nvel, order, scheme):
         # device: one call; u_prev = what the last call stored
         pending = lb.state()[1]
         hy.u = ub if n % 2 == 0 else ua
-        lb.symmetric_lb_step(hy, ua if n % 2 == 0 else ub, a, b, kappa, mob, pa, pb)
+        if split:
+            lb.symmetric_lb_collide(hy, ua if n % 2 == 0 else ub, a, b, kappa, mob, pa, pb)
+            assert lb.state()[:2] == (0, 0)
+            lb.lb_halo()
+            lb.lb_propagation()
+        else:
+            lb.symmetric_lb_step(hy, ua if n % 2 == 0 else ub, a, b, kappa, mob, pa, pb)
         pa, pb = pb, pa
         assert pending == (1 if n > 0 else 0)
         lb.synchronize()

@@ -454,6 +454,62 @@ def test_ludwig_more_regressions_with_the_free_energy_sector_bound(name):
             assert abs(a - b) <= 2e-7 * abs(b) + 1e-16
 
 
+def _all(log, tag):
+    return [_floats(l) for l in log.splitlines() if l.startswith(tag)]
+
+
+@pytest.mark.parametrize("inp,steps,folded", [
+    # 7-point gradients, first-order advection: the one-kernel form.
+    # 30 steps, reports at 10, 20, 30; step 1 runs call by call and arms
+    ("iodrop7.inp", 30, 30 - 3 - 1),
+    # 27-point gradients, second-order advection: lbmi_symmetric_lb_collide
+    # runs the single free-energy pass and the collision (no one-kernel form)
+    ("iodrop.inp", 20, 20 - 2 - 1),
+])
+def test_free_energy_sector_folded_into_the_collision(inp, steps, folded):
+    """ludwig.c calls field_halo(phi), field_grad_compute,
+    phi_force_calculation, phi_cahn_hilliard, hydro_u_zero and lb_collide one
+    by one; with nothing set the binding notes the first five of a step that
+    follows a qualifying one and runs them inside lb_collide
+    (lbmi_symmetric_lb_collide: ONE kernel for BASELINE config 4's scheme) --
+    except on steps that report or write, where every array must be what the
+    reference has. Every report of the run (rho, phi, the free energy, the
+    extrema of u) against the same run with the sector bound call by call
+    (LBMI_FE=1), with the reference's own free-energy kernels (LBMI_FE=0) and
+    against the reference's executable without the binding."""
+    exe = os.path.join(REF, "ludwig_hip_d3q19_shim")
+    env = _env(None, LBMI_REPORT="1")
+    import shutil
+    with tempfile.TemporaryDirectory() as tmp:
+        shutil.copy(os.path.join(INPUTS, inp), os.path.join(tmp, "input"))
+        r = _sp.run([exe], cwd=tmp, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Ludwig finished normally." in r.stdout, r.stderr[-2000:]
+    m = _re.search(r"of (\d+) collisions, rho alone in \d+; free-energy sector folded into (\d+)",
+                   r.stderr)
+    assert m, r.stderr[-2000:]
+    assert int(m.group(1)) == steps and int(m.group(2)) == folded
+    assert "free-energy sector folded into lb_collide" in r.stdout
+    # every symbol of the sequence was the library's at every step
+    for sym in ("field_halo", "field_grad_compute", "phi_force_calculation",
+                "phi_cahn_hilliard", "hydro_u_zero", "lb_collide"):
+        mm = _re.search(r"liblbmi report: %s\s+(\d+)\s+(\d+)" % sym, r.stderr)
+        assert mm and int(mm.group(2)) == 0 and int(mm.group(1)) >= steps, (sym, r.stderr[-1500:])
+    log = r.stdout
+    others = {"call by call": _ludwig(inp, None, extra_env={"LBMI_FE": "1"}),
+              "reference's free-energy kernels": _ludwig(inp, None, extra_env={"LBMI_FE": "0"}),
+              "unbound": _ludwig(inp, None, shim=False)}
+    assert "folded" not in others["call by call"]
+    for who, ref in others.items():
+        for tag in ("[rho]", "[phi]", "[fed]", "[minimum ]", "[maximum ]"):
+            mine, theirs = _all(log, tag), _all(ref, tag)
+            assert len(mine) == len(theirs) and len(mine) >= 2, (who, tag)
+            for a, b in zip(mine, theirs):
+                assert len(a) == len(b)
+                for x, y in zip(a, b):
+                    # (eight printed digits; u of 1e-5: the last of them)
+                    assert abs(x - y) <= 2e-7 * abs(y) + 1e-13, (who, tag, a, b)
+
+
 def test_the_free_energy_binding_leaves_other_cases_to_the_reference():
     """A case outside the conditions of the free-energy binding
     (symmetric_lb: two distributions, no finite-difference order parameter):
