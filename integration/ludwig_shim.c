@@ -291,14 +291,22 @@ typedef struct shim_fuse_s {
   double uzero[3];
   /* candidates seen on a normal step */
   field_grad_t * seen_fgrad;
-  /* device scratch: the new phi, the old u */
+  /* The second arrays of phi and u (device). The kernel reads one pair and
+   * writes the other; from one folded step to the next the new values STAY
+   * where they were written (phi_in_q, u_in_b: the latest interior values are
+   * in the second array, not in the reference's) and go back into the
+   * reference's arrays when somebody else is about to look
+   * (shim_fuse_settle: every bound symbol that is not the next one of the
+   * sequence and not one of the per-step LB calls). */
   double * phinew; double * uprev; size_t sites;
+  int phi_in_q; int u_in_b;
   int nfused;                     /* collisions that took the sector along */
 } shim_fuse_t;
 
 static shim_fuse_t fuse_;
 
-static void shim_fuse_flush(void);
+static void shim_fuse_flush(void);      /* run what was noted; settle */
+static void shim_fuse_flush_lb(void);   /* run what was noted (a per-step LB call: phi, u not looked at) */
 static int shim_fuse_wanted(void);
 
 static const char * shim_mode_name(int mode) {
@@ -798,14 +806,20 @@ int lb_collide(lb_t * lb, hydro_t * hydro, map_t * map, noise_t * noise,
       }
       SHIM_CHECK(lb, lbmi_fe_scheme_set(h, fuse_.fgrad->d2 == grad_3d_7pt_fluid_d2 ? 7 : 27,
 					order));
-      /* the velocities of the previous collision are read at the neighbours
-       * while the new ones are written: from a copy (ONE hydro->u here) */
-      SHIM_CHECK(lb, lbmi_field_interior_copy(h, 3, hy.u, fuse_.uprev));
-      SHIM_CHECK(lb, lbmi_symmetric_lb_collide(h, &hy, fuse_.uprev, param.a, param.b,
-					       param.kappa, mobility, phid,
-					       fuse_.phinew));
-      /* the reference updates phi in place */
-      SHIM_CHECK(lb, lbmi_field_interior_copy(h, 1, fuse_.phinew, phid));
+      {
+	/* the velocities of the previous collision are read at the neighbours
+	 * while the new ones are written, and phi likewise: each from the
+	 * array that holds the latest values into the other one */
+	double * ua = hy.u;
+	const double * usrc = fuse_.u_in_b ? fuse_.uprev : ua;
+	const double * psrc = fuse_.phi_in_q ? fuse_.phinew : phid;
+	double * pdst = fuse_.phi_in_q ? phid : fuse_.phinew;
+	hy.u = fuse_.u_in_b ? ua : fuse_.uprev;
+	SHIM_CHECK(lb, lbmi_symmetric_lb_collide(h, &hy, usrc, param.a, param.b,
+						 param.kappa, mobility, psrc, pdst));
+	fuse_.u_in_b = !fuse_.u_in_b;
+	fuse_.phi_in_q = !fuse_.phi_in_q;
+      }
       shim_note(S_FIELD_HALO, 1);
       shim_note(S_FIELD_GRAD_COMPUTE, 1);
       shim_note(S_PHI_FORCE_CALCULATION, 1);
@@ -928,7 +942,7 @@ static void shim_needs_canonical_f(lb_t * lb, const char * who) {
 }
 
 int wall_bbl(wall_t * wall) {
-  shim_fuse_flush();
+  shim_fuse_flush_lb();
 
   assert(wall);
   assert(wall->target);
@@ -966,7 +980,7 @@ int wall_bbl(wall_t * wall) {
  *****************************************************************************/
 
 int wall_set_wall_distributions(wall_t * wall) {
-  shim_fuse_flush();
+  shim_fuse_flush_lb();
 
   assert(wall);
 
@@ -978,7 +992,7 @@ int wall_set_wall_distributions(wall_t * wall) {
 
 int bounce_back_on_links(bbl_t * bbl, lb_t * lb, wall_t * wall,
 			 colloids_info_t * cinfo) {
-  shim_fuse_flush();
+  shim_fuse_flush_lb();
   int ntotal = 0;
 
   assert(lb);
@@ -1107,7 +1121,7 @@ int wall_free(wall_t * wall) {
  *****************************************************************************/
 
 int lb_halo_swap(lb_t * lb, lb_halo_enum_t flag) {
-  shim_fuse_flush();
+  shim_fuse_flush_lb();
 
   assert(lb);
 
@@ -1135,7 +1149,7 @@ int lb_halo(lb_t * lb) {
  *****************************************************************************/
 
 int lb_propagation(lb_t * lb) {
-  shim_fuse_flush();
+  shim_fuse_flush_lb();
 
   assert(lb);
 
@@ -1418,7 +1432,7 @@ static int shim_hydro_u_zero_now(hydro_t * hydro, const double uzero[3]) {
 int hydro_f_zero(hydro_t * hydro, const double fzero[3]) {
   lbmi_t * h = NULL;
   assert(hydro);
-  shim_fuse_flush();
+  shim_fuse_flush_lb();                          /* (neither phi nor u) */
   h = shim_handle_if_any(hydro->cs);
   if (h == NULL || hydro->nsite != shim_.lb->nsite) return hydro_f_zero_ref(hydro, fzero);
   shim_note(S_HYDRO_F_ZERO, 1);
@@ -1699,9 +1713,35 @@ static int shim_phi_ch_ok(phi_ch_t * pch, fe_t * fe, field_t * phi, hydro_t * hy
 /* What has been noted this step, run now and in order: some call came that
  * is not the next one of the sequence */
 
+/* phi and hydro->u of the reference hold the latest interior values again */
+
+static void shim_fuse_settle(void) {
+  if (shim_.h == NULL) {
+    fuse_.phi_in_q = 0;
+    fuse_.u_in_b = 0;
+    return;
+  }
+  if (fuse_.phi_in_q) {
+    fuse_.phi_in_q = 0;
+    SHIM_CHECK(shim_.lb, lbmi_field_interior_copy(shim_.h, 1, fuse_.phinew,
+						  shim_field_data(fuse_.phi)));
+  }
+  if (fuse_.u_in_b) {
+    fuse_.u_in_b = 0;
+    SHIM_CHECK(shim_.lb, lbmi_field_interior_copy(shim_.h, 3, fuse_.uprev,
+						  shim_field_data(fuse_.hydro->u)));
+  }
+}
+
 static void shim_fuse_flush(void) {
+  shim_fuse_settle();
+  shim_fuse_flush_lb();
+}
+
+static void shim_fuse_flush_lb(void) {
   const int stage = fuse_.stage;
   if (stage == FUSE_NONE) return;
+  shim_fuse_settle();                            /* the noted calls read phi, u */
   fuse_.stage = FUSE_NONE;
   fuse_.armed = 0;                               /* a normal step arms again */
   if (stage >= FUSE_HALO) shim_field_halo_now(fuse_.phi);

@@ -1,7 +1,8 @@
 #!/bin/bash
 # The reference's executable with the binding and NO LBMI_* variable set (what a drop-in user runs), by its own timer
 # report: D3Q19 single fluid 256^3 and the symmetric free energy at 128^3 (BASELINE config 4), 1000 steps each,
-# statistics at steps 0 and 1000. Beside it LBMI_FE=1 (the free-energy sequence bound as well) for the second.
+# statistics at steps 0 and 1000. Beside it, for the second: LBMI_FE=1 (the free-energy sector bound call by call, not
+# folded into the collision) and LBMI_FE=0 (left to the reference's own kernels).
 R=$PWD/oracle/_ref
 run() {  # input exe [VAR=value ...]
   d=$(mktemp -d); cp $1 $d/input; inp=$1; exe=$2; shift 2
@@ -48,4 +49,5 @@ EOT
 run $t/single256 $R/ludwig_hip_d3q19_shim
 run $t/binary128 $R/ludwig_hip_d3q19_shim
 run $t/binary128 $R/ludwig_hip_d3q19_shim LBMI_FE=1
+run $t/binary128 $R/ludwig_hip_d3q19_shim LBMI_FE=0
 rm -rf $t
