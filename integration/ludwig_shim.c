@@ -1040,6 +1040,7 @@ int bounce_back_on_links(bbl_t * bbl, lb_t * lb, wall_t * wall,
   assert(cinfo);
 
   colloids_info_ntotal(cinfo, &ntotal);
+  if (ntotal == 0) return 0;                     /* bbl.c:160 */
   if (ntotal > 0) {
     if (!shim_.colloids && shim_.h != NULL && shim_.lb == lb) {
       /* the collision of this step may have left rho, u on demand: from now
