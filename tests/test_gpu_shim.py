@@ -212,12 +212,12 @@ import subprocess as _sp                                     # noqa: E402
 INPUTS = os.path.join(HERE, "golden", "inputs")
 
 
-def _ludwig(inp, mode, shim=True, extra_env=None):
+def _ludwig(inp, mode, shim=True, extra_env=None, nvel=19):
     """Run the reference's executable on an input of tests/golden/inputs.
     mode = None leaves LBMI_MODE unset (the binding's default). Whatever the
     child wrote is kept when it fails (a GPU fault must leave evidence): in
     gpurun_out/ (merged back from the GPU box) and in the assertion message."""
-    exe = os.path.join(REF, "ludwig_hip_d3q19" + ("_shim" if shim else ""))
+    exe = os.path.join(REF, "ludwig_hip_d3q%d" % nvel + ("_shim" if shim else ""))
     if not os.path.exists(exe):
         # (not a skip: the binaries travel with the snapshot, and a missing one
         # would silently take the whole boundary out of the suite)
@@ -509,6 +509,26 @@ def test_free_energy_sector_folded_into_the_collision(inp, steps, folded):
                 assert len(a) == len(b)
                 for x, y in zip(a, b):
                     # (eight printed digits; u of 1e-5: the last of them)
+                    assert abs(x - y) <= 2e-7 * abs(y) + 1e-13, (who, tag, a, b)
+
+
+def test_free_energy_sector_folded_d3q27():
+    """The same with the D3Q27 build of the reference (k_symm_lb_step<27>):
+    every report against the call-by-call binding, the reference's own
+    free-energy kernels around the library's collision, and the unbound
+    executable."""
+    inp = "iodrop7.inp"
+    log = _ludwig(inp, None, nvel=27)
+    assert "free-energy sector folded into lb_collide" in log
+    others = {"call by call": _ludwig(inp, None, extra_env={"LBMI_FE": "1"}, nvel=27),
+              "reference's free-energy kernels": _ludwig(inp, None, extra_env={"LBMI_FE": "0"}, nvel=27),
+              "unbound": _ludwig(inp, None, shim=False, nvel=27)}
+    for who, ref in others.items():
+        for tag in ("[rho]", "[phi]", "[fed]", "[minimum ]", "[maximum ]"):
+            mine, theirs = _all(log, tag), _all(ref, tag)
+            assert len(mine) == len(theirs) and len(mine) >= 2, (who, tag)
+            for a, b in zip(mine, theirs):
+                for x, y in zip(a, b):
                     assert abs(x - y) <= 2e-7 * abs(y) + 1e-13, (who, tag, a, b)
 
 
