@@ -148,9 +148,24 @@ typedef struct lbmi_options_s {
 			       plane is one value out of every row, FUSED runs
 			       as FUSED_HALO -- the exchange where lb_halo is
 			       called, the propagation folded into the next
-			       collision: measured faster)                   */
-  int reserved[6];          /* must be zero                                  */
+			       collision: measured faster).
+			       3 = LBMI_CART_GENERAL: the Cartesian
+			       decomposition of cartgrid / cartcoords (the
+			       reference's default for N ranks is
+			       MPI_Dims_create's, e.g. 2_2_2 for eight,
+			       coords.c:520-560). With more than one direction
+			       decomposed the halo swap is the reference's
+			       sequence of passes X, Y, Z, each over the full
+			       extent of the other two (halo_swap.c:709-1063:
+			       edges and corners complete), device to device;
+			       FUSED runs as FUSED_HALO.                      */
+  int cartgrid[3];          /* cartdim 3: ranks along X, Y, Z (product =
+			       cartsz); otherwise must be zero               */
+  int cartcoords[3];        /* cartdim 3: this rank's coordinates; cartrank =
+			       (cx*gy + cy)*gz + cz, the rank of
+			       MPI_Cart_create without reordering            */
 } lbmi_options_t;
+enum {LBMI_CART_GENERAL = 3};
 
 /* Borrowed per-call fields of lb_collide(): hydro_t and map_t device arrays
  * (collision.c:200-202, 329-333, 571-579). Any pointer may be NULL:
@@ -822,6 +837,11 @@ typedef struct lbmi_xop_s {
 } lbmi_xop_t;
 int lbmi_x_schedule(const lbmi_options_t * opts, int scheme, int packed,
 		    lbmi_xop_t * ops, int maxops, int * nops);
+/* the same for the exchange along direction dim of a decomposition of any
+ * kind (cartdim 3: once per decomposed direction, in the order X, Y, Z, with
+ * the local periodic copies of the other directions in their places) */
+int lbmi_x_schedule_dim(const lbmi_options_t * opts, int dim, int scheme,
+			int packed, lbmi_xop_t * ops, int maxops, int * nops);
 
 /* The peer transport: a ring of cartsz handles inside ONE process, each
  * driven by a host thread of its own and each on a device of its own -- one

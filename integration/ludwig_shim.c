@@ -350,9 +350,11 @@ static void shim_report_policy(void) {
     }									\
   } while (0)
 
-/* Can liblbmi take this lb_t? SoA build, device halo scheme, a decomposition
- * along ONE axis (slabs: grid N_1_1, 1_N_1 or 1_1_N, coords_rt.c:46-47).
- * Anything else uses the originals. */
+/* Can liblbmi take this lb_t? SoA build, device halo scheme, any Cartesian
+ * decomposition whose ranks are numbered as MPI_Cart_create numbers them
+ * without reordering: slabs (grid N_1_1, 1_N_1 or 1_1_N, coords_rt.c:46-47)
+ * with their own fused steps, grids of ranks in more than one direction as
+ * the reference's sequence of halo passes. Anything else uses the originals. */
 
 static int shim_slab_dim(lb_t * lb, int * dim) {
   int cartsz[3];
@@ -368,6 +370,32 @@ static int shim_slab_dim(lb_t * lb, int * dim) {
   return (ndec <= 1);
 }
 
+/* More than one direction decomposed (the reference's own choice for N ranks
+ * without a `grid` key is MPI_Dims_create's, coords.c:520-560: 2_2_2 for
+ * eight): liblbmi numbers the ranks of a grid as MPI_Cart_create does when
+ * it does not reorder them -- which is what this checks, together with the
+ * six neighbours, before such a run is taken on. */
+
+static int shim_cart_general_ok(lb_t * lb) {
+  int cartsz[3], coords[3];
+  int rank = -1;
+  MPI_Comm comm;
+  cs_cartsz(lb->cs, cartsz);
+  cs_cart_coords(lb->cs, coords);
+  cs_cart_comm(lb->cs, &comm);
+  MPI_Comm_rank(comm, &rank);
+  if (rank != (coords[X]*cartsz[Y] + coords[Y])*cartsz[Z] + coords[Z]) return 0;
+  if (rank != cs_cart_rank(lb->cs)) return 0;
+  for (int d = 0; d < 3; d++) {
+    int c[3] = {coords[X], coords[Y], coords[Z]};
+    c[d] = (coords[d] + 1) % cartsz[d];
+    if (cs_cart_neighb(lb->cs, CS_FORW, d) != (c[X]*cartsz[Y] + c[Y])*cartsz[Z] + c[Z]) return 0;
+    c[d] = (coords[d] + cartsz[d] - 1) % cartsz[d];
+    if (cs_cart_neighb(lb->cs, CS_BACK, d) != (c[X]*cartsz[Y] + c[Y])*cartsz[Z] + c[Z]) return 0;
+  }
+  return 1;
+}
+
 static int shim_supported(lb_t * lb) {
   int dim = X;
   if (DATA_MODEL != DATA_MODEL_SOA) return 0;
@@ -376,13 +404,16 @@ static int shim_supported(lb_t * lb) {
   if (lb->haloscheme != LB_HALO_TARGET) return 0;
   if (!shim_slab_dim(lb, &dim)) {
     static int told = 0;
+    static int ok = -1;
     int cartsz[3];
+    if (ok < 0) ok = shim_cart_general_ok(lb);
+    if (ok) return 1;
     cs_cartsz(lb->cs, cartsz);
     if (!told) {
-      pe_info(lb->pe, "liblbmi: decomposition %d_%d_%d: slabs along one axis "
-	      "(grid N_1_1, 1_N_1, 1_1_N) are covered; this run uses the "
-	      "reference's own lattice Boltzmann kernels\n", cartsz[X],
-	      cartsz[Y], cartsz[Z]);
+      pe_info(lb->pe, "liblbmi: decomposition %d_%d_%d with ranks numbered "
+	      "otherwise than MPI_Cart_create numbers them without reordering: "
+	      "this run uses the reference's own lattice Boltzmann kernels\n",
+	      cartsz[X], cartsz[Y], cartsz[Z]);
     }
     told = 1;
     return 0;
@@ -509,6 +540,7 @@ static lbmi_t * shim_handle(lb_t * lb) {
     lbmi_options_t opts;
     int cartsz[3], coords[3];
     int slabdim = X;
+    int general = 0;
     double * f = NULL;
     double * fprime = NULL;
     /* LBMI_MODE unset (the default): the run starts in LBMI_MODE_FUSED -- halo
@@ -535,10 +567,23 @@ static lbmi_t * shim_handle(lb_t * lb) {
     cs_nhalo(lb->cs, &opts.nhalo);
     cs_cartsz(lb->cs, cartsz);
     cs_cart_coords(lb->cs, coords);
-    (void) shim_slab_dim(lb, &slabdim);          /* shim_supported: at most one */
-    opts.cartdim = slabdim;
-    opts.cartsz = cartsz[slabdim];
-    opts.cartrank = coords[slabdim];
+    if (shim_slab_dim(lb, &slabdim)) {
+      /* slabs (or one rank) */
+      opts.cartdim = slabdim;
+      opts.cartsz = cartsz[slabdim];
+      opts.cartrank = coords[slabdim];
+    }
+    else {
+      /* a grid of ranks (shim_supported has checked their numbering) */
+      general = 1;
+      opts.cartdim = LBMI_CART_GENERAL;
+      for (int d = 0; d < 3; d++) {
+	opts.cartgrid[d] = cartsz[d];
+	opts.cartcoords[d] = coords[d];
+      }
+      opts.cartsz = cartsz[X]*cartsz[Y]*cartsz[Z];
+      opts.cartrank = (coords[X]*cartsz[Y] + coords[Y])*cartsz[Z] + coords[Z];
+    }
     opts.device = -1;                            /* ludwig.c:467-492 chose it */
     opts.halo_scheme = LBMI_HALO_FULL;           /* halo_swap_packed semantics */
     opts.mode = LBMI_MODE_FUSED;                 /* ndist 1 or 2 */
@@ -569,7 +614,7 @@ static lbmi_t * shim_handle(lb_t * lb) {
     last_f = f;
     last_fprime = fprime;
 
-    if (cartsz[slabdim] > 1) {
+    if (cartsz[slabdim] > 1 || general) {
       /* ncclUniqueId from rank 0 of the Cartesian communicator */
       char id[LBMI_UNIQUE_ID_BYTES];
       MPI_Comm comm;
@@ -579,8 +624,9 @@ static lbmi_t * shim_handle(lb_t * lb) {
       if (rank == 0) SHIM_CHECK(lb, lbmi_comm_unique_id(id));
       MPI_Bcast(id, LBMI_UNIQUE_ID_BYTES, MPI_BYTE, 0, comm);
       SHIM_CHECK(lb, lbmi_comm_init(shim_.h, id));
-      if (slabdim == Z && shim_.mode == LBMI_MODE_FUSED) {
-	/* slabs along Z: the library runs fused as halo (lbmi_create) */
+      if ((slabdim == Z || general) && shim_.mode == LBMI_MODE_FUSED) {
+	/* slabs along Z, a grid of ranks: the library runs fused as halo
+	 * (lbmi_create) */
 	shim_.mode = LBMI_MODE_FUSED_HALO;
       }
     }

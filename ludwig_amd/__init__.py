@@ -8,4 +8,4 @@ fails loudly when the HIP library or a gfx950 device is missing.
 
 from .lib import build, library, LbmiError  # noqa: F401
 from .lb import LB, Hydro, Ring, x_schedule, model, io_metadata_write, io_metadata_write_fmt, io_single_metadata_write, io_metadata_write_file, io_filename, M10, BGK, TRT, EAGER, FUSED, INPLACE, FUSED_HALO, FUSED_SOA, HALO_FULL, HALO_REDUCED  # noqa: F401
-from .decomp import SlabDecomposition  # noqa: F401
+from .decomp import SlabDecomposition, CartDecomposition  # noqa: F401

@@ -91,7 +91,11 @@ struct lbmi_s {
   double * sendlo, * sendhi, * recvlo, * recvhi;   /* staging, any halo swap */
   size_t xbuf_doubles;
   int xdim;                          /* the decomposed direction: X (0) unless
-					opts.cartdim says Y (1) or Z (2) */
+					opts.cartdim says Y (1) or Z (2); with
+					LBMI_CART_GENERAL the first decomposed one */
+  int csz[3];                        /* ranks along X, Y, Z */
+  int ccoord[3];                     /* this rank's coordinates */
+  int multi;                         /* more than one direction decomposed */
   int x_packed;                      /* 1: pack/unpack through buffers */
   /* FUSED step: buffers of its own (a field halo between two steps must not
    * disturb what the boundary launch left for the next exchange) */
@@ -260,6 +264,93 @@ static void lbmi_halo_selections(lbmi_t * lb) {
  *
  *****************************************************************************/
 
+/* The decomposition, whichever way the options give it: cartdim 0, 1, 2 =
+ * cartsz slabs along that direction; LBMI_CART_GENERAL = the grid of
+ * cartgrid with this rank at cartcoords (ranks numbered as MPI_Cart_create
+ * numbers them without reordering: Z fastest). */
+
+static int lbmi_cart_rank(const int grid[3], const int coords[3]) {
+  return (coords[X]*grid[Y] + coords[Y])*grid[Z] + coords[Z];
+}
+
+static int lbmi_cart_check(const lbmi_options_t * opts) {
+  if (opts->cartdim != LBMI_CART_GENERAL) {
+    for (int d = 0; d < 3; d++) {
+      if (opts->cartgrid[d] != 0 || opts->cartcoords[d] != 0) {
+	return lbmi_fail(LBMI_ERR_ARGUMENT, "cartgrid / cartcoords are for "
+			 "cartdim = %d only (must be zero)", LBMI_CART_GENERAL);
+      }
+    }
+    return 0;
+  }
+  for (int d = 0; d < 3; d++) {
+    if (opts->cartgrid[d] < 1 || opts->cartcoords[d] < 0 ||
+	opts->cartcoords[d] >= opts->cartgrid[d]) {
+      return lbmi_fail(LBMI_ERR_ARGUMENT, "cartgrid[%d] = %d, cartcoords[%d] = %d",
+		       d, opts->cartgrid[d], d, opts->cartcoords[d]);
+    }
+  }
+  if (opts->cartgrid[X]*opts->cartgrid[Y]*opts->cartgrid[Z] != opts->cartsz ||
+      lbmi_cart_rank(opts->cartgrid, opts->cartcoords) != opts->cartrank) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "cartsz / cartrank = %d / %d do not "
+		     "belong to the grid %d x %d x %d at (%d, %d, %d)",
+		     opts->cartsz, opts->cartrank, opts->cartgrid[X],
+		     opts->cartgrid[Y], opts->cartgrid[Z], opts->cartcoords[X],
+		     opts->cartcoords[Y], opts->cartcoords[Z]);
+  }
+  return 0;
+}
+
+static void lbmi_cart_of(const lbmi_options_t * opts, int csz[3], int ccoord[3],
+			 int * xdim, int * multi) {
+  int ndec = 0;
+  for (int d = 0; d < 3; d++) {
+    csz[d] = 1;
+    ccoord[d] = 0;
+  }
+  if (opts->cartdim == LBMI_CART_GENERAL) {
+    *xdim = -1;
+    for (int d = 0; d < 3; d++) {
+      csz[d] = opts->cartgrid[d];
+      ccoord[d] = opts->cartcoords[d];
+      if (csz[d] > 1) {
+	ndec += 1;
+	if (*xdim < 0) *xdim = d;
+      }
+    }
+    if (*xdim < 0) *xdim = X;
+  }
+  else {
+    *xdim = opts->cartdim;
+    csz[*xdim] = opts->cartsz;
+    ccoord[*xdim] = opts->cartrank;
+  }
+  *multi = (ndec > 1);
+}
+
+/* the ranks below and above along direction d (periodic) */
+
+static void lbmi_cart_nbr(const int csz[3], const int ccoord[3], int d,
+			  int * prev, int * next) {
+  int c[3] = {ccoord[X], ccoord[Y], ccoord[Z]};
+  c[d] = (ccoord[d] + csz[d] - 1) % csz[d];
+  *prev = lbmi_cart_rank(csz, c);
+  c[d] = (ccoord[d] + 1) % csz[d];
+  *next = lbmi_cart_rank(csz, c);
+}
+
+static void lbmi_cart_init(lbmi_t * lb) {
+  lbmi_cart_of(&lb->opts, lb->csz, lb->ccoord, &lb->xdim, &lb->multi);
+}
+
+/* Is direction d exchanged with neighbours (else: wrapped on this rank)? A
+ * one-rank ring along the slab direction counts: its planes travel. */
+
+static int lbmi_dec(const lbmi_t * lb, int d) {
+  if (lb->multi) return lb->csz[d] > 1;
+  return d == lb->xdim && (lb->opts.cartsz > 1 || lb->have_comm);
+}
+
 int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
 
   int prio_low = 0, prio_high = 0;
@@ -294,8 +385,12 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "cartsz/cartrank = %d/%d",
 		     opts->cartsz, opts->cartrank);
   }
-  if (opts->cartdim < 0 || opts->cartdim > 2) {
-    return lbmi_fail(LBMI_ERR_ARGUMENT, "cartdim = %d (0 X, 1 Y, 2 Z)", opts->cartdim);
+  if (opts->cartdim < 0 || opts->cartdim > LBMI_CART_GENERAL) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "cartdim = %d (0 X, 1 Y, 2 Z, 3 general)", opts->cartdim);
+  }
+  {
+    int ifail = lbmi_cart_check(opts);
+    if (ifail) return ifail;
   }
   if (opts->mode != LBMI_MODE_EAGER && opts->mode != LBMI_MODE_FUSED &&
       opts->mode != LBMI_MODE_INPLACE && opts->mode != LBMI_MODE_FUSED_HALO) {
@@ -330,8 +425,14 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "calloc failed");
 
   lb->opts = *opts;
-  lb->xdim = opts->cartdim;
-  if (opts->cartsz > 1 && opts->cartdim == Z &&
+  lbmi_cart_init(lb);
+  if (lb->multi && (opts->mode == LBMI_MODE_FUSED || opts->mode == LBMI_MODE_INPLACE)) {
+    /* more than one direction decomposed: the exchange is the sequence of
+     * passes X, Y, Z where lb_halo is called; the propagation alone is folded
+     * into the next collision */
+    lb->opts.mode = LBMI_MODE_FUSED_HALO;
+  }
+  if (opts->cartsz > 1 && lb->xdim == Z && !lb->multi &&
       (opts->mode == LBMI_MODE_FUSED || opts->mode == LBMI_MODE_INPLACE)) {
     /* Slabs along Z: a boundary plane is one value out of every row of the
      * array, and a launch that redoes those two planes against the exchange
@@ -901,8 +1002,10 @@ int lbmi_propagate(lbmi_t * lb, const double * f, double * fprime) {
 
 static int lbmi_wrapmask(const lbmi_t * lb) {
   int mask = 1 | 2 | 4;
-  /* the decomposed direction has its halo planes filled by the neighbours */
-  if (lb->opts.cartsz > 1 || lb->have_comm) mask &= ~(1 << lb->xdim);
+  /* a decomposed direction has its halo planes filled by the neighbours */
+  for (int d = 0; d < 3; d++) {
+    if (lbmi_dec(lb, d)) mask &= ~(1 << d);
+  }
   return mask;
 }
 
@@ -954,11 +1057,9 @@ int lbmi_propagate_collide(lbmi_t * lb, const double * f, double * fprime,
  * Zero-copy: X is the slowest index, so the boundary plane of ONE component
  * is a contiguous run of strx doubles of the array itself. */
 
-static int lbmi_x_ops(int cartsz, int cartrank, const lbmi_halo_sel_t * sel,
+static int lbmi_x_ops(int prev, int next, const lbmi_halo_sel_t * sel,
 		      long long psz, long long ns, int nh, int nlocalx,
 		      int packed, int layer, lbmi_xop_t * ops) {
-  const int prev = (cartrank + cartsz - 1) % cartsz;
-  const int next = (cartrank + 1) % cartsz;
   int n = 0;
 
   if (packed) {
@@ -1009,7 +1110,19 @@ static void lbmi_sel_make(const int8_t cv[][3], int nvel, int reduced,
 
 int lbmi_x_schedule(const lbmi_options_t * opts, int scheme, int packed,
 		    lbmi_xop_t * ops, int maxops, int * nops) {
+  int csz[3], ccoord[3], xdim = X, multi = 0;
+  if (opts == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
+  if (opts->cartdim < 0 || opts->cartdim > LBMI_CART_GENERAL || lbmi_cart_check(opts) != 0) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_x_schedule: bad options");
+  }
+  lbmi_cart_of(opts, csz, ccoord, &xdim, &multi);
+  return lbmi_x_schedule_dim(opts, xdim, scheme, packed, ops, maxops, nops);
+}
+
+int lbmi_x_schedule_dim(const lbmi_options_t * opts, int dim, int scheme,
+			int packed, lbmi_xop_t * ops, int maxops, int * nops) {
   int8_t cv[LBMI_NVEL_MAX][3];
+  int csz[3], ccoord[3], xdim = X, multi = 0, prev = 0, next = 0;
   double wv[LBMI_NVEL_MAX], na[LBMI_NVEL_MAX];
   double * ma = NULL;
   lbmi_halo_sel_t sx;
@@ -1024,23 +1137,30 @@ int lbmi_x_schedule(const lbmi_options_t * opts, int scheme, int packed,
   }
   if (opts->cartsz < 1 || opts->cartrank < 0 || opts->cartrank >= opts->cartsz ||
       opts->nhalo < 1 || opts->nlocal[X] < 1 || opts->nlocal[Y] < 1 || opts->nlocal[Z] < 1 ||
-      opts->cartdim < 0 || opts->cartdim > 2) {
+      opts->cartdim < 0 || opts->cartdim > LBMI_CART_GENERAL || dim < X || dim > Z ||
+      lbmi_cart_check(opts) != 0) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_x_schedule: bad options");
   }
-  if (!packed && opts->cartdim != X) {
+  lbmi_cart_of(opts, csz, ccoord, &xdim, &multi);
+  if (multi ? (csz[dim] < 2) : (dim != xdim)) {
+    return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_x_schedule: direction %d is not "
+		     "decomposed", dim);
+  }
+  if (!packed && dim != X) {
     return lbmi_fail(LBMI_ERR_ARGUMENT, "lbmi_x_schedule: the planes of Y and Z "
 		     "slabs are not contiguous: packed messages only");
   }
+  lbmi_cart_nbr(csz, ccoord, dim, &prev, &next);
   ma = (double *) malloc(sizeof(double)*LBMI_NVEL_MAX*LBMI_NVEL_MAX);
   if (ma == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "malloc");
   lbmi_k_model(opts->nvel, &cv[0][0], wv, na, ma);
   free(ma);
-  lbmi_sel_make(cv, opts->nvel, scheme == LBMI_HALO_REDUCED, opts->cartdim, &sx);
+  lbmi_sel_make(cv, opts->nvel, scheme == LBMI_HALO_REDUCED, dim, &sx);
   ns = 1;
   for (int d = 0; d < 3; d++) ns *= (long long) (opts->nlocal[d] + 2*opts->nhalo);
-  psz = ns/(opts->nlocal[opts->cartdim] + 2*opts->nhalo);    /* sites of a plane */
-  n = lbmi_x_ops(opts->cartsz, opts->cartrank, &sx, psz, ns, opts->nhalo,
-		 opts->nlocal[opts->cartdim], packed, 0, tmp);
+  psz = ns/(opts->nlocal[dim] + 2*opts->nhalo);              /* sites of a plane */
+  n = lbmi_x_ops(prev, next, &sx, psz, ns, opts->nhalo,
+		 opts->nlocal[dim], packed, 0, tmp);
   if (n > maxops) return lbmi_fail(LBMI_ERR_ARGUMENT, "%d operations, room for %d", n, maxops);
   memcpy(ops, tmp, sizeof(lbmi_xop_t)*(size_t) n);
   *nops = n;
@@ -1271,13 +1391,26 @@ static int lbmi_x_sendrecv(lbmi_t * lb, const lbmi_xop_t * ops, int nops,
  * buf: the four staging buffers to use. unpack = 0 leaves what arrived in
  * the receive buffers; packed_already: the send buffers are up to date. */
 
+static int lbmi_x_exchange_dim(lbmi_t * lb, int dim, const lbmi_halo_sel_t * sel,
+			       double * data, int blocked, int layer,
+			       double * const buf[4], int packed_already,
+			       int unpack, hipStream_t st);
+
 static int lbmi_x_exchange_buf(lbmi_t * lb, const lbmi_halo_sel_t * sel,
+			       double * data, int blocked, int layer,
+			       double * const buf[4], int packed_already,
+			       int unpack, hipStream_t st) {
+  return lbmi_x_exchange_dim(lb, lb->xdim, sel, data, blocked, layer, buf,
+			     packed_already, unpack, st);
+}
+
+static int lbmi_x_exchange_dim(lbmi_t * lb, int dim, const lbmi_halo_sel_t * sel,
 			       double * data, int blocked, int layer,
 			       double * const buf[4], int packed_already,
 			       int unpack, hipStream_t st) {
   lbmi_xop_t ops[LBMI_XOPS_MAX];
   double * base[5] = {buf[0], buf[1], buf[2], buf[3], data};
-  const int dim = lb->xdim;
+  int prev = 0, next = 0;
   const long long psz = lb->kp.nsite/lb->kp.nall[dim];     /* sites of a plane */
   /* (only the planes of X slabs are contiguous runs of the array) */
   const int packed = (lb->x_packed || blocked || !unpack || packed_already ||
@@ -1292,7 +1425,8 @@ static int lbmi_x_exchange_buf(lbmi_t * lb, const lbmi_halo_sel_t * sel,
 		 (size_t) psz*(size_t) sel->nhi > lb->xbuf_doubles)) {
     return lbmi_fail(LBMI_ERR_STATE, "halo buffers too small");
   }
-  nops = lbmi_x_ops(lb->opts.cartsz, lb->opts.cartrank, sel, psz,
+  lbmi_cart_nbr(lb->csz, lb->ccoord, dim, &prev, &next);
+  nops = lbmi_x_ops(prev, next, sel, psz,
 		    lb->kp.nsite, lb->kp.nhalo, lb->kp.nlocal[dim], packed, layer,
 		    ops);
   if (packed && !packed_already) {
@@ -1308,11 +1442,10 @@ static int lbmi_x_exchange_buf(lbmi_t * lb, const lbmi_halo_sel_t * sel,
   return 0;
 }
 
-static int lbmi_x_exchange(lbmi_t * lb, const lbmi_halo_sel_t * sel,
-			   double * data, int blocked, int layer,
-			   hipStream_t st) {
+static int lbmi_x_exchange_along(lbmi_t * lb, int dim, const lbmi_halo_sel_t * sel,
+				 double * data, int layer, hipStream_t st) {
   double * const buf[4] = {lb->sendlo, lb->sendhi, lb->recvlo, lb->recvhi};
-  return lbmi_x_exchange_buf(lb, sel, data, blocked, layer, buf, 0, 1, st);
+  return lbmi_x_exchange_dim(lb, dim, sel, data, 0, layer, buf, 0, 1, st);
 }
 
 static int lbmi_halo_generic(lbmi_t * lb, const lbmi_halo_sel_t sel[3],
@@ -1321,8 +1454,8 @@ static int lbmi_halo_generic(lbmi_t * lb, const lbmi_halo_sel_t sel[3],
    * covers the full extent of the others, so edges and corners complete
    * (halo_swap.c:709-1063 does the same with its Cartesian neighbours) */
   for (int d = 0; d < 3; d++) {
-    if (d == lb->xdim && (lb->opts.cartsz > 1 || lb->have_comm)) {
-      int ifail = lbmi_x_exchange(lb, &sel[d], data, 0, 0, st);
+    if (lbmi_dec(lb, d)) {
+      int ifail = lbmi_x_exchange_along(lb, d, &sel[d], data, 0, st);
       if (ifail) return ifail;
     }
     else {
@@ -1356,9 +1489,9 @@ int lbmi_halo_x_count(lbmi_t * lb, int scheme, size_t * nsendlo,
   if (lb == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   sel = lbmi_sel(lb, scheme);
   if (sel == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "halo scheme %d", scheme);
-  if (lb->xdim != X) {
+  if (lb->xdim != X || lb->multi) {
     return lbmi_fail(LBMI_ERR_UNSUPPORTED, "lbmi_halo_x_*: slabs along X only "
-		     "(cartdim = %d: lbmi_halo / lbmi_lb_halo do the exchange)", lb->xdim);
+		     "(cartdim = %d: lbmi_halo / lbmi_lb_halo do the exchange)", lb->opts.cartdim);
   }
   /* sendlo feeds the neighbour's HIGH halo (components hi), sendhi its LOW */
   if (nsendlo) *nsendlo = (size_t) lb->kp.strx*(size_t) sel[X].nhi;
@@ -1547,7 +1680,7 @@ static int lbmi_blocked_ok(const lbmi_t * lb) {
    * fluctuations (their collision has no variant in this order) */
   if (lb->opts.ndist != 1 &&
       (lb->opts.cartsz > 1 || lb->have_comm || lb->noise_state != NULL)) return 0;
-  if (lb->xdim != X && (lb->opts.cartsz > 1 || lb->have_comm)) return 0;
+  if ((lb->xdim != X || lb->multi) && (lb->opts.cartsz > 1 || lb->have_comm)) return 0;
   if (lb->opts.cartsz == 1 && !lb->have_comm) {
     /* every pull is wrapped by index: nothing beyond the interior planes */
     int last = (lb->kp.nhalo + lb->kp.nlocal[X])*lb->kp.strx;
@@ -2049,8 +2182,8 @@ int lbmi_wall_map(lbmi_t * lb, const int isboundary[3], char * status) {
 	  for (int d = 0; d < 3; d++) {
 	    /* in the decomposed direction only the first rank has the low
 	     * wall, only the last one the high wall */
-	    const int first = (d != lb->xdim || lb->opts.cartrank == 0);
-	    const int last = (d != lb->xdim || lb->opts.cartrank == lb->opts.cartsz - 1);
+	    const int first = (lb->ccoord[d] == 0);
+	    const int last = (lb->ccoord[d] == lb->csz[d] - 1);
 	    if (isboundary[d] && c[d] == h - 1 && first) wall = 1;
 	    if (isboundary[d] && c[d] == h + lb->kp.nlocal[d] && last) wall = 1;
 	  }
@@ -2915,9 +3048,10 @@ int lbmi_lb_mode_set(lbmi_t * lb, int mode) {
   if (lb->opts.ndist == 2 && mode == LBMI_MODE_INPLACE) {
     return lbmi_fail(LBMI_ERR_UNSUPPORTED, "ndist = 2 needs LBMI_MODE_EAGER, LBMI_MODE_FUSED_HALO or LBMI_MODE_FUSED");
   }
-  if ((mode == LBMI_MODE_FUSED || mode == LBMI_MODE_INPLACE) && lb->xdim == Z &&
-      (lb->opts.cartsz > 1 || lb->have_comm)) {
-    mode = LBMI_MODE_FUSED_HALO;     /* slabs along Z: see lbmi_create */
+  if ((mode == LBMI_MODE_FUSED || mode == LBMI_MODE_INPLACE) &&
+      (lb->xdim == Z || lb->multi) && (lb->opts.cartsz > 1 || lb->have_comm)) {
+    mode = LBMI_MODE_FUSED_HALO;     /* slabs along Z, or more than one
+					direction decomposed: see lbmi_create */
   }
   if (mode == lb->opts.mode) return 0;
   if (lb->f != NULL) {
@@ -3241,11 +3375,11 @@ int lbmi_field_halo_n(lbmi_t * lb, int nel, int nswap, double * data) {
     sel.hi[sel.nhi++] = (int8_t) n;
   }
   for (int d = 0; d < 3; d++) {
-    if (d == lb->xdim && (lb->opts.cartsz > 1 || lb->have_comm)) {
+    if (lbmi_dec(lb, d)) {
       /* slabs: the planes of every layer over the ring (device to device,
        * where the reference stages them through the host, halo_swap.c:762-881) */
       for (int layer = 0; layer < nswap; layer++) {
-	int ifail = lbmi_x_exchange(lb, &sel, data, 0, layer, lb->stream);
+	int ifail = lbmi_x_exchange_along(lb, d, &sel, data, layer, lb->stream);
 	if (ifail) return ifail;
       }
     }
@@ -3993,7 +4127,7 @@ static int lbmi_io_args(lbmi_t * lb, const char * dir, int ntotal_x,
 			int offset_x) {
   if (lb == NULL || dir == NULL) return lbmi_fail(LBMI_ERR_ARGUMENT, "NULL");
   if (lb->f == NULL) return lbmi_fail(LBMI_ERR_STATE, "no distributions bound");
-  if (lb->xdim != X && lb->opts.cartsz > 1) {
+  if ((lb->xdim != X || lb->multi) && lb->opts.cartsz > 1) {
     return lbmi_fail(LBMI_ERR_UNSUPPORTED, "distribution files: a slab along Y or "
 		     "Z is not a contiguous byte range of the file (X slabs, or "
 		     "the reference's lb_io_write)");
@@ -4189,9 +4323,14 @@ int lbmi_comm_unique_id(void * id) {
 static int lbmi_comm_buffers(lbmi_t * lb) {
   size_t bytes;
   const int dim = lb->xdim;
-  const size_t psz = (size_t) (lb->kp.nsite/lb->kp.nall[dim]);
+  size_t psz = (size_t) (lb->kp.nsite/lb->kp.nall[dim]);
   int nred = lb->sel_reduced[dim].nlo > lb->sel_reduced[dim].nhi
     ? lb->sel_reduced[dim].nlo : lb->sel_reduced[dim].nhi;
+  /* (the largest plane among the decomposed directions) */
+  for (int d = 0; d < 3; d++) {
+    size_t pd = (size_t) (lb->kp.nsite/lb->kp.nall[d]);
+    if (lb->multi && lb->csz[d] > 1 && pd > psz) psz = pd;
+  }
   lb->xbuf_doubles = psz*LBMI_NVEL_MAX;
   bytes = sizeof(double)*lb->xbuf_doubles;
   if (hipMalloc((void **) &lb->sendlo, bytes) != hipSuccess ||
@@ -4262,9 +4401,13 @@ int lbmi_comm_init_ring(lbmi_t * lb, lbmi_ring_t * ring) {
    * able to reach both (whichever of them are other devices; a neighbour
    * that attaches later enables its own direction, and the copies name both
    * devices, so an order of attachment is not required) */
-  for (int dn = -1; dn <= 1; dn += 2) {
-    int peer = (lb->opts.cartrank + dn + ring->nranks) % ring->nranks;
+  for (int dn = 0; dn < 6; dn++) {
+    int pn[2] = {0, 0};
+    int peer;
     int pdev;
+    if (lb->csz[dn/2] < 2) continue;
+    lbmi_cart_nbr(lb->csz, lb->ccoord, dn/2, &pn[0], &pn[1]);
+    peer = pn[dn % 2];
     pthread_mutex_lock(&ring->mu);
     pdev = ring->device[peer];
     pthread_mutex_unlock(&ring->mu);

@@ -62,3 +62,52 @@ class SlabDecomposition:
         lo = [p for p in range(len(cv)) if cv[p][axis] == 1]
         hi = [p for p in range(len(cv)) if cv[p][axis] == -1]
         return lo, hi
+
+
+class CartDecomposition:
+    """A Cartesian decomposition of any shape (the reference's default for N
+    ranks is MPI_Dims_create's, e.g. 2_2_2 for eight; coords.c:520-560), even
+    parts (coords.c:327-338). Ranks as MPI_Cart_create numbers them without
+    reordering: rank = (cx*gy + cy)*gz + cz."""
+
+    def __init__(self, ntotal, grid, rank, nhalo=1):
+        grid = tuple(int(g) for g in grid)
+        size = grid[0] * grid[1] * grid[2]
+        if not (0 <= rank < size):
+            raise ValueError("rank")
+        for d in range(3):
+            if ntotal[d] % grid[d] != 0:
+                raise ValueError("ntotal[%d] = %d not divisible by %d ranks"
+                                 % (d, ntotal[d], grid[d]))
+        self.ntotal = tuple(ntotal)
+        self.grid = grid
+        self.rank = rank
+        self.size = size
+        self.nhalo = nhalo
+        self.coords = (rank // (grid[1] * grid[2]), (rank // grid[2]) % grid[1], rank % grid[2])
+        self.nlocal = tuple(ntotal[d] // grid[d] for d in range(3))
+        self.noffset = tuple(self.nlocal[d] * self.coords[d] for d in range(3))
+
+    @property
+    def nall(self):
+        return tuple(n + 2 * self.nhalo for n in self.nlocal)
+
+    def rank_of(self, coords):
+        g = self.grid
+        c = [coords[d] % g[d] for d in range(3)]
+        return (c[0] * g[1] + c[1]) * g[2] + c[2]
+
+    def neighbours(self, dim):
+        """(rank below, rank above) along dim, periodic."""
+        lo = list(self.coords)
+        hi = list(self.coords)
+        lo[dim] -= 1
+        hi[dim] += 1
+        return self.rank_of(lo), self.rank_of(hi)
+
+    def local_block(self, h=None):
+        """Slices of a global array WITH halo (nhalo = h) that hold this
+        rank's block with its halo."""
+        h = self.nhalo if h is None else h
+        return tuple(slice(self.noffset[d], self.noffset[d] + self.nlocal[d] + 2 * h)
+                     for d in range(3))

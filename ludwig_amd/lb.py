@@ -93,7 +93,8 @@ class LB:
 
     def __init__(self, nvel=19, nlocal=(64, 64, 64), nhalo=1, mode=EAGER,
                  halo_scheme=HALO_FULL, device=0, cartsz=1, cartrank=0,
-                 own_stream=False, ndist=1, cartdim=0):
+                 own_stream=False, ndist=1, cartdim=0, cartgrid=None,
+                 cartcoords=None):
         """own_stream=False (default): the library works on torch's current
         stream of `device`, so its kernels are ordered with torch operations
         on the same tensors. own_stream=True keeps the handle's private
@@ -116,6 +117,9 @@ class LB:
         opts.cartsz = cartsz
         opts.cartrank = cartrank
         opts.cartdim = cartdim
+        if cartgrid is not None:
+            # LBMI_CART_GENERAL: a grid of ranks, this one at cartcoords
+            _cart_options(opts, cartgrid, cartcoords)
         _l.check(self._lib.lbmi_create(ctypes.byref(opts), ctypes.byref(self._h)))
         self.nvel = nvel
         self.ndist = ndist
@@ -759,7 +763,7 @@ class Ring:
 
 
 def x_schedule(nvel, nlocal, nhalo, cartsz, cartrank, scheme=HALO_REDUCED,
-               packed=True, cartdim=0):
+               packed=True, cartdim=0, cartgrid=None, cartcoords=None, dim=0):
     """lbmi_x_schedule: the point-to-point operations of one X exchange of a
     rank, in issue order, as dicts (kind 'send'|'recv', peer, buffer 'sendlo'|
     'sendhi'|'recvlo'|'recvhi'|'data', offset, count). Pure host: no GPU."""
@@ -774,13 +778,33 @@ def x_schedule(nvel, nlocal, nhalo, cartsz, cartrank, scheme=HALO_REDUCED,
     opts.cartdim = cartdim
     ops = (_l.XOp * 128)()
     n = ctypes.c_int(0)
-    _l.check(lib.lbmi_x_schedule(ctypes.byref(opts), int(scheme), int(bool(packed)),
-                                 ctypes.cast(ops, ctypes.c_void_p), 128,
-                                 ctypes.byref(n)))
+    if cartgrid is not None:
+        _cart_options(opts, cartgrid, cartcoords)
+        _l.check(lib.lbmi_x_schedule_dim(ctypes.byref(opts), int(dim), int(scheme),
+                                         int(bool(packed)),
+                                         ctypes.cast(ops, ctypes.c_void_p), 128,
+                                         ctypes.byref(n)))
+    else:
+        _l.check(lib.lbmi_x_schedule(ctypes.byref(opts), int(scheme), int(bool(packed)),
+                                     ctypes.cast(ops, ctypes.c_void_p), 128,
+                                     ctypes.byref(n)))
     names = ("sendlo", "sendhi", "recvlo", "recvhi", "data")
     return [{"kind": "send" if ops[k].kind == 0 else "recv", "peer": ops[k].peer,
              "buffer": names[ops[k].buffer], "offset": int(ops[k].offset),
              "count": int(ops[k].count)} for k in range(n.value)]
+
+
+CART_GENERAL = 3                      # lbmi.h: LBMI_CART_GENERAL
+
+
+def _cart_options(opts, cartgrid, cartcoords):
+    g = [int(v) for v in cartgrid]
+    c = [int(v) for v in cartcoords]
+    opts.cartdim = CART_GENERAL
+    opts.cartgrid[:] = g
+    opts.cartcoords[:] = c
+    opts.cartsz = g[0] * g[1] * g[2]
+    opts.cartrank = (c[0] * g[1] + c[1]) * g[2] + c[2]
 
 
 def model(nvel):

@@ -26,7 +26,8 @@ class Options(ctypes.Structure):
         ("cartsz", ctypes.c_int),
         ("cartrank", ctypes.c_int),
         ("cartdim", ctypes.c_int),
-        ("reserved", ctypes.c_int * 6),
+        ("cartgrid", ctypes.c_int * 3),
+        ("cartcoords", ctypes.c_int * 3),
     ]
 
 
@@ -191,6 +192,8 @@ SYMBOLS = [
                             ctypes.POINTER(_i)]),
     ("lbmi_x_schedule", _i, [ctypes.POINTER(Options), _i, _i, _vp, _i,
                              ctypes.POINTER(_i)]),
+    ("lbmi_x_schedule_dim", _i, [ctypes.POINTER(Options), _i, _i, _i, _vp, _i,
+                                 ctypes.POINTER(_i)]),
     ("lbmi_ring_create", _i, [_i, ctypes.POINTER(_vp)]),
     ("lbmi_comm_init_ring", _i, [_vp, _vp]),
     ("lbmi_ring_free", _i, [_vp]),

@@ -210,6 +210,116 @@ def test_slabs_along_y_or_z_equal_single_domain(world, nvel, reduced, dim):
         assert np.array_equal(res[0][1], res[r][1])
 
 
+def _exchange_cart(dec, f, nh, cv, reduced, dim):
+    """One exchange of f along direction `dim` of a Cartesian decomposition
+    by the product's schedule (lbmi_x_schedule_dim): packed planes of the full
+    extent of the other two directions, halos included."""
+    nvel = f.shape[0]
+    scheme = ludwig_amd.HALO_REDUCED if reduced else ludwig_amd.HALO_FULL
+    ops = ludwig_amd.x_schedule(nvel, dec.nlocal, nh, dec.size, dec.rank, scheme=scheme,
+                                packed=True, cartgrid=dec.grid, cartcoords=dec.coords,
+                                dim=dim)
+    if reduced:
+        lo, hi = ludwig_amd.SlabDecomposition.reduced_populations(cv, axis=dim)
+    else:
+        lo = hi = list(range(nvel))
+    first, last = nh, nh + dec.nlocal[dim] - 1
+    g = np.moveaxis(f, 1 + dim, 1)
+    psz = g.shape[2] * g.shape[3]
+    buf = {"sendhi": np.ascontiguousarray(g[lo, last]).reshape(-1),
+           "sendlo": np.ascontiguousarray(g[hi, first]).reshape(-1),
+           "recvlo": np.full(len(lo) * psz, np.nan),
+           "recvhi": np.full(len(hi) * psz, np.nan)}
+    below, above = dec.neighbours(dim)
+    assert len(ops) == 4 and {op["peer"] for op in ops} <= {below, above}
+    p2p = []
+    for op in ops:
+        t = torch.from_numpy(buf[op["buffer"]])[op["offset"]:op["offset"] + op["count"]]
+        assert t.numel() == op["count"]
+        fn = dist.isend if op["kind"] == "send" else dist.irecv
+        p2p.append(dist.P2POp(fn, t, op["peer"]))
+    for r in dist.batch_isend_irecv(p2p):
+        r.wait()
+    g[lo, first - 1] = buf["recvlo"].reshape(len(lo), *g.shape[2:])
+    g[hi, last + 1] = buf["recvhi"].reshape(len(hi), *g.shape[2:])
+
+
+def _cart_worker(rank, grid, port, nvel, ntotal, nsteps, reduced, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GLOO_SOCKET_IFNAME"] = "lo"
+    world = grid[0] * grid[1] * grid[2]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nh = 1
+        dec = ludwig_amd.CartDecomposition(ntotal, grid, rank, nh)
+        cv = lbo.model(nvel)["cv"]
+        p = lbo.make_param(nvel, dec.nlocal, nh, "m10", 0.1, 0.3, 1.0, FBODY)
+        f = lbo.init_synthetic(p, ntotal, dec.noffset)
+        fp = np.zeros_like(f)
+        for _ in range(nsteps):
+            lbo.collide(p, f)
+            # halo_swap.c:709-1063: X, Y, Z in this order, each over the full
+            # extent of the others; a direction with one rank wraps locally
+            for d in range(3):
+                if grid[d] > 1:
+                    _exchange_cart(dec, f, nh, cv, reduced, d)
+                else:
+                    lbo.halo_dirs(p, f, 1 << d)
+            lbo.propagate(p, f, fp)
+            f, fp = fp, f
+        q.put((rank, dec.noffset, interior(f, nh).copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid,nvel,reduced", [
+    ((2, 2, 1), 19, False),     # lb_halo semantics: every population of every plane
+    ((1, 2, 2), 19, True),      # the face-crossing populations of each pass are enough
+    ((2, 1, 2), 27, True),
+    ((2, 2, 2), 19, False),     # MPI_Dims_create's grid for eight ranks
+])
+def test_cartesian_decomposition_equals_single_domain(grid, nvel, reduced):
+    """More than one direction decomposed (LBMI_CART_GENERAL; the reference's
+    default for N ranks is MPI_Dims_create's grid): the product's schedule per
+    decomposed direction, in the reference's order of passes, edges and
+    corners completing through the halos of the earlier passes -- bit for bit
+    the single domain."""
+    ntotal, nsteps = (4 * grid[0], 3 * grid[1], 4 * grid[2]), 3
+    world = grid[0] * grid[1] * grid[2]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cart_worker,
+                         args=(r, grid, port, nvel, ntotal, nsteps, reduced, q))
+             for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = np.zeros((nvel,) + ntotal)
+    for _ in range(world):
+        rank, off, fi = q.get(timeout=240)
+        got[:, off[0]:off[0] + fi.shape[1], off[1]:off[1] + fi.shape[2],
+            off[2]:off[2] + fi.shape[3]] = fi
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    _, f = _single_domain(nvel, ntotal, nsteps)
+    assert np.array_equal(got, interior(f, 1))
+
+
+def test_cartesian_options_are_checked():
+    with pytest.raises(ludwig_amd.LbmiError):       # direction 0 has one rank
+        ludwig_amd.x_schedule(19, (4, 5, 6), 1, 4, 0, cartgrid=(1, 2, 2),
+                              cartcoords=(0, 0, 0), dim=0)
+    ops = ludwig_amd.x_schedule(19, (4, 5, 6), 1, 4, 3, cartgrid=(1, 2, 2),
+                                cartcoords=(0, 1, 1), dim=1)
+    # rank (0, 1, 1) = 3; below and above along Y: (0, 0, 1) = 1
+    assert {op["peer"] for op in ops} == {1}
+    ops = ludwig_amd.x_schedule(19, (4, 5, 6), 1, 4, 3, cartgrid=(1, 2, 2),
+                                cartcoords=(0, 1, 1), dim=2)
+    assert {op["peer"] for op in ops} == {2}
+
+
 def test_zero_copy_messages_are_for_x_slabs_only():
     with pytest.raises(ludwig_amd.LbmiError):
         ludwig_amd.x_schedule(19, (4, 5, 6), 1, 2, 0, packed=False, cartdim=2)
