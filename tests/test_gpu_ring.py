@@ -678,3 +678,60 @@ def test_walls_on_a_cartesian_decomposition(bnd, mode_name):
         assert relmax(_assemble(out, 1, (nvel,) + ntotal), ref) < 1e-13
         tot = sum(o[4] for o in out)
         assert np.max(np.abs(tot - fnet)) < 1e-12 * max(1.0, np.abs(fnet).max())
+
+
+@pytest.mark.parametrize("grid", [(2, 2, 1), (1, 2, 2), (2, 2, 2)])
+def test_field_halo_of_two_layers_on_a_cartesian_decomposition(grid):
+    """field_halo of a three-component field with a halo two sites wide (phi
+    of the free-energy runs, hydro->u) on a grid of ranks: every layer of
+    every decomposed direction as its own packed plane over the transport,
+    the passes in the order X, Y, Z -- afterwards every halo site, edges and
+    corners included, holds the value of its periodic image in the global
+    lattice."""
+    import ludwig_amd
+    import torch
+    nh = 2
+    ntotal = (4 * grid[0], 4 * grid[1], 4 * grid[2])
+    world = grid[0] * grid[1] * grid[2]
+    # a global field whose value tells component and site apart
+    x, y, z = np.meshgrid(*[np.arange(n) for n in ntotal], indexing="ij")
+    glob = np.stack([(c + 1) * 1000000.0 + (x * ntotal[1] + y) * ntotal[2] + z for c in range(3)])
+    ring = ludwig_amd.Ring(world)
+    out = [None] * world
+    err = []
+    start = threading.Barrier(world)
+
+    def rank_main(rank):
+        try:
+            dec = ludwig_amd.CartDecomposition(ntotal, grid, rank, nh)
+            lb = ludwig_amd.LB(19, dec.nlocal, nh, mode=ludwig_amd.FUSED_HALO, own_stream=True,
+                               cartgrid=grid, cartcoords=dec.coords)
+            lb.comm_init_ring(ring)
+            a = np.full((3,) + lb.nall, -1.0)
+            sl = tuple(slice(dec.noffset[d], dec.noffset[d] + dec.nlocal[d]) for d in range(3))
+            interior(a, nh)[...] = glob[(slice(None),) + sl]
+            t = torch.from_numpy(a).to(lb.device)
+            torch.cuda.synchronize()
+            start.wait()
+            lb.field_halo_n(t, nh)
+            lb.synchronize()
+            torch.cuda.synchronize()
+            out[rank] = (dec.noffset, dec.nlocal, t.cpu().numpy())
+            start.wait()
+            lb.free()
+        except Exception as e:           # noqa: BLE001
+            err.append((rank, repr(e)))
+            ring.abort()
+            start.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not err, err
+    ring.free()
+    for off, nl, a in out:
+        idx = [np.arange(off[d] - nh, off[d] + nl[d] + nh) % ntotal[d] for d in range(3)]
+        want = glob[:, idx[0][:, None, None], idx[1][None, :, None], idx[2][None, None, :]]
+        assert np.array_equal(a, want)
