@@ -19,6 +19,8 @@
 //   J  as B with hipStreamWriteValue32 / hipStreamWaitValue32 on signal memory
 //      in place of the events
 //   K  as B, the small kernel launched with a hipExtLaunch stop event (no record call)
+//   L  pattern B, 10 steps captured into ONE hipGraph (fork / join per step), launched 40 times
+//   M  pattern D (serial), 10 steps in one graph
 // big = copy of `nbig` MB, small = copy of nbig/15.
 //
 // Build: hipcc -O3 --offload-arch=gfx950 -std=c++17 tools/probe_handover.hip -o tools/probe_handover
@@ -63,8 +65,47 @@ int main(int argc, char ** argv) {
   bool haveflag = (hipExtMallocWithFlags((void **) &flag, 64, hipMallocSignalMemory) == hipSuccess);
   if (haveflag) CHECK(hipMemset(flag, 0, 64));
   uint32_t seq = 0;
-  for (int pat = 0; pat < 11; pat++) {
+  for (int pat = 0; pat < 13; pat++) {
     if (pat == 9 && !haveflag) { printf("pattern J: no signal memory\n"); continue; }
+    if (pat >= 11) {
+      /* graphs: capture 10 steps on S (B forked from it and joined), launch 40 times */
+      hipGraph_t g; hipGraphExec_t ge;
+      CHECK(hipStreamBeginCapture(S, hipStreamCaptureModeGlobal));
+      for (int s = 0; s < 10; s++) {
+	double * x = (s & 1) ? b : a, * y = (s & 1) ? a : b;
+	if (pat == 11) {
+	  CHECK(hipEventRecord(f0, S));
+	  copy(S, x, y, n);
+	  CHECK(hipStreamWaitEvent(B, f0, 0));
+	  copy(B, c, d, ns);
+	  CHECK(hipEventRecord(f1, B));
+	  CHECK(hipStreamWaitEvent(S, f1, 0));
+	}
+	else {
+	  copy(S, x, y, n);
+	  copy(S, c, d, ns);
+	}
+      }
+      CHECK(hipStreamEndCapture(S, &g));
+      CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      for (int rep = 0; rep < 2; rep++) {
+	CHECK(hipDeviceSynchronize());
+	auto t0 = std::chrono::steady_clock::now();
+	for (int k = 0; k < 40; k++) CHECK(hipGraphLaunch(ge, S));
+	auto t1 = std::chrono::steady_clock::now();
+	CHECK(hipDeviceSynchronize());
+	auto t2 = std::chrono::steady_clock::now();
+	if (rep == 1) {
+	  printf("pattern %c  %4zu MB: issued %.2f us/step, finished %.2f us/step\n", 'A' + pat, mb,
+		 1e6*std::chrono::duration<double>(t1 - t0).count()/400,
+		 1e6*std::chrono::duration<double>(t2 - t0).count()/400);
+	  fflush(stdout);
+	}
+      }
+      CHECK(hipGraphExecDestroy(ge));
+      CHECK(hipGraphDestroy(g));
+      continue;
+    }
     for (int rep = 0; rep < 2; rep++) {
       CHECK(hipDeviceSynchronize());
       auto t0 = std::chrono::steady_clock::now();
