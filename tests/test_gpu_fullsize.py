@@ -367,3 +367,59 @@ def test_one_kernel_binary_fluid_step_full_size(n):
         lb.free()
     for x, y in zip(out[0], out[1]):
         assert float((x - y).abs().max()) <= 1e-13 * float(y.abs().max())
+
+
+@pytest.mark.parametrize("nvel,mode_name", [(19, "fused"), (19, "fused_halo"), (27, "fused")])
+def test_a_lattice_whose_population_offsets_pass_2_to_the_31(nvel, mode_name):
+    """512^3 (514^3 = 135.8 M sites with the halo): nsite * p exceeds 2^31 from
+    p = 16 on, the arrays are 20.6 GB (D3Q19) / 29.3 GB (D3Q27) each -- every
+    population offset has to be 64-bit arithmetic (site indices stay 32-bit,
+    as the reference's). The check: a lattice that is a periodic tiling of a
+    64^3 pattern, 8 x 8 x 8 times, must stay that tiling of the 64^3 lattice's
+    own evolution, bit for bit (every site sees the same neighbourhood),
+    distributions and rho, u, in the blocked deferred order (fused) and in the
+    reference's order with the halo shell computed by the kernel
+    (fused_halo)."""
+    import torch
+    import ludwig_amd
+    from ludwig_amd import synthetic
+    mode = {"fused": ludwig_amd.FUSED, "fused_halo": ludwig_amd.FUSED_HALO}[mode_name]
+    small, reps, nsteps = 64, 8, 3
+    big = small * reps
+    fb = (1.0e-6, -2.0e-6, 3.0e-6)
+    m = ludwig_amd.lb.model(nvel)
+
+    def make(n):
+        lb = ludwig_amd.LB(nvel, (n, n, n), 1, mode=mode)
+        lb.relaxation_set("m10", 0.1, 0.3)
+        lb.body_force_set(fb)
+        return lb
+
+    s = make(small)
+    synthetic.fill_device(s, m["cv"], m["wv"], (small,) * 3)
+    pattern = s.f[:, 1:-1, 1:-1, 1:-1].clone()
+    b = make(big)
+    assert b.nsite * (nvel - 1) > 2 ** 31
+    b.f[:, 1:-1, 1:-1, 1:-1] = pattern.repeat(1, reps, reps, reps)
+    torch.cuda.synchronize()
+    b.lb_dirty()
+    hs = ludwig_amd.Hydro(s.nall, s.device)
+    hb = ludwig_amd.Hydro(b.nall, b.device)
+    for _ in range(nsteps):
+        s.step(hs)
+        b.step(hb)
+    s.lb_flush()
+    b.lb_flush()
+    s.synchronize()
+    b.synchronize()
+    torch.cuda.synchronize()
+    want = s.f[:, 1:-1, 1:-1, 1:-1]
+    got = b.f[:, 1:-1, 1:-1, 1:-1]
+    for p in range(nvel):                     # (one population at a time: 1 GB temporaries)
+        assert torch.equal(got[p], want[p].repeat(reps, reps, reps)), p
+    assert torch.equal(hb.rho[1:-1, 1:-1, 1:-1], hs.rho[1:-1, 1:-1, 1:-1].repeat(reps, reps, reps))
+    for a in range(3):
+        assert torch.equal(hb.u[a, 1:-1, 1:-1, 1:-1],
+                           hs.u[a, 1:-1, 1:-1, 1:-1].repeat(reps, reps, reps))
+    s.free()
+    b.free()
