@@ -423,3 +423,63 @@ def test_a_lattice_whose_population_offsets_pass_2_to_the_31(nvel, mode_name):
                            hs.u[a, 1:-1, 1:-1, 1:-1].repeat(reps, reps, reps))
     s.free()
     b.free()
+
+
+def test_one_kernel_binary_fluid_step_beyond_2_to_the_31():
+    """The same tiling property for BASELINE config 4's step as one kernel
+    (lbmi_symmetric_lb_step, halo 2): 512^3 tiled from a 64^3 droplet pattern
+    -- distributions, phi and u after three steps are the tiling of the 64^3
+    lattice's, bit for bit."""
+    import torch
+    import ludwig_amd
+    from ludwig_amd import synthetic
+    small, reps, nsteps, nh = 64, 8, 3, 2
+    big = small * reps
+    a, b, kappa, mob = -0.00625, 0.00625, 0.004, 1.25
+    m = ludwig_amd.lb.model(19)
+    x = torch.arange(small, dtype=torch.float64)
+    r2 = ((x[:, None, None] - 31.5) ** 2 + (x[None, :, None] - 31.5) ** 2
+          + (x[None, None, :] - 31.5) ** 2)
+    phi_pattern = torch.tanh((16.0 - torch.sqrt(r2)) / 1.5)
+
+    def run(n, rep):
+        lb = ludwig_amd.LB(19, (n, n, n), nh, mode=ludwig_amd.FUSED)
+        lb.relaxation_set("m10", 0.1, 0.3)
+        lb.fe_scheme_set(7, 1)
+        return lb
+
+    s = run(small, 1)
+    synthetic.fill_device(s, m["cv"], m["wv"], (small,) * 3)
+    pattern = s.f[:, nh:-nh, nh:-nh, nh:-nh].clone()
+    g = run(big, reps)
+    assert g.nsite * 18 > 2 ** 31
+    g.f[:, nh:-nh, nh:-nh, nh:-nh] = pattern.repeat(1, reps, reps, reps)
+    torch.cuda.synchronize()
+    g.lb_dirty()
+    res = []
+    for lb, rep in ((s, 1), (g, reps)):
+        hy = ludwig_amd.Hydro(lb.nall, lb.device)
+        ua, ub = hy.u, torch.zeros_like(hy.u)
+        pa = torch.zeros(lb.nall, dtype=torch.float64, device=lb.device)
+        pa[nh:-nh, nh:-nh, nh:-nh] = phi_pattern.to(lb.device).repeat(rep, rep, rep)
+        pb = torch.zeros_like(pa)
+        torch.cuda.synchronize()
+        for n in range(nsteps):
+            hy.u = ub if n % 2 == 0 else ua
+            lb.symmetric_lb_step(hy, ua if n % 2 == 0 else ub, a, b, kappa, mob, pa, pb)
+            pa, pb = pb, pa
+        lb.hydro_sync()
+        lb.lb_flush()
+        lb.synchronize()
+        torch.cuda.synchronize()
+        res.append((lb.f[:, nh:-nh, nh:-nh, nh:-nh], pa[nh:-nh, nh:-nh, nh:-nh],
+                    hy.u[:, nh:-nh, nh:-nh, nh:-nh], hy.rho[nh:-nh, nh:-nh, nh:-nh]))
+    (fs, ps, us, rs), (fg, pg, ug, rg) = res
+    for p in range(19):
+        assert torch.equal(fg[p], fs[p].repeat(reps, reps, reps)), p
+    assert torch.equal(pg, ps.repeat(reps, reps, reps))
+    assert torch.equal(rg, rs.repeat(reps, reps, reps))
+    for c in range(3):
+        assert torch.equal(ug[c], us[c].repeat(reps, reps, reps))
+    s.free()
+    g.free()
