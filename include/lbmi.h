@@ -778,6 +778,10 @@ int lbmi_timing_read_detail(lbmi_t * lb, double ms[3], int * nsample);
  *            leaves those the next exchange sends in the send buffers: no pack
  *            and no unpack kernel in a steady-state step (default; needs
  *            x_packed), 0 = pack, messages, unpack into the halo planes;
+ * "eager_oop": 1 = LBMI_MODE_EAGER: lbmi_lb_collide writes the other array and
+ *            swaps the two (default: in-place read-modify-write is the slower
+ *            way to move the same bytes, 1.22 against 1.0 ms at 256^3), 0 = in
+ *            place as the reference;
  * "x_concurrent": 1 = slabs: the two boundary planes run on a third stream
  *            beside the interior launch once the halo has arrived (default),
  *            0 = after it on the compute stream;

@@ -48,6 +48,7 @@ struct lbmi_s {
   hipStream_t bnd_stream;            /* boundary planes of a slab (FUSED) */
   hipEvent_t ev_bnd;                 /* boundary planes of fprime written */
   int x_concurrent;                  /* 1: boundary planes beside the interior */
+  int eager_oop;                     /* EAGER lb_collide out of place + swap (default) */
   hipEvent_t ev_ready;               /* boundary planes of f written */
   hipEvent_t ev_halo;                /* x halo planes of f filled */
 
@@ -505,6 +506,7 @@ int lbmi_create(const lbmi_options_t * opts, lbmi_t ** handle) {
   lb->x_direct = 1;
   lb->halo_fold = 1;
   lb->x_concurrent = 1;
+  lb->eager_oop = 1;
   lb->use_blocked = 1;               /* profiles/r01_blocked_order.txt */
   lb->kp.fe_tiled = 1;
   lb->kp.fe_stripes = 0;             /* profiles/r03_rejected.txt, 6 */
@@ -953,6 +955,10 @@ int lbmi_tune(lbmi_t * lb, const char * key, int value) {
   }
   if (strcmp(key, "halo_fold") == 0) {
     lb->halo_fold = (value != 0);
+    return 0;
+  }
+  if (strcmp(key, "eager_oop") == 0) {
+    lb->eager_oop = (value != 0);
     return 0;
   }
   if (strcmp(key, "x_concurrent") == 0) {
@@ -2100,7 +2106,15 @@ static int lbmi_lb_collide_dev(lbmi_t * lb, const lbmi_hydro_dev_t * hp) {
     int ifail = lbmi_unblock(lb);
     if (ifail) return ifail;
   }
-  lb->xsend_valid = 0; lb->halo_fresh = 0;               /* f changes in place */
+  lb->xsend_valid = 0; lb->halo_fresh = 0;               /* f changes */
+  if (h.noise == NULL && lb->opts.ndist == 1 && lb->eager_oop) {
+    /* out of place into the other array, then the two change roles (as
+     * lb_propagation's swap): in-place read-modify-write is the slower way to
+     * move the same bytes here (lbmi_kernels.hip, k_collide_to) */
+    KCHECK(lbmi_k_collide_to(&lb->kp, lb->f, lb->fprime, &h, lb->stream));
+    lbmi_swapf(lb);
+    return 0;
+  }
   KCHECK(lbmi_k_collide(&lb->kp, lb->f, &h, lb->stream));
 
   return 0;

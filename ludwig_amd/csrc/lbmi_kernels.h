@@ -92,6 +92,9 @@ typedef struct lbmi_xbuf_s {
 
 int lbmi_k_collide(const lbmi_kparam_t * kp, double * f,
 		   const lbmi_hydro_dev_t * h, void * stream);
+/* out of place over the whole array (sites that do not collide are copied); no fluctuations */
+int lbmi_k_collide_to(const lbmi_kparam_t * kp, const double * f, double * fo,
+		      const lbmi_hydro_dev_t * h, void * stream);
 
 int lbmi_k_propagate(const lbmi_kparam_t * kp, const double * f,
 		     double * fprime, void * stream);
