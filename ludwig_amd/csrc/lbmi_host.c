@@ -2783,6 +2783,36 @@ int lbmi_lb_collide_fe(lbmi_t * lb, const lbmi_hydro_t * hydro,
     return lbmi_fail(LBMI_ERR_STATE, "lb_collide after lb_halo without "
 		     "lb_propagation");
   }
+  if (lb->pending_prop && lb->pending_halo && !lbmi_inplace(lb) &&
+      (lb->opts.mode == LBMI_MODE_FUSED_HALO ||
+       (lb->opts.mode == LBMI_MODE_FUSED && lb->opts.cartsz == 1 && !lb->have_comm))) {
+    /* the propagation of the step before folded into this collision: one pass
+     * over f. FUSED on one rank: every direction wrapped by index;
+     * FUSED_HALO: the halo swap has been done, pull from the array as it is. */
+    const int wrap = (lb->opts.mode == LBMI_MODE_FUSED) ? lbmi_wrapmask(lb) : 0;
+    ifail = lbmi_hydro_materialise(lb);      /* (rho, u an earlier collision owes) */
+    if (ifail) return ifail;
+    if (lb->blocked) {
+      ifail = lbmi_unblock(lb);
+      if (ifail) return ifail;
+    }
+    lb->hydro_stale = 0;
+    lbmi_known_zero_drop(lb, h.rho);
+    lbmi_known_zero_drop(lb, h.u);
+    ifail = lbmi_time_begin(lb);
+    if (ifail) return ifail;
+    KCHECK(lbmi_k_propagate_collide_fe(&lb->kp, lb->f, lb->fprime, &h, fe->a, fe->b,
+				       fe->kappa, fe->phi, fe->grad, fe->delsq, wrap,
+				       lb->stream));
+    ifail = lbmi_time_end(lb);
+    if (ifail) return ifail;
+    lbmi_swapf(lb);
+    lb->pending_prop = 0;
+    lb->pending_halo = 0;
+    lb->halo_done = 0;
+    lb->xsend_valid = 0; lb->halo_fresh = 0;
+    return 0;
+  }
   ifail = lbmi_lb_flush(lb);
   if (ifail) return ifail;
   lb->xsend_valid = 0; lb->halo_fresh = 0;

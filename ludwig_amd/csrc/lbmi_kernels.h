@@ -231,6 +231,14 @@ int lbmi_k_collide_fe(const lbmi_kparam_t * kp, double * f,
 		      const lbmi_hydro_dev_t * h, double a, double b,
 		      double kappa, const double * phi, const double * grad,
 		      const double * delsq, void * stream);
+/* propagation fused with that collision, f -> fp, SoA; wrapmask: directions
+ * wrapped by index (0: pull from the halo as it is) */
+int lbmi_k_propagate_collide_fe(const lbmi_kparam_t * kp, const double * f,
+				double * fp, const lbmi_hydro_dev_t * h,
+				double a, double b, double kappa,
+				const double * phi, const double * grad,
+				const double * delsq, int wrapmask,
+				void * stream);
 
 /* Two distributions (symmetric_lb): f2[(n*nvel + p)*nsite + i] */
 /* pull != 0 / src != f2: a propagation is pending on the array read:

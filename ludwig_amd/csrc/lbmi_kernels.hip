@@ -1094,6 +1094,69 @@ void k_propagate_collide(lbmi_kparam_t kp, const double * __restrict__ f,
   });
 }
 
+/* k_propagate_collide_fe: propagation(t) fused with the collision(t+1) of
+ * fe->use_stress_relaxation (collision.c:413-429: the symmetric stress of the
+ * site, from phi and the field_grad_compute arrays, joins the equilibrium
+ * stress) -- k_collide_fe's arithmetic behind the pull of k_propagate_collide,
+ * SoA -> SoA; WRAP: the periodic directions by index (FUSED on one rank),
+ * else from the halo as it is (FUSED_HALO). Before it lbmi_lb_collide_fe
+ * flushed every step: three passes over f where this is one. */
+
+template <int NVEL, int SCHEME, bool WRAP>
+__global__ __launch_bounds__(BLOCK, LBMI_WAVES)
+void k_propagate_collide_fe(lbmi_kparam_t kp, const double * __restrict__ f,
+			    double * __restrict__ fp, lbmi_hydro_dev_t h,
+			    double qa, double qb, double qkappa,
+			    const double * __restrict__ phi,
+			    const double * __restrict__ grad,
+			    const double * __restrict__ delsq,
+			    int wrapmask, int i0, int i1, unsigned nblk) {
+
+  unsigned lb;
+  if (!logical_block(nblk, lb, (unsigned) kp.xcd_group)) return;
+  const int i = (i0/LBMI_ALIGN)*LBMI_ALIGN + (int) (lb*BLOCK + threadIdx.x);
+  if (i < i0 || i >= i1) return;
+
+  const lbmi_xbuf_t none = {nullptr, nullptr, nullptr, nullptr};
+  const size_t ns = (size_t) kp.nsite;
+  PulledSite<NVEL> ps;
+  pc_pull<NVEL, WRAP, false, false>(kp, f, wrapmask, i, ps, none);
+
+  bool active = ps.s.interior;
+  if (h.status) active = active && (h.status[i] == 0);      /* collision.c:299-304 */
+  if (active) {
+    double frc[3] = {kp.fbody[0], kp.fbody[1], kp.fbody[2]};
+    if (h.force) {
+      frc[0] += h.force[i];
+      frc[1] += h.force[hstride(kp, h) + i];
+      frc[2] += h.force[2*hstride(kp, h) + i];
+    }
+    Relax rx = site_relax<SCHEME>(kp, h, i);
+    double rho, u[3];
+    double sth[6];
+    {
+      /* P_ab = p0 delta_ab + kappa d_a phi d_b phi (symmetric.c:371-420) */
+      const double ph = phi[i], d2 = delsq[i];
+      const size_t gs = (h.gstride > 0) ? (size_t) h.gstride : ns;
+      const double g0 = grad[i], g1 = grad[gs + i], g2 = grad[2*gs + i];
+      const double p0 = 0.5*qa*ph*ph + 0.75*qb*ph*ph*ph*ph - qkappa*ph*d2
+	- 0.5*qkappa*(g0*g0 + g1*g1 + g2*g2);
+      sth[0] = p0 + qkappa*g0*g0; sth[1] = qkappa*g0*g1; sth[2] = qkappa*g0*g2;
+      sth[3] = p0 + qkappa*g1*g1; sth[4] = qkappa*g1*g2;
+      sth[5] = p0 + qkappa*g2*g2;
+    }
+    const double (&sthr)[6] = sth;
+    collide_site_impl<NVEL, SCHEME, true>(ps.fl, frc, rx, sthr, rho, u);
+    if (h.rho) h.rho[i] = rho;
+    if (h.u) {
+      h.u[i] = u[0];
+      h.u[hstride(kp, h) + i] = u[1];
+      h.u[2*hstride(kp, h) + i] = u[2];
+    }
+  }
+  static_for<0, NVEL>([&](auto P) { stf(&fp[ns*P + i], ps.fl[P]); });
+}
+
 /* k_propagate_collide_halo: the step of LBMI_MODE_FUSED_HALO on one rank with
  * the halo swap of its OWN result folded in. f is the reference's
  * post-collision state with its halo (whatever bounced back into it included);
@@ -3553,6 +3616,54 @@ extern "C" int lbmi_k_collide_fe(const lbmi_kparam_t * kp, double * f,
   hipStream_t st = (hipStream_t) stream;
   if (kp->nvel == 19) return launch_collide_fe<19>(*kp, f, *h, a, b, kappa, phi, grad, delsq, st);
   if (kp->nvel == 27) return launch_collide_fe<27>(*kp, f, *h, a, b, kappa, phi, grad, delsq, st);
+  return (int) hipErrorInvalidValue;
+}
+
+template <int NVEL, bool WRAP>
+static int launch_pc_fe(const lbmi_kparam_t & kp, const double * f, double * fp,
+			const lbmi_hydro_dev_t & h, double a, double b, double kappa,
+			const double * phi, const double * grad, const double * delsq,
+			int wrapmask, hipStream_t st) {
+  Range1D r = interior_range(kp);
+  dim3 grid(r.grid), block(BLOCK);
+  switch (kp.scheme) {
+  case LBMI_M10:
+    hipLaunchKernelGGL((k_propagate_collide_fe<NVEL, LBMI_M10, WRAP>), grid, block, r.lds, st,
+		       kp, f, fp, h, a, b, kappa, phi, grad, delsq, wrapmask, r.i0, r.i1, r.nblk);
+    break;
+  case LBMI_BGK:
+    hipLaunchKernelGGL((k_propagate_collide_fe<NVEL, LBMI_BGK, WRAP>), grid, block, r.lds, st,
+		       kp, f, fp, h, a, b, kappa, phi, grad, delsq, wrapmask, r.i0, r.i1, r.nblk);
+    break;
+  case LBMI_TRT:
+    if constexpr (NVEL == 19) {
+      hipLaunchKernelGGL((k_propagate_collide_fe<NVEL, LBMI_TRT, WRAP>), grid, block, r.lds, st,
+			 kp, f, fp, h, a, b, kappa, phi, grad, delsq, wrapmask, r.i0, r.i1, r.nblk);
+      break;
+    }
+    return (int) hipErrorInvalidValue;
+  default:
+    return (int) hipErrorInvalidValue;
+  }
+  return (int) hipGetLastError();
+}
+
+extern "C" int lbmi_k_propagate_collide_fe(const lbmi_kparam_t * kp, const double * f,
+					   double * fp, const lbmi_hydro_dev_t * h,
+					   double a, double b, double kappa,
+					   const double * phi, const double * grad,
+					   const double * delsq, int wrapmask,
+					   void * stream) {
+  hipStream_t st = (hipStream_t) stream;
+  if (f == fp) return (int) hipErrorInvalidValue;
+  if (kp->nvel == 19) {
+    return wrapmask ? launch_pc_fe<19, true>(*kp, f, fp, *h, a, b, kappa, phi, grad, delsq, wrapmask, st)
+      : launch_pc_fe<19, false>(*kp, f, fp, *h, a, b, kappa, phi, grad, delsq, 0, st);
+  }
+  if (kp->nvel == 27) {
+    return wrapmask ? launch_pc_fe<27, true>(*kp, f, fp, *h, a, b, kappa, phi, grad, delsq, wrapmask, st)
+      : launch_pc_fe<27, false>(*kp, f, fp, *h, a, b, kappa, phi, grad, delsq, 0, st);
+  }
   return (int) hipErrorInvalidValue;
 }
 

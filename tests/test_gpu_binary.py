@@ -163,9 +163,13 @@ def test_binary_rejections():
 from tests.common import golden_relax_names  # noqa: E402
 
 
-@pytest.mark.parametrize("mode", [0, 1], ids=["eager", "fused"])
+@pytest.mark.parametrize("mode", [0, 1, 3], ids=["eager", "fused", "fused_halo"])
 @pytest.mark.parametrize("name", golden_relax_names())
 def test_stress_relaxation_vs_reference(name, mode):
+    """fe->use_stress_relaxation (collision.c:413-429). fused / fused_halo:
+    from the second step on the propagation of the step before runs inside
+    the collision (k_propagate_collide_fe: one pass over f; it used to flush
+    every step) -- lbmi_lb_state says so."""
     import ludwig_amd
     g = load_golden(name)
     meta = g["meta"]
@@ -180,10 +184,12 @@ def test_stress_relaxation_vs_reference(name, mode):
     assert relmax(interior(_host(lb, hy.rho), 1), interior(g["rho"], 1)) < 1e-12
     assert relmax(interior(_host(lb, hy.u), 1), interior(g["u"], 1)) < 1e-12
     lb.lb_memcpy_h2d(g["f0"])
-    for _ in range(meta["nsteps"]):
+    for n in range(meta["nsteps"]):
         lb.lb_collide_fe(hy, meta["a"], meta["b"], meta["kappa"], phi, grad, delsq)
         lb.lb_halo()
         lb.lb_propagation()
+        # deferred modes: the propagation stays pending for the next collision
+        assert lb.state()[1] == (0 if mode == 0 else 1)
     assert relmax(interior(lb.lb_memcpy_d2h(), 1), interior(g["f_final"], 1)) < 1e-12
     lb.free()
 
