@@ -428,8 +428,10 @@ int lbmi_lb_phi_to_field(lbmi_t * lb, double * phi);
 /* lb_collide with fe->use_stress_relaxation (collision.c:413-429; force
  * method relaxation_symm, ludwig.c:1235-1237) for the symmetric free energy
  * and ONE distribution: the stress of fe joins the equilibrium stress (the
- * mobility member is not used). In-place on the canonical state in every
- * mode (a deferred FUSED state is flushed first). */
+ * mobility member is not used). EAGER: in place on the canonical state.
+ * FUSED_HALO, and FUSED on one rank: the pending propagation of the step
+ * before runs inside this collision (one pass over f, SoA -> SoA; rho and u
+ * are stored by every such collision). FUSED on slabs: flushed first. */
 int lbmi_lb_collide_fe(lbmi_t * lb, const lbmi_hydro_t * hydro,
 		       const lbmi_fe_symm_t * fe);
 int lbmi_lb_collide_binary(lbmi_t * lb, const lbmi_hydro_t * hydro,
