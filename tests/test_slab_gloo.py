@@ -360,3 +360,35 @@ def test_schedule_pairs_up_for_any_ring_size():
                             if packed and world > 2:
                                 assert peer == ((r + 1) % world if s["buffer"] == "sendhi"
                                                 else (r - 1) % world)
+
+
+def test_schedule_pairs_up_on_grids_of_ranks():
+    """Host-only: on grids of up to 3 x 3 x 3 ranks (LBMI_CART_GENERAL) every
+    send of the schedule of a decomposed direction meets, in issue order, a
+    receive of the same length on the peer, into the buffer the layout says;
+    the peers are the Cartesian neighbours along that direction and nobody
+    else; a direction with one rank has no schedule."""
+    for nvel in (19, 27):
+        for grid in ((2, 2, 1), (1, 2, 2), (2, 1, 3), (2, 2, 2), (3, 3, 1), (3, 2, 3), (3, 3, 3)):
+            world = grid[0] * grid[1] * grid[2]
+            decs = [ludwig_amd.CartDecomposition((6, 6, 6), grid, r) for r in range(world)]
+            for dim in range(3):
+                if grid[dim] < 2:
+                    with pytest.raises(ludwig_amd.LbmiError):
+                        ludwig_amd.x_schedule(nvel, decs[0].nlocal, 1, world, 0, cartgrid=grid,
+                                              cartcoords=decs[0].coords, dim=dim)
+                    continue
+                sched = [ludwig_amd.x_schedule(nvel, d.nlocal, 1, world, d.rank, cartgrid=grid,
+                                               cartcoords=d.coords, dim=dim) for d in decs]
+                for r, d in enumerate(decs):
+                    below, above = d.neighbours(dim)
+                    assert {op["peer"] for op in sched[r]} == {below, above}
+                    for peer in (below, above):
+                        sends = [op for op in sched[r] if op["kind"] == "send" and op["peer"] == peer]
+                        recvs = [op for op in sched[peer] if op["kind"] == "recv" and op["peer"] == r]
+                        assert len(sends) == len(recvs) and sends
+                        for s, v in zip(sends, recvs):
+                            assert s["count"] == v["count"]
+                            assert v["buffer"] == {"sendhi": "recvlo", "sendlo": "recvhi"}[s["buffer"]]
+                            if grid[dim] > 2:
+                                assert peer == (above if s["buffer"] == "sendhi" else below)
