@@ -735,3 +735,94 @@ def test_field_halo_of_two_layers_on_a_cartesian_decomposition(grid):
         idx = [np.arange(off[d] - nh, off[d] + nl[d] + nh) % ntotal[d] for d in range(3)]
         want = glob[:, idx[0][:, None, None], idx[1][None, :, None], idx[2][None, None, :]]
         assert np.array_equal(a, want)
+
+
+@pytest.mark.parametrize("mode_name", ["eager", "fused_halo", "fused"])
+@pytest.mark.parametrize("dim", [0, 2], ids=["x", "z"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_relaxed_stress_collision_on_slabs(world, dim, mode_name):
+    """lb_collide with fe->use_stress_relaxation (lbmi_lb_collide_fe) on slabs:
+    in `halo` the pending propagation runs inside the collision, pulling from
+    the halo planes the exchange has filled (k_propagate_collide_fe without
+    index wrap); in `fused` on slabs the deferred state is flushed first; the
+    joined slabs are the single domain's distributions, rho and u (whose steps
+    are checked against the compiled reference's fixtures in
+    test_gpu_binary.py)."""
+    import ludwig_amd
+    import torch
+    mode = {"eager": ludwig_amd.EAGER, "fused_halo": ludwig_amd.FUSED_HALO,
+            "fused": ludwig_amd.FUSED}[mode_name]
+    nvel, ntotal, nsteps = 19, (12, 6, 12), 5
+    a, b, kappa = -0.00625, 0.00625, 0.004
+    rng = np.random.default_rng(21)
+    nall = tuple(n + 2 for n in ntotal)
+    phi = 0.1 * rng.standard_normal(nall)
+    grad = 0.01 * rng.standard_normal((3,) + nall)
+    delsq = 0.01 * rng.standard_normal(nall)
+    p = lbo.make_param(nvel, ntotal, 1, "m10", 0.1, 0.3, 1.0, FBODY)
+    f0 = lbo.init_synthetic(p)
+
+    def run(lb, sl):
+        dev = lb.device
+        hy = ludwig_amd.Hydro(lb.nall, dev)
+        ph = torch.from_numpy(np.ascontiguousarray(phi[sl[1:]])).to(dev)
+        gr = torch.from_numpy(np.ascontiguousarray(grad[sl])).to(dev)
+        d2 = torch.from_numpy(np.ascontiguousarray(delsq[sl[1:]])).to(dev)
+        lb.lb_memcpy_h2d(np.ascontiguousarray(f0[sl]))
+        torch.cuda.synchronize()
+        return hy, ph, gr, d2
+
+    def steps(lb, hy, ph, gr, d2):
+        for _ in range(nsteps):
+            lb.lb_collide_fe(hy, a, b, kappa, ph, gr, d2)
+            lb.lb_halo()
+            lb.lb_propagation()
+
+    lb = ludwig_amd.LB(nvel, ntotal, 1, mode=mode)
+    lb.relaxation_set("m10", 0.1, 0.3)
+    lb.body_force_set(FBODY)
+    whole = (slice(None),) * 4
+    hy, ph, gr, d2 = run(lb, whole)
+    steps(lb, hy, ph, gr, d2)
+    ref = (interior(lb.lb_memcpy_d2h(), 1).copy(), interior(hy.rho.cpu().numpy(), 1).copy(),
+           interior(hy.u.cpu().numpy(), 1).copy())
+    lb.free()
+
+    ring = ludwig_amd.Ring(world)
+    out = [None] * world
+    err = []
+    start = threading.Barrier(world)
+
+    def rank_main(rank):
+        try:
+            dec = ludwig_amd.SlabDecomposition(ntotal, world, rank, 1, dim=dim)
+            lb = ludwig_amd.LB(nvel, dec.nlocal, 1, mode=mode, cartsz=world, cartrank=rank,
+                               own_stream=True, cartdim=dim)
+            lb.relaxation_set("m10", 0.1, 0.3)
+            lb.body_force_set(FBODY)
+            lb.comm_init_ring(ring)
+            sl = [slice(None)] * 4
+            sl[1 + dim] = slice(dec.noffset[dim], dec.noffset[dim] + dec.nlocal[dim] + 2)
+            hy, ph, gr, d2 = run(lb, tuple(sl))
+            start.wait()
+            steps(lb, hy, ph, gr, d2)
+            f = interior(lb.lb_memcpy_d2h(), 1).copy()
+            lb.synchronize()
+            torch.cuda.synchronize()
+            out[rank] = (f, interior(hy.rho.cpu().numpy(), 1), interior(hy.u.cpu().numpy(), 1))
+            start.wait()
+            lb.free()
+        except Exception as e:           # noqa: BLE001
+            err.append((rank, repr(e)))
+            ring.abort()
+            start.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not err, err
+    ring.free()
+    for k in range(3):
+        assert relmax(_join(out, k, dim), ref[k]) < 1e-13, k
