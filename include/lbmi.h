@@ -431,7 +431,8 @@ int lbmi_lb_phi_to_field(lbmi_t * lb, double * phi);
  * mobility member is not used). EAGER: in place on the canonical state.
  * FUSED_HALO, and FUSED on one rank: the pending propagation of the step
  * before runs inside this collision (one pass over f, SoA -> SoA; rho and u
- * are stored by every such collision). FUSED on slabs: flushed first. */
+ * are stored by every such collision). FUSED on several ranks: the halo swap
+ * that mode had only noted is done first, then the same. */
 int lbmi_lb_collide_fe(lbmi_t * lb, const lbmi_hydro_t * hydro,
 		       const lbmi_fe_symm_t * fe);
 int lbmi_lb_collide_binary(lbmi_t * lb, const lbmi_hydro_t * hydro,

@@ -2784,16 +2784,22 @@ int lbmi_lb_collide_fe(lbmi_t * lb, const lbmi_hydro_t * hydro,
 		     "lb_propagation");
   }
   if (lb->pending_prop && lb->pending_halo && !lbmi_inplace(lb) &&
-      (lb->opts.mode == LBMI_MODE_FUSED_HALO ||
-       (lb->opts.mode == LBMI_MODE_FUSED && lb->opts.cartsz == 1 && !lb->have_comm))) {
+      (lb->opts.mode == LBMI_MODE_FUSED_HALO || lb->opts.mode == LBMI_MODE_FUSED)) {
     /* the propagation of the step before folded into this collision: one pass
      * over f. FUSED on one rank: every direction wrapped by index;
-     * FUSED_HALO: the halo swap has been done, pull from the array as it is. */
-    const int wrap = (lb->opts.mode == LBMI_MODE_FUSED) ? lbmi_wrapmask(lb) : 0;
+     * FUSED_HALO: the halo swap has been done, pull from the array as it is;
+     * FUSED on several ranks: the halo swap it has only noted, now, then the
+     * same. */
+    const int ranks = (lb->opts.cartsz > 1 || lb->have_comm);
+    const int wrap = (lb->opts.mode == LBMI_MODE_FUSED && !ranks) ? lbmi_wrapmask(lb) : 0;
     ifail = lbmi_hydro_materialise(lb);      /* (rho, u an earlier collision owes) */
     if (ifail) return ifail;
     if (lb->blocked) {
       ifail = lbmi_unblock(lb);
+      if (ifail) return ifail;
+    }
+    if (lb->opts.mode == LBMI_MODE_FUSED && ranks && !lb->halo_done) {
+      ifail = lbmi_halo(lb, lb->f, lb->opts.halo_scheme);
       if (ifail) return ifail;
     }
     lb->hydro_stale = 0;

@@ -744,7 +744,8 @@ def test_relaxed_stress_collision_on_slabs(world, dim, mode_name):
     """lb_collide with fe->use_stress_relaxation (lbmi_lb_collide_fe) on slabs:
     in `halo` the pending propagation runs inside the collision, pulling from
     the halo planes the exchange has filled (k_propagate_collide_fe without
-    index wrap); in `fused` on slabs the deferred state is flushed first; the
+    index wrap); in `fused` on slabs the halo swap that mode had only noted is
+    done first, then the same; the
     joined slabs are the single domain's distributions, rho and u (whose steps
     are checked against the compiled reference's fixtures in
     test_gpu_binary.py)."""
